@@ -1,0 +1,109 @@
+"""Deterministic name-keyed weight synthesiser.
+
+There is no network for ``timm.create_model(..., pretrained=True)`` (cav_mae_base.py:236) or the
+``jx_vit_base_patch16_224_in21k`` file (:240), so weights are synthesised.  Every tensor is generated
+from a Philox stream keyed by (seed, crc32(canonical name)); the same call reproduces the same
+248 M parameters on the build container and on the GPU box without shipping them.
+
+mode='init'   : reference-like initial state - LayerNorm 1/0, zero decoder pos/mask/modality tokens
+                (:312-314,336-337), N(0, 0.02) weights, and the structural identities of the ctor:
+                norm*_a/_v == norm* (:265-269), patch_embed_a = RGB-mean of patch_embed (:292-293),
+                pos_embed_a = nearest interpolation of pos_embed[:,1:] (:298), ast_base == vit_base (:303),
+                mm_layer_1/2 == vit_base.blocks[-1] (:306-307).
+mode='random' : every tensor independent and non-trivial (used by parity tests so that selecting the
+                wrong LayerNorm set / tower / token is visible).
+"""
+import zlib
+
+import numpy as np
+import torch
+
+from .config import AVSiamConfig
+from .param_spec import alias_of, build_spec
+
+
+def _stream(seed: int, name: str):
+    key = zlib.crc32(alias_of(name).encode())
+    return np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, key]))
+
+
+def _random_tensor(info, seed):
+    g = _stream(seed, info.name)
+    n = int(np.prod(info.shape))
+    x = g.standard_normal(n, dtype=np.float32)
+    if info.kind == "ln_w":
+        x = 1.0 + 0.1 * x
+    elif info.kind == "ln_b":
+        x = 0.05 * x
+    elif info.kind in ("pos", "token"):
+        x = 0.02 * x
+    elif info.kind == "bias":
+        x = 0.02 * x
+    else:  # linear_w / conv_w
+        x = 0.02 * x
+    return torch.from_numpy(x.reshape(info.shape))
+
+
+def synth_state(cfg: AVSiamConfig, seed: int = 0, mode: str = "init", include_dead: bool = True):
+    """Returns {name: fp32 tensor} for the unique tensors of the schema."""
+    spec = build_spec(cfg)
+    out = {}
+    for info in spec:
+        if not include_dead and info.live == 0:
+            continue
+        if mode == "random":
+            out[info.name] = _random_tensor(info, seed)
+            continue
+        if info.kind == "ln_w":
+            out[info.name] = torch.ones(info.shape)
+        elif info.kind == "ln_b":
+            out[info.name] = torch.zeros(info.shape)
+        elif info.zero_init:
+            out[info.name] = torch.zeros(info.shape)
+        else:
+            out[info.name] = _random_tensor(info, seed)
+    if mode == "init":
+        _tie_init(out, cfg)
+    return out
+
+
+def _tie_init(st, cfg):
+    """Structural identities of the reference constructor (see module docstring)."""
+    v = "vit_base."
+    if v + "patch_embed_a.proj.weight" in st:
+        st[v + "patch_embed_a.proj.weight"] = st[v + "patch_embed.proj.weight"].mean(dim=1, keepdim=True).clone()
+        st[v + "patch_embed_a.proj.bias"] = st[v + "patch_embed.proj.bias"].clone()
+        pe = st[v + "pos_embed"][:, 1:].permute(0, 2, 1)
+        st[v + "pos_embed_a"] = torch.nn.functional.interpolate(pe, size=[cfg.audio_tokens]).permute(0, 2, 1).contiguous()
+    for k in list(st.keys()):
+        if k.startswith(v):
+            a = "ast_base." + k[len(v):]
+            if a in st:
+                st[a] = st[k].clone()
+    last = f"vit_base.blocks.{cfg.depth - 1}."
+    for k in list(st.keys()):
+        if k.startswith(last):
+            for mm in ("mm_layer_1.", "mm_layer_2."):
+                if mm + k[len(last):] in st:
+                    st[mm + k[len(last):]] = st[k].clone()
+    for k in ("my_patch_embed.proj.weight", "my_patch_embed.proj.bias"):
+        if k in st:
+            st[k] = st["vit_base." + k[len("my_"):]].clone()
+    for k in ("my_patch_embed_a.proj.weight", "my_patch_embed_a.proj.bias"):
+        if k in st:
+            st[k] = st["vit_base." + k[len("my_"):]].clone()
+
+
+def synth_inputs(cfg: AVSiamConfig, batch: int, seed: int = 87, constant: float = None):
+    """AudioSet-shaped synthetic pair: a ~ N(0,1) [B, target_length, 128] (fbank after normalisation,
+    /root/reference/src/dataloader.py:505-506), v ~ N(0,1) [B,(T,)3,224,224] (:152-155).
+    ``constant`` reproduces the loader's degenerate fallback tensors (:385,424)."""
+    g = np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, 0xA5A5]))
+    a_shape = (batch, cfg.audio_len, cfg.n_mels)
+    v_shape = (batch, cfg.in_chans, cfg.img_size, cfg.img_size) if cfg.frames == 1 else \
+        (batch, cfg.frames, cfg.in_chans, cfg.img_size, cfg.img_size)
+    if constant is not None:
+        return torch.full(a_shape, constant), torch.full(v_shape, constant)
+    a = torch.from_numpy(g.standard_normal(int(np.prod(a_shape)), dtype=np.float32).reshape(a_shape))
+    v = torch.from_numpy(g.standard_normal(int(np.prod(v_shape)), dtype=np.float32).reshape(v_shape))
+    return a, v

@@ -1,0 +1,71 @@
+"""The oracle (oracle/ref_cpu.py) against golden vectors produced by the unmodified reference
+(oracle/gen_golden.py, run in the build container).  fp32 vs fp32, identical mask plan:
+losses rel 1e-5, gradients rel 1e-4 (summation order only) - SURVEY.md section 8(c)."""
+import numpy as np
+import pytest
+import torch
+
+from avsiam_amd.config import AVSiamConfig
+from avsiam_amd.weights import synth_inputs, synth_state
+from oracle import ref_cpu
+from tests.helpers import check_grads_against_golden, golden_plan, load_golden, sample_positions
+
+
+def _run(name):
+    d = load_golden(name)
+    cfg = AVSiamConfig()
+    B = int(d["batch"])
+    const = float(d["constant"])
+    a, v = synth_inputs(cfg, B, int(d["input_seed"]), None if np.isnan(const) else const)
+    P = {k: t.clone().requires_grad_(True) for k, t in synth_state(cfg, int(d["weight_seed"]), "random").items()}
+    plan = golden_plan(d)
+    extras = {}
+    mae = str(d["which"]) == "mae"
+    out = ref_cpu.forward(P, cfg, a, v, plan, mae_loss_weight=1 if mae else 0,
+                          contrast_loss_weight=0 if mae else 1, extras=extras)
+    out[0].backward()
+    return d, out, extras, {k: p.grad for k, p in P.items()}
+
+
+@pytest.mark.parametrize("name", ["c_w1_b4", "m_w1_b4", "m_w1_b2_const"])
+def test_oracle_matches_reference(name):
+    torch.set_num_threads(8)
+    d, out, extras, grads = _run(name)
+    got = np.array([out[i].item() for i in (0, 1, 2, 3, 4, 7)])
+    np.testing.assert_allclose(got, d["out_scalars"], rtol=1e-5, atol=1e-6)
+    if str(d["which"]) == "mae":
+        np.testing.assert_array_equal(out[5].numpy(), d["mask_a"])
+        np.testing.assert_array_equal(out[6].numpy(), d["mask_v"])
+        for k in ("pred_a", "pred_v"):
+            p = extras[k].detach().double().reshape(-1)
+            assert abs(p.norm().item() - d[k + "_l2"]) <= 1e-5 * d[k + "_l2"]
+            s = np.array([p[i].item() for i in sample_positions(k, p.numel(), 64)])
+            np.testing.assert_allclose(s, d[k + "_samples"], rtol=1e-4, atol=1e-5)
+    else:
+        assert out[5] is None and out[6] is None
+        np.testing.assert_allclose(extras["logits"].detach().numpy(), d["logits"], rtol=1e-4, atol=2e-4)
+    check_grads_against_golden(d, grads, rel_l2=1e-4)
+
+
+def test_schema_matches_reference(golden_dir):
+    import json
+    import os
+    from avsiam_amd.param_spec import build_spec, state_dict_keys, alias_of
+    with open(os.path.join(golden_dir, "schema.json")) as f:
+        sch = json.load(f)
+    cfg = AVSiamConfig()
+    keys = state_dict_keys(cfg)
+    assert len(keys) == sch["n_keys"] == 963
+    assert sorted(keys) == sorted(sch["shapes"].keys())
+    spec = {s.name: s for s in build_spec(cfg)}
+    assert len(spec) == 723
+    assert sum(int(np.prod(s.shape)) for s in spec.values()) == sch["n_params"] == 248035494
+    for k in keys:
+        assert list(spec[alias_of(k)].shape) == sch["shapes"][k], k
+    # LayerNorm eps: 1e-5 everywhere except vit_base.norm / norm_a (and their ast_base copies) = 1e-6
+    for n, e in sch["ln_eps"].items():
+        want = 1e-6 if n in ("vit_base.norm", "vit_base.norm_a", "ast_base.norm", "ast_base.norm_a") else 1e-5
+        assert e == want, (n, e)
+    # live sets: 86,426,880 (contrastive pass) and 212,123,392 (MAE pass)
+    assert sum(int(np.prod(s.shape)) for s in spec.values() if s.live & 1) == 86426880
+    assert sum(int(np.prod(s.shape)) for s in spec.values() if s.live & 2) == 212123392
