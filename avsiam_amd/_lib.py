@@ -1,0 +1,88 @@
+"""ctypes loader of libavsiam_hip.so - the only door from Python into the HIP kernels.
+
+Signatures are generated from include/avsiam_hip.h so the header is the single source of truth.  There is no
+fallback: if the library is missing (or a call fails) this raises - the product path never runs on anything
+but the hand-written gfx950 kernels.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "avsiam_hip.h")
+LIB_PATH = os.path.join(_HERE, "csrc", "libavsiam_hip.so")
+
+_lib = None
+_protos = None
+
+
+class AvsiamHipError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtype, ...])} as strings 'ptr' | 'int' | 'll' | 'float' | 'str'."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(avs_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        kinds = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a or a.startswith("avs_stream_t"):
+                    kinds.append("ptr")
+                elif a.startswith("long long"):
+                    kinds.append("ll")
+                elif a.startswith("float"):
+                    kinds.append("float")
+                elif a.startswith("int"):
+                    kinds.append("int")
+                else:
+                    raise ValueError(f"unparsed argument '{a}' of {name}")
+        protos[name] = ("str" if "char" in ret else "int", kinds)
+    return protos
+
+
+_CT = {"ptr": ctypes.c_void_p, "int": ctypes.c_int, "ll": ctypes.c_longlong, "float": ctypes.c_float}
+
+
+def load():
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AvsiamHipError(f"{LIB_PATH} not found - build it with `python -m avsiam_amd.build` "
+                             "(there is no CPU or PyTorch fallback for the hot path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (ret, kinds) in _protos.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_char_p if ret == "str" else ctypes.c_int
+        fn.argtypes = [_CT[k] for k in kinds]
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an entry point; torch tensors are passed as their data_ptr(), None as NULL."""
+    lib = load()
+    fn = getattr(lib, name)
+    conv = []
+    for a in args:
+        if a is None:
+            conv.append(None)
+        elif hasattr(a, "data_ptr"):
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
+    rc = fn(*conv)
+    if rc != 0:
+        raise AvsiamHipError(f"{name} failed ({rc}): {lib.avs_last_error().decode()}")
+    return rc
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

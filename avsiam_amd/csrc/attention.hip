@@ -1,0 +1,412 @@
+// k4 - variable-length multi-head self-attention, forward and backward, for the packed token matrix.
+//
+// Replaces F.scaled_dot_product_attention inside Attention.forward
+// (/root/reference/src/models/cav_mae_base.py:60-68: qkv.reshape(B,N,3,H,hd) -> softmax(q k^T / sqrt(hd)) v,
+// no mask, dropout 0) and its autograd backward, for ragged sequences: the reference calls the block once per
+// multi-ratio group (:554-558); here every sequence of a pass lives in one [rows, 3*D] qkv matrix and a
+// (sequence start, length, q0) triple per 128-row tile drives the grid.
+//
+// Structure (gfx950, wave64, v_mfma_f32_32x32x16_bf16, fp32 softmax):
+//   * the score tile is computed TRANSPOSED (S^T = K.Q^T, keys on the accumulator rows, the query on the lane),
+//     so the row max / row sum of a query are per-lane scalars (+ one cross-half shuffle) and the P tile is, with
+//     no lane movement, the B operand of the next product O^T += V^T.P^T;
+//   * K / V (or Q / dO in the dK,dV kernel) tiles are staged in LDS in 8-row x 32-column sub-tiles with a
+//     (row>>2)&3 chunk XOR - one image that is conflict-free for both the row reads (ds_read_b128) feeding the
+//     score products and the transposing reads (ds_read_b64_tr_b16) feeding the products that contract over the
+//     tile's rows;
+//   * backward recomputes P from the saved log-sum-exp (no N x N tensor), in two kernels: dQ (query-major, same
+//     shape as forward) and dK/dV (key-major), so no atomics and bitwise-reproducible gradients.
+// Head dims 64 (encoder, 12 heads) and 32 (decoder, 16 heads).
+#include "common.h"
+
+#define LDS_AS __attribute__((address_space(3)))
+
+template <int HD>
+struct Img {                                   // LDS image of a [rows][HD] bf16 tile
+    static constexpr int NSUB = HD / 32;       // 32-column sub-tiles per row
+    static constexpr int NCH = HD / 8;         // 16-byte chunks per row
+    __device__ static __forceinline__ int off(int row, int ch) {
+        return (row >> 3) * (512 * NSUB) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+    }
+};
+
+// A-operand fragment of v_mfma_f32_32x32x16_bf16 read by ROWS: lane (r = lane&31, h = lane>>5) gets
+// tile[rowbase + r][16*kk + 8h .. +7]
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int rowbase, int kk, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + Img<HD>::off(rowbase + (lane & 31), 2 * kk + (lane >> 5)));
+}
+
+// A-operand fragment of the TRANSPOSED tile: MFMA row = tile column db*32 + (lane&31), k = tile rows
+// rowbase16 + {8(j>>2) + 4h + (j&3)} - the k order of an accumulator tile used as the other operand.
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rowbase16, int db, int lane) {
+    const int h = lane >> 5, cb = (lane >> 4) & 1, li = lane & 15, q = li >> 2, p4 = li & 3;
+    const int ch = db * 4 + 2 * cb + (p4 >> 1);
+    const int r0 = rowbase16 + 4 * h + q;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(tile + Img<HD>::off(r0, ch) + 8 * (p4 & 1)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(tile + Img<HD>::off(r0 + 8, ch) + 8 * (p4 & 1)));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// accumulator registers 8s..8s+7 -> bf16 fragment (B operand, k-step s)
+__device__ __forceinline__ bf16x8 acc_frag(const float* v) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    u32x4 u = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// stage a [64][HD] tile: global rows (clamped to the sequence) -> LDS image
+template <int HD>
+__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, long long ld, int row0, int last_row, int tid) {
+    constexpr int NCH = HD / 8;
+    constexpr int PER = 64 * NCH / 256;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = i * 256 + tid;
+        const int row = c / NCH, ch = c % NCH;
+        const int gr = min(row0 + row, last_row);
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)gr * ld + ch * 8);
+        *reinterpret_cast<uint4*>(tile + Img<HD>::off(row, ch)) = v;
+    }
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+struct AttnArgs {
+    const bf16_t* qkv; long long ld; int D;     // [rows, 3*D]: q | k | v, head h at columns h*HD
+    const int* tile_start;                      // first packed row of the tile's sequence
+    const int* tile_len;                        // length of that sequence
+    const int* tile_q0;                         // first row (within the sequence) of this 128-row tile
+    bf16_t* out; long long ldo;                 // fwd: attention output [rows, D]
+    float* lse; int rows_total;                 // [H][rows_total] natural-log sum-exp of the scaled scores
+    const bf16_t* dout;                         // bwd: dO [rows, D] (ldo)
+    float* delta;                               // bwd: rowsum(dO * O) [H][rows_total]
+    bf16_t* dqkv;                               // bwd: [rows, 3*D] (ld)
+    float scale;                                // hd^-0.5
+};
+
+// ---------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int NKK = HD / 16, NDB = HD / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2];
+    char* sK = smem;
+    char* sV = smem + 64 * HD * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int head = blockIdx.y;
+    const int seq0 = a.tile_start[blockIdx.x], L = a.tile_len[blockIdx.x];
+    const int qw = a.tile_q0[blockIdx.x] + 32 * wave;          // first query of this wave
+    const bool active = qw < L;
+    const int q = min(qw + (lane & 31), L - 1);
+    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
+    const float sl2 = a.scale * 1.4426950408889634f;
+
+    bf16x8 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * a.ld + (2 * kk + hh) * 8);
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        __syncthreads();
+        stage_tile<HD>(sK, base + a.D, a.ld, k0, L - 1, tid);
+        stage_tile<HD>(sV, base + 2 * a.D, a.ld, k0, L - 1, tid);
+        __syncthreads();
+        if (!active) continue;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
+        }
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float x = key < L ? s[kb][r] * sl2 : -INFINITY;
+                s[kb][r] = x;
+                mloc = fmaxf(mloc, x);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        float p[2][16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[kb][r] = fast_exp2(s[kb][r] - m_new);
+                psum += p[kb][r];
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 pf = acc_frag(&p[kb][8 * st]);
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sV, kb * 32 + 16 * st, d, lane), pf, o[d], 0, 0, 0);
+            }
+    }
+    if (!active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qq = qw + (lane & 31);
+    if (qq < L) {
+        bf16_t* orow = a.out + (size_t)(seq0 + qq) * a.ldo + head * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = pack_bf2(o[d][4 * t + 0] * inv, o[d][4 * t + 1] * inv);
+                w.y = pack_bf2(o[d][4 * t + 2] * inv, o[d][4 * t + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + d * 32 + 8 * t + 4 * hh) = w;
+            }
+        if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dQ (query-major).  Also produces delta = rowsum(dO * O), reused by the dK/dV kernel.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int NKK = HD / 16, NDB = HD / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2];
+    char* sK = smem;
+    char* sV = smem + 64 * HD * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int head = blockIdx.y;
+    const int seq0 = a.tile_start[blockIdx.x], L = a.tile_len[blockIdx.x];
+    const int qw = a.tile_q0[blockIdx.x] + 32 * wave;
+    const bool active = qw < L;
+    const int q = min(qw + (lane & 31), L - 1);
+    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
+    const float sl2 = a.scale * 1.4426950408889634f;
+
+    bf16x8 qf[NKK], dof[NKK];
+    float dpart = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * a.ld + (2 * kk + hh) * 8);
+        dof[kk] = *reinterpret_cast<const bf16x8*>(a.dout + (size_t)(seq0 + q) * a.ldo + head * HD + (2 * kk + hh) * 8);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.out + (size_t)(seq0 + q) * a.ldo + head * HD + (2 * kk + hh) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart += bf2f((bf16_t)dof[kk][j]) * bf2f((bf16_t)of[j]);
+    }
+    const float delta = dpart + __shfl_xor(dpart, 32, 64);
+    const float lse2 = a.lse[(size_t)head * a.rows_total + seq0 + q] * 1.4426950408889634f;
+    if (active && hh == 0 && qw + (lane & 31) < L) a.delta[(size_t)head * a.rows_total + seq0 + q] = delta;
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        __syncthreads();
+        stage_tile<HD>(sK, base + a.D, a.ld, k0, L - 1, tid);
+        stage_tile<HD>(sV, base + 2 * a.D, a.ld, k0, L - 1, tid);
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, kk, lane), qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, kb * 32, kk, lane), dof[kk], dp, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float pr = key < L ? fast_exp2(s[r] * sl2 - lse2) : 0.f;
+                ds[r] = pr * (dp[r] - delta);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 dsf = acc_frag(&ds[8 * st]);
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sK, kb * 32 + 16 * st, d, lane), dsf, dq[d], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+    const int qq = qw + (lane & 31);
+    if (qq < L) {
+        bf16_t* drow = a.dqkv + (size_t)(seq0 + qq) * a.ld + head * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = pack_bf2(dq[d][4 * t + 0] * a.scale, dq[d][4 * t + 1] * a.scale);
+                w.y = pack_bf2(dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale);
+                *reinterpret_cast<uint2*>(drow + d * 32 + 8 * t + 4 * hh) = w;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dK, dV (key-major): each wave owns 32 keys (the lane) and walks the query rows of the sequence.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int NKK = HD / 16, NDB = HD / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 2 * 64 * 4];
+    char* sQ = smem;
+    char* sDO = smem + 64 * HD * 2;
+    float* sLse = reinterpret_cast<float*>(smem + 2 * 64 * HD * 2);
+    float* sDel = sLse + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int head = blockIdx.y;
+    const int seq0 = a.tile_start[blockIdx.x], L = a.tile_len[blockIdx.x];
+    const int kw = a.tile_q0[blockIdx.x] + 32 * wave;          // first key of this wave
+    const bool active = kw < L;
+    const int key = min(kw + (lane & 31), L - 1);
+    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
+    const float sl2 = a.scale * 1.4426950408889634f;
+
+    bf16x8 kf[NKK], vf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        kf[kk] = *reinterpret_cast<const bf16x8*>(base + a.D + (size_t)key * a.ld + (2 * kk + hh) * 8);
+        vf[kk] = *reinterpret_cast<const bf16x8*>(base + 2 * a.D + (size_t)key * a.ld + (2 * kk + hh) * 8);
+    }
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+
+    for (int q0 = 0; q0 < L; q0 += 64) {
+        __syncthreads();
+        stage_tile<HD>(sQ, base, a.ld, q0, L - 1, tid);
+        stage_tile<HD>(sDO, a.dout + (size_t)seq0 * a.ldo + head * HD, a.ldo, q0, L - 1, tid);
+        if (tid < 64) {
+            const int qr = min(q0 + tid, L - 1);
+            sLse[tid] = a.lse[(size_t)head * a.rows_total + seq0 + qr] * 1.4426950408889634f;
+            sDel[tid] = a.delta[(size_t)head * a.rows_total + seq0 + qr];
+        }
+        __syncthreads();
+        if (!active) continue;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, qb * 32, kk, lane), kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sDO, qb * 32, kk, lane), vf[kk], dp, 0, 0, 0);
+            }
+            float p[16], ds[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rb = qb * 32 + 8 * t + 4 * hh;                 // rows rb..rb+3 of the staged tile
+                const float4 l4 = *reinterpret_cast<const float4*>(sLse + rb);
+                const float4 d4 = *reinterpret_cast<const float4*>(sDel + rb);
+                const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * t + j;
+                    const float pr = (q0 + rb + j) < L ? fast_exp2(s[r] * sl2 - ls[j]) : 0.f;
+                    p[r] = pr;
+                    ds[r] = pr * (dp[r] - dl[j]);
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 pf = acc_frag(&p[8 * st]);
+                const bf16x8 dsf = acc_frag(&ds[8 * st]);
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) {
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sDO, qb * 32 + 16 * st, d, lane), pf, dv[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, qb * 32 + 16 * st, d, lane), dsf, dk[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const int kq = kw + (lane & 31);
+    if (kq < L) {
+        bf16_t* krow = a.dqkv + (size_t)(seq0 + kq) * a.ld + a.D + head * HD;
+        bf16_t* vrow = krow + a.D;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = pack_bf2(dk[d][4 * t + 0] * a.scale, dk[d][4 * t + 1] * a.scale);
+                w.y = pack_bf2(dk[d][4 * t + 2] * a.scale, dk[d][4 * t + 3] * a.scale);
+                *reinterpret_cast<uint2*>(krow + d * 32 + 8 * t + 4 * hh) = w;
+                w.x = pack_bf2(dv[d][4 * t + 0], dv[d][4 * t + 1]);
+                w.y = pack_bf2(dv[d][4 * t + 2], dv[d][4 * t + 3]);
+                *reinterpret_cast<uint2*>(vrow + d * 32 + 8 * t + 4 * hh) = w;
+            }
+    }
+}
+
+// ===================================================================================================
+static int check_common(const char* name, const void* qkv, long long ld, int D, int H, int hd, const int* ts, const int* tl,
+                        const int* tq, int ntiles) {
+    if (!(qkv && ts && tl && tq && ntiles > 0 && H > 0 && (hd == 32 || hd == 64) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0)) {
+        avs_set_error("%s: bad arguments (D=%d H=%d hd=%d ld=%lld ntiles=%d)", name, D, H, hd, ld, ntiles);
+        return -2;
+    }
+    return 0;
+}
+
+extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                            const int* tile_q0, int ntiles, bf16_t* out, long long ldo, float* lse, int rows_total,
+                            hipStream_t stream) {
+    const int hd = H > 0 ? D / H : 0;
+    if (int e = check_common("attn_fwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
+    AVS_CHECK_ARG(out && lse && (ldo % 4) == 0, "attn_fwd: null output");
+    AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd)};
+    dim3 grid(ntiles, H);
+    if (hd == 64) attn_fwd_kernel<64><<<grid, 256, 0, stream>>>(a);
+    else attn_fwd_kernel<32><<<grid, 256, 0, stream>>>(a);
+    AVS_LAUNCH_CHECK("attn_fwd");
+    return 0;
+}
+
+extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                            const int* tile_q0, int ntiles, const bf16_t* out, const bf16_t* dout, long long ldo,
+                            const float* lse, float* delta, int rows_total, bf16_t* dqkv, hipStream_t stream) {
+    const int hd = H > 0 ? D / H : 0;
+    if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
+    AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
+    AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
+               dout, delta, dqkv, 1.0f / sqrtf((float)hd)};
+    dim3 grid(ntiles, H);
+    if (hd == 64) attn_bwd_dq_kernel<64><<<grid, 256, 0, stream>>>(a);
+    else attn_bwd_dq_kernel<32><<<grid, 256, 0, stream>>>(a);
+    AVS_LAUNCH_CHECK("attn_bwd_dq");
+    if (hd == 64) attn_bwd_dkv_kernel<64><<<grid, 256, 0, stream>>>(a);
+    else attn_bwd_dkv_kernel<32><<<grid, 256, 0, stream>>>(a);
+    AVS_LAUNCH_CHECK("attn_bwd_dkv");
+    return 0;
+}

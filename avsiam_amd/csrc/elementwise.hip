@@ -1,0 +1,326 @@
+// HBM-bound data-movement kernels of the AVSiam hot path: patch gather (k1/k7), decoder un-shuffle (k8),
+// token-mean pooling, column sums (bias grads), positional-embedding scatter, weight cast/transposes and
+// the fused Adam step.  All accesses are 8-16 B per lane and coalesced along the feature dimension.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// k1 + k7: im2col of the KEPT patches only.  The reference embeds every patch and discards 75 % of them
+// (/root/reference/src/models/cav_mae_base.py:448-455 then :476-477); conv k=s=16 is a per-patch linear
+// map, so gathering first is identical math.  Output rows are GEMM A-operands (bf16).
+// audio: a [B, time, mel] fp32; token = f*tP + t (:444-445 transpose -> image [mel, time]);
+//        out[r, p*16+q] = a[b, t*16+q, f*16+p]
+__global__ void im2col_audio_kernel(const float* __restrict__ a, const int* __restrict__ row_b,
+                                    const int* __restrict__ row_tok, bf16_t* __restrict__ out, int rows, int tlen,
+                                    int mel, int tP) {
+    const int r = blockIdx.x;
+    const int q = threadIdx.x >> 4, p = threadIdx.x & 15;      // consecutive threads read consecutive mel bins
+    const int b = row_b[r], tok = row_tok[r];
+    const int f = tok / tP, t = tok - f * tP;
+    const float v = a[((size_t)b * tlen + t * 16 + q) * mel + f * 16 + p];
+    out[(size_t)r * 256 + p * 16 + q] = f2bf(v);
+}
+
+// video: v [NF, C, H, W] fp32; token = gy*G + gx; out[r, c*256 + p*16 + q] = v[img, c, gy*16+p, gx*16+q]
+__global__ void im2col_video_kernel(const float* __restrict__ v, const int* __restrict__ row_img,
+                                    const int* __restrict__ row_tok, bf16_t* __restrict__ out, int rows, int C, int H,
+                                    int W, int G) {
+    const int r = blockIdx.x;
+    const int img = row_img[r], tok = row_tok[r];
+    const int gy = tok / G, gx = tok - gy * G;
+    const int K = C * 256;
+    for (int e = threadIdx.x * 4; e < K; e += blockDim.x * 4) {
+        const int c = e >> 8, p = (e >> 4) & 15, q = e & 15;
+        const float4 x = *reinterpret_cast<const float4*>(v + (((size_t)img * C + c) * H + gy * 16 + p) * W + gx * 16 + q);
+        uint2 o;
+        o.x = pack_bf2(x.x, x.y);
+        o.y = pack_bf2(x.z, x.w);
+        *reinterpret_cast<uint2*>(out + (size_t)r * K + e) = o;
+    }
+}
+
+// fp32 -> bf16 with a scale (d(2*(conv+pos)) = 2*dOut for the embed prologue `x + norm_pre(x)`, :449-450)
+__global__ void cast_scale_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4, float alpha) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        uint2 o;
+        o.x = pack_bf2(v.x * alpha, v.y * alpha);
+        o.y = pack_bf2(v.z * alpha, v.w * alpha);
+        reinterpret_cast<uint2*>(y)[i] = o;
+    }
+}
+
+// dst[idx[r], :] += scale * src[r, :]   (positional-embedding gradient: many samples hit the same row)
+__global__ void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, float* dst,
+                                        int rows, int D, float scale) {
+    const int r = blockIdx.x;
+    float* d = dst + (size_t)idx[r] * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) atomicAdd(d + c, scale * bf2f(src[(size_t)r * D + c]));
+}
+
+// out[c] += sum_r x[r, c]  (bias gradients).  Each block reduces COLSUM_ROWS rows in registers, one atomic per
+// column per block.
+constexpr int COLSUM_ROWS = 256;
+__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* out, int rows, int C) {
+    const int c2 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (c2 >= C) return;
+    const int r0 = blockIdx.y * COLSUM_ROWS;
+    const int r1 = min(rows, r0 + COLSUM_ROWS);
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(x + (size_t)r * C + c2);
+        s0 += __uint_as_float(v << 16);
+        s1 += __uint_as_float(v & 0xffff0000u);
+    }
+    atomicAdd(out + c2, s0);
+    atomicAdd(out + c2 + 1, s1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k8: decoder un-shuffle (forward_decoder :604-626).  Output row r of [B*(La+T*Lv), Dd]:
+//   src_row[r] >= 0 -> x[src_row[r]]  else mask_token;  + pos[pos_row[r]] + modality[row_mod[r]]
+// pos is the concatenation [decoder_pos_embed_a ; decoder_pos_embed_v].
+__global__ void unshuffle_fwd_kernel(const float* __restrict__ x, const int* __restrict__ src_row,
+                                     const int* __restrict__ pos_row, const uint8_t* __restrict__ row_mod,
+                                     const float* __restrict__ mask_token, const float* __restrict__ pos_a,
+                                     const float* __restrict__ pos_v, int La, const float* __restrict__ mod_a,
+                                     const float* __restrict__ mod_v, float* __restrict__ out, int rows, int D) {
+    const int r = blockIdx.x;
+    const int s = src_row[r];
+    const int pr = pos_row[r];
+    const float4* src = reinterpret_cast<const float4*>(s >= 0 ? x + (size_t)s * D : mask_token);
+    const float4* pp = reinterpret_cast<const float4*>(pr < La ? pos_a + (size_t)pr * D : pos_v + (size_t)(pr - La) * D);
+    const float4* mm = reinterpret_cast<const float4*>(row_mod[r] ? mod_v : mod_a);
+    float4* o = reinterpret_cast<float4*>(out + (size_t)r * D);
+    for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
+        const float4 a = src[c], p = pp[c], m = mm[c];
+        o[c] = make_float4(a.x + p.x + m.x, a.y + p.y + m.y, a.z + p.z + m.z, a.w + p.w + m.w);
+    }
+}
+
+// Backward of the un-shuffle.  One block per position l of [La + Lv]; it walks every (sample, frame) row at
+// that position: sums the positional gradient in registers (no atomics), routes kept rows back to the encoder
+// layout (dx[src] = dout row) and accumulates mask-token / modality sums (one atomic per column per block).
+__global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ src_row, int B, int T,
+                                     int La, int Lv, float* __restrict__ dx, float* dpos_a, float* dpos_v,
+                                     float* dmask, float* dmod_a, float* dmod_v, int D) {
+    const int l = blockIdx.x;
+    const bool audio = l < La;
+    const int Ltot = La + T * Lv;
+    for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
+        float4 sp = make_float4(0, 0, 0, 0), sm = sp;
+        const int reps = audio ? 1 : T;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < reps; ++t) {
+                const int r = b * Ltot + (audio ? l : La + t * Lv + (l - La));
+                const float4 g = reinterpret_cast<const float4*>(dout + (size_t)r * D)[c];
+                sp.x += g.x; sp.y += g.y; sp.z += g.z; sp.w += g.w;
+                const int s = src_row[r];
+                if (s >= 0) reinterpret_cast<float4*>(dx + (size_t)s * D)[c] = g;
+                else { sm.x += g.x; sm.y += g.y; sm.z += g.z; sm.w += g.w; }
+            }
+        float* dp = audio ? dpos_a + (size_t)l * D : dpos_v + (size_t)(l - La) * D;
+        float4 old = reinterpret_cast<float4*>(dp)[c];
+        reinterpret_cast<float4*>(dp)[c] = make_float4(old.x + sp.x, old.y + sp.y, old.z + sp.z, old.w + sp.w);
+        float* dm = audio ? dmod_a : dmod_v;
+        atomicAdd(dm + c * 4 + 0, sp.x); atomicAdd(dm + c * 4 + 1, sp.y);
+        atomicAdd(dm + c * 4 + 2, sp.z); atomicAdd(dm + c * 4 + 3, sp.w);
+        atomicAdd(dmask + c * 4 + 0, sm.x); atomicAdd(dmask + c * 4 + 1, sm.y);
+        atomicAdd(dmask + c * 4 + 2, sm.z); atomicAdd(dmask + c * 4 + 3, sm.w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// token mean of each packed sequence (``.mean(dim=1)`` at :563,566): reps[s] = mean_{r in seg s} y[r]
+__global__ void segment_mean_fwd_kernel(const bf16_t* __restrict__ y, const int* __restrict__ seg_start, float* __restrict__ reps,
+                                        int D) {
+    const int s = blockIdx.x;
+    const int r0 = seg_start[s], r1 = seg_start[s + 1];
+    const float inv = 1.0f / (float)(r1 - r0);
+    for (int c2 = threadIdx.x * 2; c2 < D; c2 += blockDim.x * 2) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(y + (size_t)r * D + c2);
+            s0 += __uint_as_float(v << 16);
+            s1 += __uint_as_float(v & 0xffff0000u);
+        }
+        reps[(size_t)s * D + c2] = s0 * inv;
+        reps[(size_t)s * D + c2 + 1] = s1 * inv;
+    }
+}
+
+// dy[r] = dreps[seg(r)] / len(seg)
+__global__ void segment_mean_bwd_kernel(const float* __restrict__ dreps, const int* __restrict__ seg_start, bf16_t* __restrict__ dy,
+                                        int D) {
+    const int s = blockIdx.x;
+    const int r0 = seg_start[s], r1 = seg_start[s + 1];
+    const float inv = 1.0f / (float)(r1 - r0);
+    for (int c2 = threadIdx.x * 2; c2 < D; c2 += blockDim.x * 2) {
+        const uint32_t v = pack_bf2(dreps[(size_t)s * D + c2] * inv, dreps[(size_t)s * D + c2 + 1] * inv);
+        for (int r = r0; r < r1; ++r) *reinterpret_cast<uint32_t*>(dy + (size_t)r * D + c2) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 transpose [R, C] -> [C, R] through LDS (weight copies for the dgrad GEMMs).
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int C) {
+    __shared__ bf16_t tile[64][66];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    for (int i = threadIdx.y; i < 64; i += blockDim.y) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < C) ? in[(size_t)r * C + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 64; i += blockDim.y) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < C && r < R) out[(size_t)c * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        uint2 o;
+        o.x = pack_bf2(v.x, v.y);
+        o.y = pack_bf2(v.z, v.w);
+        reinterpret_cast<uint2*>(y)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = f2bf(x[n4 * 4 + threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused Adam over a contiguous slice of the flat arena: torch.optim.Adam(lr, betas=(0.95,0.999), eps=1e-8,
+// weight_decay=5e-7) as constructed at /root/reference/src/traintest_cavmae_base.py:64-66 (L2 decay folded into
+// the gradient, bias correction).  Also refreshes the bf16 shadow copy the GEMMs read.  28 B/param of traffic.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            bf16_t* __restrict__ pb, size_t n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float gscale) {
+    const size_t n4 = n / 4;
+    const float step = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = gp[k] * gscale + wd * pp[k];
+            mp[k] = b1 * mp[k] + (1.f - b1) * gg;
+            vp[k] = b2 * vp[k] + (1.f - b2) * gg * gg;
+            pp[k] -= step * mp[k] / (sqrtf(vp[k]) / bc2_sqrt + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (pb) {
+            uint2 o;
+            o.x = pack_bf2(pv.x, pv.y);
+            o.y = pack_bf2(pv.z, pv.w);
+            reinterpret_cast<uint2*>(pb)[i] = o;
+        }
+    }
+}
+
+// ===================================================================================================
+static inline int grid_1d(size_t n, int block) {
+    size_t g = (n + block - 1) / block;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+extern "C" int avs_im2col_audio(const float* a, const int* row_b, const int* row_tok, bf16_t* out, int rows, int tlen,
+                                int mel, int t_patches, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && a && row_b && row_tok && out, "im2col_audio: bad args");
+    im2col_audio_kernel<<<rows, 256, 0, stream>>>(a, row_b, row_tok, out, rows, tlen, mel, t_patches);
+    AVS_LAUNCH_CHECK("im2col_audio");
+    return 0;
+}
+
+extern "C" int avs_im2col_video(const float* v, const int* row_img, const int* row_tok, bf16_t* out, int rows, int C, int H,
+                                int W, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && v && row_img && row_tok && out && (W % 16) == 0 && (H % 16) == 0, "im2col_video: bad args");
+    im2col_video_kernel<<<rows, 192, 0, stream>>>(v, row_img, row_tok, out, rows, C, H, W, W / 16);
+    AVS_LAUNCH_CHECK("im2col_video");
+    return 0;
+}
+
+extern "C" int avs_cast_scale_bf16(const float* x, bf16_t* y, long long n, float alpha, hipStream_t stream) {
+    AVS_CHECK_ARG(n > 0 && (n % 4) == 0 && x && y, "cast_scale: n must be a positive multiple of 4");
+    cast_scale_kernel<<<grid_1d(n / 4, 256), 256, 0, stream>>>(x, y, (size_t)n / 4, alpha);
+    AVS_LAUNCH_CHECK("cast_scale");
+    return 0;
+}
+
+extern "C" int avs_scatter_add_rows(const bf16_t* src, const int* idx, float* dst, int rows, int D, float scale,
+                                    hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && src && idx && dst, "scatter_add_rows: bad args");
+    scatter_add_rows_kernel<<<rows, 256, 0, stream>>>(src, idx, dst, rows, D, scale);
+    AVS_LAUNCH_CHECK("scatter_add_rows");
+    return 0;
+}
+
+extern "C" int avs_colsum_bf16(const bf16_t* x, float* out, int rows, int C, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && (C % 2) == 0 && x && out, "colsum: bad args");
+    dim3 grid(ceil_div(C / 2, 128), ceil_div(rows, COLSUM_ROWS));
+    colsum_bf16_kernel<<<grid, 128, 0, stream>>>(x, out, rows, C);
+    AVS_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+extern "C" int avs_unshuffle_fwd(const float* x, const int* src_row, const int* pos_row, const uint8_t* row_mod,
+                                 const float* mask_token, const float* pos_a, const float* pos_v, int La,
+                                 const float* mod_a, const float* mod_v, float* out, int rows, int D, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && (D % 4) == 0 && x && src_row && pos_row && row_mod && out, "unshuffle_fwd: bad args");
+    unshuffle_fwd_kernel<<<rows, 128, 0, stream>>>(x, src_row, pos_row, row_mod, mask_token, pos_a, pos_v, La, mod_a, mod_v,
+                                                   out, rows, D);
+    AVS_LAUNCH_CHECK("unshuffle_fwd");
+    return 0;
+}
+
+extern "C" int avs_unshuffle_bwd(const float* dout, const int* src_row, int B, int T, int La, int Lv, float* dx,
+                                 float* dpos_a, float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D,
+                                 hipStream_t stream) {
+    AVS_CHECK_ARG(B > 0 && T > 0 && (D % 4) == 0 && dout && src_row && dx, "unshuffle_bwd: bad args");
+    unshuffle_bwd_kernel<<<La + Lv, 128, 0, stream>>>(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D);
+    AVS_LAUNCH_CHECK("unshuffle_bwd");
+    return 0;
+}
+
+extern "C" int avs_segment_mean_fwd(const bf16_t* y, const int* seg_start, float* reps, int nseg, int D, hipStream_t stream) {
+    AVS_CHECK_ARG(nseg > 0 && (D % 2) == 0, "segment_mean_fwd: bad args");
+    segment_mean_fwd_kernel<<<nseg, 256, 0, stream>>>(y, seg_start, reps, D);
+    AVS_LAUNCH_CHECK("segment_mean_fwd");
+    return 0;
+}
+
+extern "C" int avs_segment_mean_bwd(const float* dreps, const int* seg_start, bf16_t* dy, int nseg, int D, hipStream_t stream) {
+    AVS_CHECK_ARG(nseg > 0 && (D % 2) == 0, "segment_mean_bwd: bad args");
+    segment_mean_bwd_kernel<<<nseg, 256, 0, stream>>>(dreps, seg_start, dy, D);
+    AVS_LAUNCH_CHECK("segment_mean_bwd");
+    return 0;
+}
+
+extern "C" int avs_transpose_bf16(const bf16_t* in, bf16_t* out, int R, int C, hipStream_t stream) {
+    AVS_CHECK_ARG(R > 0 && C > 0 && in && out, "transpose: bad args");
+    transpose_bf16_kernel<<<dim3(ceil_div(C, 64), ceil_div(R, 64)), dim3(64, 4), 0, stream>>>(in, out, R, C);
+    AVS_LAUNCH_CHECK("transpose");
+    return 0;
+}
+
+extern "C" int avs_cast_bf16(const float* x, bf16_t* y, long long n, hipStream_t stream) {
+    AVS_CHECK_ARG(n > 0 && x && y, "cast_bf16: bad args");
+    cast_bf16_kernel<<<grid_1d(n / 4 + 1, 256), 256, 0, stream>>>(x, y, (size_t)n);
+    AVS_LAUNCH_CHECK("cast_bf16");
+    return 0;
+}
+
+extern "C" int avs_adam(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, long long n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, float grad_scale, hipStream_t stream) {
+    AVS_CHECK_ARG(n > 0 && (n % 4) == 0 && step >= 1 && p && g && m && v, "adam: n must be a positive multiple of 4, step>=1");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);          // torch computes these in double
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    adam_kernel<<<grid_1d(n / 4, 256), 256, 0, stream>>>(p, g, m, v, p_bf16, (size_t)n, lr, beta1, beta2, eps, weight_decay,
+                                                         (float)bc1, (float)sqrt(bc2), grad_scale);
+    AVS_LAUNCH_CHECK("adam");
+    return 0;
+}

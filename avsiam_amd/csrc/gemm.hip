@@ -1,0 +1,296 @@
+// k3/k5/k9 - bf16 MFMA GEMMs of the AVSiam hot path (gfx950 only).
+//
+//   gemm_nt : out[M,N] = epilogue( A[M,K] . B[N,K]^T )       forward Linear (B = weight, as stored by nn.Linear) and
+//                                                            dgrad (A = dY, B = W^T copy)
+//   gemm_tn : C[N1,N2] += A[M,N1]^T . B[M,N2]                wgrad (A = dY, B = layer input), fp32 atomics
+//
+// Replaces Attention.qkv/.proj (/root/reference/src/models/cav_mae_base.py:51,55,60,77), timm Mlp fc1/fc2 (:138-143),
+// PatchEmbed.proj (:96-99), decoder_embed / decoder_pred_* (:600,634-635) and their autograd backward.
+// Both kernels: 128x128 block tile, K-step 64, 4 waves (2x2) of 64x64, operands streamed HBM -> LDS with
+// global_load_lds (16 B/lane, no VGPR round trip), double-buffered, one barrier per K-step; the LDS image is
+// lane-linear so the bank-conflict swizzle is applied to the per-lane SOURCE address and again on the read.
+// fp32 accumulation on v_mfma_f32_16x16x32_bf16 (nt) / v_mfma_f32_32x32x16_bf16 (tn).
+#include "common.h"
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;     // one operand tile (either orientation) = 16 KiB
+
+struct GemmNtArgs {
+    const bf16_t* A; long long lda;
+    const bf16_t* B; long long ldb;
+    int M, N, K;
+    const float* bias;
+    const float* res; long long ldr; const int* res_idx;
+    const bf16_t* aux; long long ldaux;
+    void* out; long long ldo; int out_f32;
+    bf16_t* out2; long long ldo2;
+    float alpha; int act;                    // 0 none | 1 gelu (out = pre-activation, out2 = gelu) | 2 gelu-backward (aux = pre-activation)
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run of tiles so that
+    // neighbouring tiles (same A panel) hit the same L2.  Bijective for any nwg.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];     // [buf][A|B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nt_n = a.N / BN;
+    const int nt_m = (a.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, nt_m * nt_n);
+    const int m0 = (wg / nt_n) * BM, n0 = (wg % nt_n) * BN;
+
+    // per-thread source pointers of the 4+4 16-byte chunks it stages per K-step
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = i * 256 + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
+        const int ra = min(m0 + row, a.M - 1);
+        srcA[i] = a.A + (size_t)ra * a.lda + c * 8;
+        srcB[i] = a.B + (size_t)(n0 + row) * a.ldb + c * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+        char* sa = smem + buf * 2 * TILE_BYTES;
+        char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + k0), (LDS_AS void*)(sa + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + k0), (LDS_AS void*)(sb + off), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = base + (lane&15), chunk = kk*4 + (lane>>4), swizzled with row&7 == lane&7
+    const int fr = lane & 15, fq = lane >> 4;
+    const int off_k0 = fr * 128 + (((0 + fq) ^ (lane & 7)) << 4);
+    const int off_k1 = fr * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+
+    const int nk = a.K / BK;
+    stage(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();                                   // tile t landed (vmcnt(0)) and buffer (t+1)&1 is free
+        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+        const char* sa = smem + (t & 1) * 2 * TILE_BYTES + wm * 64 * 128;
+        const char* sb = smem + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + wn * 64 * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = kk ? off_k1 : off_k0;
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + off);
+                xf[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + off);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+
+    // epilogue straight from the accumulators: the weight tile was the MFMA A operand, so a lane holds 4
+    // consecutive output columns n of one row m -> 8/16-byte stores.
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + fr;
+        if (m >= a.M) continue;
+        const long long rrow = a.res ? (a.res_idx ? (long long)a.res_idx[m] : (long long)m) : 0;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (ACT == 2) {
+                const uint2 p = *reinterpret_cast<const uint2*>(a.aux + (size_t)m * a.ldaux + n);
+                v[0] *= gelu_erf_grad(__uint_as_float(p.x << 16));
+                v[1] *= gelu_erf_grad(__uint_as_float(p.x & 0xffff0000u));
+                v[2] *= gelu_erf_grad(__uint_as_float(p.y << 16));
+                v[3] *= gelu_erf_grad(__uint_as_float(p.y & 0xffff0000u));
+            }
+            if (a.res) {
+                const float4 r = *reinterpret_cast<const float4*>(a.res + rrow * a.ldr + n);
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            }
+            v[0] *= a.alpha; v[1] *= a.alpha; v[2] *= a.alpha; v[3] *= a.alpha;
+            if (a.out_f32) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 o;
+                o.x = pack_bf2(v[0], v[1]);
+                o.y = pack_bf2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = o;
+            }
+            if (ACT == 1) {
+                uint2 o;
+                o.x = pack_bf2(gelu_erf(v[0]), gelu_erf(v[1]));
+                o.y = pack_bf2(gelu_erf(v[2]), gelu_erf(v[3]));
+                *reinterpret_cast<uint2*>(a.out2 + (size_t)m * a.ldo2 + n) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad.  Both operands are row-major with the CONTRACTION index (token row m) as the slow dimension, so the
+// MFMA fragments (8 consecutive k per lane) are columns of the staged tiles: they are read with the gfx950
+// transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, lane i receives column i).
+// Tiles are [64 token rows][128 columns] (256-B rows); chunk swizzle c ^= (row&3)<<2 spreads the 4 rows of a
+// transposed read over the four 64-B quarters of the bank row (conflict-free).  The contraction is split over
+// gridDim.z; partial tiles are accumulated with fp32 atomics whose wave footprint is two 128-B row segments.
+// Contract: A and B are allocated (and zero) up to the next multiple of 64 rows beyond M.
+struct GemmTnArgs {
+    const bf16_t* A; long long lda;
+    const bf16_t* B; long long ldb;
+    float* C; long long ldc;
+    int M, N1, N2;
+    int stages_per_split;
+};
+
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* base) {
+    // rows r..r+3 then r+4..r+7 of the same 16 columns -> 8 consecutive k of one column per lane
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(base));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(base + 4 * 256));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n2_0 = blockIdx.x * 128, n1_0 = blockIdx.y * 128;
+    const int nstages = (a.M + BK - 1) / BK;
+    const int s_begin = blockIdx.z * a.stages_per_split;
+    const int s_end = min(nstages, s_begin + a.stages_per_split);
+    if (s_begin >= s_end) return;
+
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = i * 256 + tid, row = p >> 4, c = (p & 15) ^ ((row & 3) << 2);
+        srcA[i] = a.A + (size_t)row * a.lda + n1_0 + c * 8;
+        srcB[i] = a.B + (size_t)row * a.ldb + n2_0 + c * 8;
+    }
+    auto stage = [&](int buf, int s) {
+        char* sa = smem + buf * 2 * TILE_BYTES;
+        char* sb = sa + TILE_BYTES;
+        const size_t ra = (size_t)s * BK * a.lda, rb = (size_t)s * BK * a.ldb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + ra), (LDS_AS void*)(sa + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + rb), (LDS_AS void*)(sb + off), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read address of this lane inside a tile, for k16-step 0 and column block 0:
+    //   group G = lane>>4: h = G>>1 (k half), cb = G&1 (16-column half); lane i = lane&15 supplies row q = i>>2,
+    //   columns 4*(i&3).. ; row = 8h + q ; col = 16*cb + 4*(i&3)
+    const int h = lane >> 5, cb = (lane >> 4) & 1, li = lane & 15, q = li >> 2, p4 = li & 3;
+    const int trow = 8 * h + q;
+    const int tcol = 16 * cb + 4 * p4;                      // + column block base (multiple of 32)
+    auto tr_off = [&](int colbase, int ks) {
+        const int col = colbase + tcol;
+        const int chunk = (col >> 3) ^ (q << 2);            // row&3 == q for every row this lane addresses
+        return (ks * 16 + trow) * 256 + (chunk << 4) + (col & 7) * 2;
+    };
+
+    stage(0, s_begin);
+    for (int s = s_begin; s < s_end; ++s) {
+        const int t = s - s_begin;
+        __syncthreads();
+        if (s + 1 < s_end) stage((t + 1) & 1, s + 1);
+        const char* sa = smem + (t & 1) * 2 * TILE_BYTES;
+        const char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = lds_tr_frag(sa + tr_off(wr * 64 + i * 32, ks));
+                bfr[i] = lds_tr_frag(sb + tr_off(wc * 64 + i * 32, ks));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n2 = n2_0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n1 = n1_0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(a.C + (size_t)n1 * a.ldc + n2, acc[i][j][r]);
+            }
+        }
+}
+
+// ===================================================================================================
+extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
+                                const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
+                                long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
+                                float alpha, int act, hipStream_t stream) {
+    AVS_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % BN) == 0 && (K % BK) == 0, "gemm_nt: need N%%128==0, K%%64==0 (M=%d N=%d K=%d)", M, N, K);
+    AVS_CHECK_ARG(A && B && out, "gemm_nt: null operand");
+    AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % 4) == 0, "gemm_nt: leading dimensions must keep 16-byte alignment");
+    AVS_CHECK_ARG(act >= 0 && act <= 2 && (act != 1 || out2) && (act != 2 || aux), "gemm_nt: bad activation arguments");
+    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act};
+    const int nwg = ceil_div(M, BM) * (N / BN);
+    if (act == 0) gemm_nt_kernel<0><<<nwg, 256, 0, stream>>>(a);
+    else if (act == 1) gemm_nt_kernel<1><<<nwg, 256, 0, stream>>>(a);
+    else gemm_nt_kernel<2><<<nwg, 256, 0, stream>>>(a);
+    AVS_LAUNCH_CHECK("gemm_nt");
+    return 0;
+}
+
+extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, float* C, long long ldc,
+                                int M, int N1, int N2, int splits, hipStream_t stream) {
+    AVS_CHECK_ARG(M > 0 && (N1 % 128) == 0 && (N2 % 128) == 0, "gemm_tn: need N1%%128==0 and N2%%128==0 (N1=%d N2=%d)", N1, N2);
+    AVS_CHECK_ARG(A && B && C && (lda % 8) == 0 && (ldb % 8) == 0, "gemm_tn: bad operands");
+    const int nstages = ceil_div(M, BK);
+    if (splits <= 0) {                                      // fill >= ~2 waves of workgroups over 256 CUs
+        const int tiles = (N1 / 128) * (N2 / 128);
+        splits = ceil_div(512, tiles);
+    }
+    if (splits > nstages) splits = nstages;
+    const int per = ceil_div(nstages, splits);
+    splits = ceil_div(nstages, per);
+    GemmTnArgs a{A, lda, B, ldb, C, ldc, M, N1, N2, per};
+    gemm_tn_kernel<<<dim3(N2 / 128, N1 / 128, splits), 256, 0, stream>>>(a);
+    AVS_LAUNCH_CHECK("gemm_tn");
+    return 0;
+}

@@ -1,0 +1,188 @@
+// k2 - LayerNorm forward/backward with a per-row modality affine select.
+//
+// Replaces nn.LayerNorm as used by Block (/root/reference/src/models/cav_mae_base.py:120-122,135-137,
+// 151-152,169-170,190-191) and the final norms (:492,495,563,566,631).  Packing all sequences of a pass
+// into one [rows, D] matrix means rows of both modalities share a launch, so the affine pair is picked
+// per row (row_mod 0/1).  HBM-bound: one wave per row, 16 B per lane per access, the row stays in
+// registers between the statistics and the normalisation (algorithmic bytes: 4D read + 2D written fwd).
+// fp32 in (residual stream), bf16 out (GEMM operand), fp32 statistics - the reference's autocast keeps
+// LayerNorm in fp32 as well.
+#include "common.h"
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g0,
+                                                     const float* __restrict__ b0, const float* __restrict__ g1,
+                                                     const float* __restrict__ b1, const uint8_t* __restrict__ row_mod,
+                                                     const int* __restrict__ out_map, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int rows, float eps) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[i * 64 + lane];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float var = wave_sum(q) * (1.0f / D);
+    const float rs = 1.0f / sqrtf(var + eps);
+    const int mod = row_mod ? row_mod[row] : 0;
+    const float4* gp = reinterpret_cast<const float4*>(mod ? g1 : g0);
+    const float4* bp = reinterpret_cast<const float4*>(mod ? b1 : b0);
+    const int orow = out_map ? out_map[row] : row;
+    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)orow * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 g = gp[i * 64 + lane], b = bp[i * 64 + lane];
+        uint2 o;
+        o.x = pack_bf2(v[i].x * rs * g.x + b.x, v[i].y * rs * g.y + b.y);
+        o.y = pack_bf2(v[i].z * rs * g.z + b.z, v[i].w * rs * g.w + b.w);
+        yr[i * 64 + lane] = o;
+    }
+    if (lane == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rs;
+    }
+}
+
+// Backward.  dx = dres + rstd * (gy - mean(gy) - xhat * mean(gy * xhat)),  gy = dy * gamma.
+// Parameter gradients: each block reduces its rows into a private slab ws[block][set][{dgamma,dbeta}][D]
+// (plain stores, deterministic); ln_bwd_reduce_kernel sums the slabs into the gradient arena.
+constexpr int LN_ROWS_PER_WAVE = 16;
+constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ g0, const float* __restrict__ g1,
+                                                     const uint8_t* __restrict__ row_mod, const int* __restrict__ out_map,
+                                                     const float* dres, float* dx, float* __restrict__ ws, int rows) {
+    constexpr int D = NV * 256;
+    __shared__ float red[4][D];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float4 dg0[NV], db0[NV], dg1[NV], db1[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg0[i] = make_float4(0, 0, 0, 0); db0[i] = dg0[i]; dg1[i] = dg0[i]; db1[i] = dg0[i];
+    }
+    const int row0 = blockIdx.x * LN_ROWS_PER_BLOCK + wave * LN_ROWS_PER_WAVE;
+    for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        const int mod = row_mod ? row_mod[row] : 0;
+        const float mean = mean_in[row], rs = rstd_in[row];
+        const int drow = out_map ? out_map[row] : row;
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+        const uint2* dyr = reinterpret_cast<const uint2*>(dy + (size_t)drow * D);
+        const float4* gp = reinterpret_cast<const float4*>(mod ? g1 : g0);
+        float4 xh[NV], gy[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 xv = xr[i * 64 + lane];
+            const uint2 dv = dyr[i * 64 + lane];
+            const float4 g = gp[i * 64 + lane];
+            float4 d;
+            d.x = __uint_as_float(dv.x << 16); d.y = __uint_as_float(dv.x & 0xffff0000u);
+            d.z = __uint_as_float(dv.y << 16); d.w = __uint_as_float(dv.y & 0xffff0000u);
+            xh[i].x = (xv.x - mean) * rs; xh[i].y = (xv.y - mean) * rs;
+            xh[i].z = (xv.z - mean) * rs; xh[i].w = (xv.w - mean) * rs;
+            gy[i].x = d.x * g.x; gy[i].y = d.y * g.y; gy[i].z = d.z * g.z; gy[i].w = d.w * g.w;
+            s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
+            s2 += (gy[i].x * xh[i].x + gy[i].y * xh[i].y) + (gy[i].z * xh[i].z + gy[i].w * xh[i].w);
+            if (mod) {                                       // wave-uniform branch
+                dg1[i].x += d.x * xh[i].x; dg1[i].y += d.y * xh[i].y; dg1[i].z += d.z * xh[i].z; dg1[i].w += d.w * xh[i].w;
+                db1[i].x += d.x; db1[i].y += d.y; db1[i].z += d.z; db1[i].w += d.w;
+            } else {
+                dg0[i].x += d.x * xh[i].x; dg0[i].y += d.y * xh[i].y; dg0[i].z += d.z * xh[i].z; dg0[i].w += d.w * xh[i].w;
+                db0[i].x += d.x; db0[i].y += d.y; db0[i].z += d.z; db0[i].w += d.w;
+            }
+        }
+        const float m1 = wave_sum(s1) * (1.0f / D);
+        const float m2 = wave_sum(s2) * (1.0f / D);
+        float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * D);
+        const float4* drr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * D) : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float4 o;
+            o.x = rs * (gy[i].x - m1 - xh[i].x * m2); o.y = rs * (gy[i].y - m1 - xh[i].y * m2);
+            o.z = rs * (gy[i].z - m1 - xh[i].z * m2); o.w = rs * (gy[i].w - m1 - xh[i].w * m2);
+            if (drr) {
+                const float4 r = drr[i * 64 + lane];
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            dxr[i * 64 + lane] = o;
+        }
+    }
+    // cross-wave reduction of the four accumulator sets, one set at a time through LDS
+    float* slab = ws + (size_t)blockIdx.x * 4 * D;
+#pragma unroll
+    for (int set = 0; set < 4; ++set) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 a = set == 0 ? dg0[i] : set == 1 ? db0[i] : set == 2 ? dg1[i] : db1[i];
+            reinterpret_cast<float4*>(red[wave])[i * 64 + lane] = a;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) slab[set * D + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, int D, float* dg0, float* db0,
+                                     float* dg1, float* db1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int set = blockIdx.y;
+    if (c >= D) return;
+    float* dst = set == 0 ? dg0 : set == 1 ? db0 : set == 2 ? dg1 : db1;
+    if (!dst) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += ws[((size_t)b * 4 + set) * D + c];
+    dst[c] += s;
+}
+
+extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, LN_ROWS_PER_BLOCK) * 4 * D; }
+
+extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                                 const uint8_t* row_mod, const int* out_map, bf16_t* y, float* mean, float* rstd,
+                                 int rows, int D, float eps, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
+    AVS_CHECK_ARG(x && g0 && b0 && y && mean && rstd, "layernorm_fwd: null pointer");
+    AVS_CHECK_ARG(!row_mod || (g1 && b1), "layernorm_fwd: row_mod given without second affine set");
+    dim3 grid(ceil_div(rows, 4)), block(256);
+    if (D == 512) ln_fwd_kernel<2><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps);
+    else if (D == 768) ln_fwd_kernel<3><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps);
+    else ln_fwd_kernel<4><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps);
+    AVS_LAUNCH_CHECK("layernorm_fwd");
+    return 0;
+}
+
+// dg*/db* are ACCUMULATED into (+=); dx may alias dres.  ws: avs_layernorm_ws_floats(rows, D) floats.
+extern "C" int avs_layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* g0,
+                                 const float* g1, const uint8_t* row_mod, const int* out_map, const float* dres,
+                                 float* dx, float* dg0, float* db0, float* dg1, float* db1, float* ws, int rows, int D,
+                                 hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
+    AVS_CHECK_ARG(dy && x && mean && rstd && g0 && dx && ws, "layernorm_bwd: null pointer");
+    const int nblocks = ceil_div(rows, LN_ROWS_PER_BLOCK);
+    dim3 grid(nblocks), block(256);
+    if (D == 512) ln_bwd_kernel<2><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, ws, rows);
+    else if (D == 768) ln_bwd_kernel<3><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, ws, rows);
+    else ln_bwd_kernel<4><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, ws, rows);
+    AVS_LAUNCH_CHECK("layernorm_bwd");
+    ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), 4), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1);
+    AVS_LAUNCH_CHECK("layernorm_bwd_reduce");
+    return 0;
+}

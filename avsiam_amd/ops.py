@@ -1,0 +1,291 @@
+"""Host-side wrappers of the C ABI: shape/dtype/device validation, then one kernel launch on torch's current
+stream.  Every function here runs ONLY on the HIP kernels; there is no eager fallback.
+
+Shapes are validated on the host before any launch: a hand-written kernel that faults can reset the GPU.
+"""
+import torch
+
+from . import _lib
+
+BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
+
+
+def _chk(t, dtype, name, ndim=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.AvsiamHipError(f"{name}: tensor must live on the GPU")
+    if t.dtype != dtype:
+        raise _lib.AvsiamHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.AvsiamHipError(f"{name}: tensor must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise _lib.AvsiamHipError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+
+
+def _stream():
+    return _lib.current_stream()
+
+
+def pad_rows(n, mult=128):
+    return (n + mult - 1) // mult * mult
+
+
+# ---------------------------------------------------------------------------------------------------
+def layernorm_ws(rows, D):
+    return _lib.load().avs_layernorm_ws_floats(rows, D)
+
+
+def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod=None, out_map=None):
+    D = x.shape[1]
+    _chk(x, F32, "ln.x", 2); _chk(y, BF16, "ln.y", 2); _chk(mean, F32, "ln.mean"); _chk(rstd, F32, "ln.rstd")
+    _chk(g0, F32, "ln.g0"); _chk(b0, F32, "ln.b0"); _chk(g1, F32, "ln.g1"); _chk(b1, F32, "ln.b1")
+    _chk(row_mod, U8, "ln.row_mod"); _chk(out_map, I32, "ln.out_map")
+    assert x.shape[0] >= rows and mean.numel() >= rows and rstd.numel() >= rows and y.shape[1] == D
+    assert g0.numel() == D and b0.numel() == D
+    if row_mod is not None:
+        assert row_mod.numel() >= rows and g1 is not None and b1 is not None and g1.numel() == D
+    if out_map is not None:
+        assert out_map.numel() >= rows
+    else:
+        assert y.shape[0] >= rows
+    _lib.call("avs_layernorm_fwd", x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, D, float(eps), _stream())
+
+
+def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=None, db1=None, row_mod=None,
+                  out_map=None, dres=None):
+    D = x.shape[1]
+    _chk(dy, BF16, "lnb.dy", 2); _chk(x, F32, "lnb.x", 2); _chk(dx, F32, "lnb.dx", 2); _chk(dres, F32, "lnb.dres", 2)
+    _chk(ws, F32, "lnb.ws"); _chk(row_mod, U8, "lnb.row_mod"); _chk(out_map, I32, "lnb.out_map")
+    for t, n in ((g0, "g0"), (g1, "g1"), (dg0, "dg0"), (db0, "db0"), (dg1, "dg1"), (db1, "db1"), (mean, "mean"), (rstd, "rstd")):
+        _chk(t, F32, "lnb." + n)
+    assert x.shape[0] >= rows and dx.shape[0] >= rows and dy.shape[1] == D and dx.shape[1] == D
+    assert ws.numel() >= layernorm_ws(rows, D)
+    if out_map is None:
+        assert dy.shape[0] >= rows
+    if dres is not None:
+        assert dres.shape[0] >= rows and dres.shape[1] == D
+    _lib.call("avs_layernorm_bwd", dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dg0, db0, dg1, db1, ws, rows, D,
+              _stream())
+
+
+# ---------------------------------------------------------------------------------------------------
+def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None, alpha=1.0, act=0):
+    """out[M,N] = alpha * (A[M,K] @ B[N,K]^T + bias [* gelu'(aux)] + res[res_idx])."""
+    _chk(A, BF16, "gemm.A", 2); _chk(B, BF16, "gemm.B", 2); _chk(bias, F32, "gemm.bias"); _chk(res, F32, "gemm.res", 2)
+    _chk(res_idx, I32, "gemm.res_idx"); _chk(aux, BF16, "gemm.aux", 2); _chk(out2, BF16, "gemm.out2", 2)
+    if out.dtype not in (BF16, F32) or not out.is_cuda or not out.is_contiguous() or out.dim() != 2:
+        raise _lib.AvsiamHipError("gemm.out: need contiguous 2-D bf16/fp32 GPU tensor")
+    N, K = B.shape
+    assert A.shape[1] == K and A.shape[0] >= M and out.shape[0] >= M and out.shape[1] == N, (A.shape, B.shape, out.shape, M)
+    if bias is not None:
+        assert bias.numel() == N
+    if res is not None:
+        assert res.shape[1] == N
+        if res_idx is None:
+            assert res.shape[0] >= M
+        else:
+            assert res_idx.numel() >= M
+    if act == 1:
+        assert out2 is not None and out2.shape[0] >= M and out2.shape[1] == N
+    if act == 2:
+        assert aux is not None and aux.shape[0] >= M and aux.shape[1] == N
+    _lib.call("avs_gemm_nt_bf16", A, A.stride(0), B, B.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
+              res_idx, aux, aux.stride(0) if aux is not None else 0, out, out.stride(0), 1 if out.dtype == F32 else 0, out2,
+              out2.stride(0) if out2 is not None else 0, float(alpha), act, _stream())
+
+
+def gemm_tn(A, B, C, M, splits=0):
+    """C[N1,N2] += A[M,N1]^T @ B[M,N2]; A/B zero-padded to a multiple of 64 rows."""
+    _chk(A, BF16, "wgrad.A", 2); _chk(B, BF16, "wgrad.B", 2); _chk(C, F32, "wgrad.C")
+    N1, N2 = A.shape[1], B.shape[1]
+    need = pad_rows(M, 64)
+    assert A.shape[0] >= need and B.shape[0] >= need, "wgrad operands must be allocated (zero) to a multiple of 64 rows"
+    assert C.numel() == N1 * N2
+    _lib.call("avs_gemm_tn_bf16", A, A.stride(0), B, B.stride(0), C, N2, M, N1, N2, splits, _stream())
+
+
+# ---------------------------------------------------------------------------------------------------
+class AttnTiles:
+    """(sequence start, length, q0) per 128-row tile for a packed batch of sequences."""
+
+    def __init__(self, seq_lens, device, start_row=0):
+        starts, lens, q0s = [], [], []
+        row = start_row
+        for L in seq_lens:
+            for q0 in range(0, L, 128):
+                starts.append(row); lens.append(L); q0s.append(q0)
+            row += L
+        self.rows = row - start_row
+        self.ntiles = len(starts)
+        self.start = torch.tensor(starts, dtype=I32, device=device)
+        self.len = torch.tensor(lens, dtype=I32, device=device)
+        self.q0 = torch.tensor(q0s, dtype=I32, device=device)
+        self.max_row = row
+
+
+def attn_fwd(qkv, tiles, H, out, lse):
+    _chk(qkv, BF16, "attn.qkv", 2); _chk(out, BF16, "attn.out", 2); _chk(lse, F32, "attn.lse", 2)
+    D = qkv.shape[1] // 3
+    assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64)
+    assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row
+    assert lse.shape[0] == H and lse.shape[1] >= tiles.max_row
+    _lib.call("avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, out, out.stride(0),
+              lse, lse.shape[1], _stream())
+
+
+def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
+    _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2)
+    _chk(lse, F32, "attnb.lse", 2); _chk(delta, F32, "attnb.delta", 2); _chk(dqkv, BF16, "attnb.dqkv", 2)
+    D = qkv.shape[1] // 3
+    assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape
+    assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
+    _lib.call("avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, out, dout,
+              out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
+
+
+# ---------------------------------------------------------------------------------------------------
+def im2col_audio(a, row_b, row_tok, out, rows, t_patches):
+    _chk(a, F32, "im2col.a", 3); _chk(row_b, I32, "im2col.row_b"); _chk(row_tok, I32, "im2col.row_tok"); _chk(out, BF16, "im2col.out", 2)
+    assert out.shape[1] == 256 and out.shape[0] >= rows and row_b.numel() >= rows and row_tok.numel() >= rows
+    assert a.shape[1] == t_patches * 16 and a.shape[2] % 16 == 0
+    _lib.call("avs_im2col_audio", a, row_b, row_tok, out, rows, a.shape[1], a.shape[2], t_patches, _stream())
+
+
+def im2col_video(v, row_img, row_tok, out, rows):
+    _chk(v, F32, "im2col.v", 4); _chk(row_img, I32, "im2col.row_img"); _chk(row_tok, I32, "im2col.row_tok"); _chk(out, BF16, "im2col.out", 2)
+    NF, C, H, W = v.shape
+    assert out.shape[1] == C * 256 and out.shape[0] >= rows and row_img.numel() >= rows and row_tok.numel() >= rows
+    _lib.call("avs_im2col_video", v, row_img, row_tok, out, rows, C, H, W, _stream())
+
+
+def cast_scale(x, y, n, alpha):
+    _chk(x, F32, "cast.x"); _chk(y, BF16, "cast.y")
+    assert x.numel() >= n and y.numel() >= n and n % 4 == 0
+    _lib.call("avs_cast_scale_bf16", x, y, n, float(alpha), _stream())
+
+
+def scatter_add_rows(src, idx, dst, rows, scale=1.0):
+    _chk(src, BF16, "scatter.src", 2); _chk(idx, I32, "scatter.idx"); _chk(dst, F32, "scatter.dst")
+    D = src.shape[1]
+    assert src.shape[0] >= rows and idx.numel() >= rows and dst.numel() % D == 0
+    _lib.call("avs_scatter_add_rows", src, idx, dst, rows, D, float(scale), _stream())
+
+
+def colsum(x, out, rows):
+    _chk(x, BF16, "colsum.x", 2); _chk(out, F32, "colsum.out")
+    assert x.shape[0] >= rows and out.numel() == x.shape[1]
+    _lib.call("avs_colsum_bf16", x, out, rows, x.shape[1], _stream())
+
+
+def unshuffle_fwd(x, src_row, pos_row, row_mod, mask_token, pos_a, pos_v, mod_a, mod_v, out, rows):
+    _chk(x, F32, "unshuffle.x", 2); _chk(out, F32, "unshuffle.out", 2); _chk(src_row, I32, "unshuffle.src"); _chk(pos_row, I32, "unshuffle.pos")
+    _chk(row_mod, U8, "unshuffle.mod")
+    D = x.shape[1]
+    for t in (mask_token, pos_a, pos_v, mod_a, mod_v):
+        _chk(t, F32, "unshuffle.param")
+    assert out.shape[1] == D and out.shape[0] >= rows and src_row.numel() >= rows and pos_row.numel() >= rows and row_mod.numel() >= rows
+    assert mask_token.numel() == D and mod_a.numel() == D and mod_v.numel() == D
+    _lib.call("avs_unshuffle_fwd", x, src_row, pos_row, row_mod, mask_token, pos_a, pos_v, pos_a.numel() // D, mod_a, mod_v, out,
+              rows, D, _stream())
+
+
+def unshuffle_bwd(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v):
+    _chk(dout, F32, "unshuffleb.dout", 2); _chk(dx, F32, "unshuffleb.dx", 2); _chk(src_row, I32, "unshuffleb.src")
+    D = dout.shape[1]
+    assert dout.shape[0] >= B * (La + T * Lv) and src_row.numel() >= B * (La + T * Lv) and dx.shape[1] == D
+    assert dpos_a.numel() == La * D and dpos_v.numel() == Lv * D and dmask.numel() == D
+    _lib.call("avs_unshuffle_bwd", dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, _stream())
+
+
+def segment_mean_fwd(y, seg_start, reps, nseg):
+    _chk(y, BF16, "segmean.y", 2); _chk(seg_start, I32, "segmean.seg"); _chk(reps, F32, "segmean.reps", 2)
+    assert seg_start.numel() >= nseg + 1 and reps.shape[0] >= nseg and reps.shape[1] == y.shape[1]
+    _lib.call("avs_segment_mean_fwd", y, seg_start, reps, nseg, y.shape[1], _stream())
+
+
+def segment_mean_bwd(dreps, seg_start, dy, nseg):
+    _chk(dy, BF16, "segmeanb.dy", 2); _chk(seg_start, I32, "segmeanb.seg"); _chk(dreps, F32, "segmeanb.dreps", 2)
+    assert seg_start.numel() >= nseg + 1 and dreps.shape[0] >= nseg and dreps.shape[1] == dy.shape[1]
+    _lib.call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], _stream())
+
+
+def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask):
+    _chk(pred, F32, "mae.pred", 2); _chk(inp, F32, "mae.inp"); _chk(mask, F32, "mae.mask"); _chk(row_loss, F32, "mae.row_loss"); _chk(loss, F32, "mae.loss")
+    rows = mask.numel()
+    if audio:
+        C, H, W = 1, inp.shape[1], inp.shape[2]          # [B, time, mel]
+        assert inp.dim() == 3 and rows == inp.shape[0] * L and pred.shape[1] == 256 and (H // 16) * (W // 16) == L
+    else:
+        C, H, W = inp.shape[-3:]
+        assert rows == inp.numel() // (C * H * W) * L and pred.shape[1] == 256 * C and (H // 16) * (W // 16) == L
+    assert pred.shape[0] >= rows and row_loss.numel() >= rows
+    _lib.call("avs_mae_loss_fwd", pred, inp, mask, row_loss, loss, rows, int(audio), L, C, H, W, float(nmask), _stream())
+
+
+def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask):
+    _chk(pred, F32, "maeb.pred", 2); _chk(inp, F32, "maeb.inp"); _chk(mask, F32, "maeb.mask"); _chk(gout, F32, "maeb.gout"); _chk(dpred, BF16, "maeb.dpred", 2)
+    rows = mask.numel()
+    if audio:
+        C, H, W = 1, inp.shape[1], inp.shape[2]
+    else:
+        C, H, W = inp.shape[-3:]
+    assert pred.shape[0] >= rows and dpred.shape[0] >= rows and dpred.shape[1] == pred.shape[1] == 256 * C
+    _lib.call("avs_mae_loss_bwd", pred, inp, mask, gout, dpred, rows, int(audio), L, C, H, W, float(nmask), _stream())
+
+
+def l2norm_fwd(x, xn, norm):
+    _chk(x, F32, "l2.x", 2); _chk(xn, F32, "l2.xn", 2); _chk(norm, F32, "l2.norm")
+    assert xn.shape == x.shape and norm.numel() >= x.shape[0]
+    _lib.call("avs_l2norm_fwd", x, xn, norm, x.shape[0], x.shape[1], _stream())
+
+
+def l2norm_bwd(dxn, xn, norm, dx, scale=1.0):
+    for t in (dxn, xn, dx):
+        _chk(t, F32, "l2b", 2)
+    _chk(norm, F32, "l2b.norm")
+    assert dxn.shape == xn.shape == dx.shape
+    _lib.call("avs_l2norm_bwd", dxn, xn, norm, dx, xn.shape[0], xn.shape[1], float(scale), _stream())
+
+
+def gemm_f32_small(A, B, C, M, N, K, sa, sb, alpha=1.0):
+    """C[M,N] = alpha * sum_k A(m,k) B(k,n); sa = (stride_m, stride_k) of A, sb = (stride_k, stride_n) of B, in elements."""
+    _chk(A, F32, "sgemm.A"); _chk(B, F32, "sgemm.B"); _chk(C, F32, "sgemm.C", 2)
+    assert C.shape[0] >= M and C.shape[1] == N
+    assert (M - 1) * sa[0] + (K - 1) * sa[1] < A.numel() and (K - 1) * sb[0] + (N - 1) * sb[1] < B.numel()
+    _lib.call("avs_gemm_f32_small", A, sa[0], sa[1], B, sb[0], sb[1], C, C.stride(0), M, N, K, float(alpha), _stream())
+
+
+def infonce_fwd(total, stats, out):
+    _chk(total, F32, "nce.total", 2); _chk(stats, F32, "nce.stats", 2); _chk(out, F32, "nce.out")
+    N = total.shape[0]
+    assert total.shape[1] == N and stats.shape == (N, 4) and out.numel() >= 2
+    _lib.call("avs_infonce_fwd", total, stats, out, N, _stream())
+
+
+def infonce_dlogits(total, stats, gout, weight, dtotal):
+    _chk(total, F32, "nceb.total", 2); _chk(stats, F32, "nceb.stats", 2); _chk(gout, F32, "nceb.gout"); _chk(dtotal, F32, "nceb.dtotal", 2)
+    N = total.shape[0]
+    assert dtotal.shape == total.shape
+    _lib.call("avs_infonce_dlogits", total, stats, gout, float(weight), dtotal, N, _stream())
+
+
+def transpose_bf16(x, out):
+    _chk(x, BF16, "tr.x", 2); _chk(out, BF16, "tr.out", 2)
+    assert out.shape == (x.shape[1], x.shape[0])
+    _lib.call("avs_transpose_bf16", x, out, x.shape[0], x.shape[1], _stream())
+
+
+def cast_bf16(x, y, n):
+    _chk(x, F32, "castb.x"); _chk(y, BF16, "castb.y")
+    assert x.numel() >= n and y.numel() >= n
+    _lib.call("avs_cast_bf16", x, y, n, _stream())
+
+
+def adam(p, g, m, v, p_bf16, n, lr, step, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=5e-7, grad_scale=1.0):
+    for t in (p, g, m, v):
+        _chk(t, F32, "adam")
+    _chk(p_bf16, BF16, "adam.p_bf16")
+    assert n % 4 == 0 and all(t.numel() >= n for t in (p, g, m, v)) and (p_bf16 is None or p_bf16.numel() >= n)
+    _lib.call("avs_adam", p, g, m, v, p_bf16, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+              float(grad_scale), _stream())

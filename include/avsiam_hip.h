@@ -1,0 +1,110 @@
+/* libavsiam_hip.so - C ABI of the MI355X (gfx950) kernels behind the AVSiam pre-training hot path.
+ *
+ * The reference (GenjiB/AVSiam) has no native code and no FFI: its hot path is torch.nn calls inside
+ * src/models/cav_mae_base.py.  Each entry point below names the reference operation it replaces (file:line
+ * relative to /root/reference).  The binding a maintainer adds on the reference side is the ctypes loader of
+ * INTEGRATION.md (avsiam_amd/_lib.py is that loader).
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers; bf16 tensors are raw uint16_t bits; row-major; leading dimensions in elements
+ *  - kernels are enqueued on `stream` and never synchronise, allocate or take ownership
+ *  - return 0 on success, -1 runtime/launch error, -2 bad argument; avs_last_error() describes the failure
+ *  - re-entrant per stream; the only global state is the thread-local error string
+ */
+#ifndef AVSIAM_HIP_H
+#define AVSIAM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* avs_stream_t;
+typedef uint16_t avs_bf16;
+
+const char* avs_last_error(void);
+int avs_abi_version(void);
+int avs_device_cu_count(void);
+
+/* ---- LayerNorm with per-row modality affine (Block.norm1/_a/_v, norm2/_a/_v: src/models/cav_mae_base.py:120-122,
+ * 135-137,151-152,169-170,190-191; final norms :492,495,563,566,631).  x fp32 [rows,D] -> y bf16.  row_mod (0/1 per
+ * row, may be NULL) picks (g0,b0) or (g1,b1); out_map (may be NULL) redirects output row r to y[out_map[r]]. */
+int avs_layernorm_ws_floats(int rows, int D);
+int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                      const uint8_t* row_mod, const int* out_map, avs_bf16* y, float* mean, float* rstd, int rows, int D,
+                      float eps, avs_stream_t stream);
+/* dx = dres + LN'(dy) (dres may be NULL; dx may alias dres); dg/db are accumulated (+=); ws: avs_layernorm_ws_floats */
+int avs_layernorm_bwd(const avs_bf16* dy, const float* x, const float* mean, const float* rstd, const float* g0,
+                      const float* g1, const uint8_t* row_mod, const int* out_map, const float* dres, float* dx, float* dg0,
+                      float* db0, float* dg1, float* db1, float* ws, int rows, int D, avs_stream_t stream);
+
+/* ---- bf16 MFMA GEMMs (nn.Linear / PatchEmbed.proj and their backward: cav_mae_base.py:51,55,60,77,96-99,138-143,
+ * 600,634-635).  nt: out = alpha*(A[M,K].B[N,K]^T + bias [*gelu'(aux)] + res[res_idx? res_idx[m] : m]); act 0 none,
+ * 1 gelu (out = pre-activation, out2 = gelu(out) bf16), 2 gelu-backward (aux = saved pre-activation).  N%128==0, K%64==0. */
+int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, int M, int N, int K,
+                     const float* bias, const float* res, long long ldr, const int* res_idx, const avs_bf16* aux,
+                     long long ldaux, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
+                     int act, avs_stream_t stream);
+/* tn (weight gradient): C[N1,N2] += A[M,N1]^T . B[M,N2], fp32 atomics; A and B must be allocated and ZERO up to the
+ * next multiple of 64 rows; N1%128==0, N2%128==0; splits<=0 picks a split of the contraction that fills the chip. */
+int avs_gemm_tn_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, float* C, long long ldc, int M,
+                     int N1, int N2, int splits, avs_stream_t stream);
+
+/* ---- varlen attention (F.scaled_dot_product_attention in Attention.forward, cav_mae_base.py:60-68) on the packed
+ * qkv matrix [rows, 3*D] (q|k|v, head h at columns h*hd); one (tile_start, tile_len, tile_q0) triple per 128-row tile.
+ * lse/delta: [H][rows_total] fp32. */
+int avs_attn_fwd(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                 const int* tile_q0, int ntiles, avs_bf16* out, long long ldo, float* lse, int rows_total,
+                 avs_stream_t stream);
+int avs_attn_bwd(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                 const int* tile_q0, int ntiles, const avs_bf16* out, const avs_bf16* dout, long long ldo, const float* lse,
+                 float* delta, int rows_total, avs_bf16* dqkv, avs_stream_t stream);
+
+/* ---- patch gather of the kept tokens (PatchEmbed input side + random_masking gather: cav_mae_base.py:96-99,
+ * 382,431,444-455) */
+int avs_im2col_audio(const float* a, const int* row_b, const int* row_tok, avs_bf16* out, int rows, int tlen, int mel,
+                     int t_patches, avs_stream_t stream);
+int avs_im2col_video(const float* v, const int* row_img, const int* row_tok, avs_bf16* out, int rows, int C, int H, int W,
+                     avs_stream_t stream);
+int avs_cast_scale_bf16(const float* x, avs_bf16* y, long long n, float alpha, avs_stream_t stream);
+int avs_scatter_add_rows(const avs_bf16* src, const int* idx, float* dst, int rows, int D, float scale, avs_stream_t stream);
+int avs_colsum_bf16(const avs_bf16* x, float* out, int rows, int C, avs_stream_t stream);
+
+/* ---- decoder un-shuffle (forward_decoder, cav_mae_base.py:604-626) */
+int avs_unshuffle_fwd(const float* x, const int* src_row, const int* pos_row, const uint8_t* row_mod,
+                      const float* mask_token, const float* pos_a, const float* pos_v, int La, const float* mod_a,
+                      const float* mod_v, float* out, int rows, int D, avs_stream_t stream);
+int avs_unshuffle_bwd(const float* dout, const int* src_row, int B, int T, int La, int Lv, float* dx, float* dpos_a,
+                      float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D, avs_stream_t stream);
+
+/* ---- token mean per packed sequence (.mean(dim=1), cav_mae_base.py:563,566) */
+int avs_segment_mean_fwd(const avs_bf16* y, const int* seg_start, float* reps, int nseg, int D, avs_stream_t stream);
+int avs_segment_mean_bwd(const float* dreps, const int* seg_start, avs_bf16* dy, int nseg, int D, avs_stream_t stream);
+
+/* ---- masked-MSE with patchify on the fly (patchify + forward_mae_loss, cav_mae_base.py:343-351,663-683) */
+int avs_mae_loss_fwd(const float* pred, const float* inp, const float* mask, float* row_loss, float* loss, int rows,
+                     int audio, int L, int C, int H, int W, float nmask, avs_stream_t stream);
+int avs_mae_loss_bwd(const float* pred, const float* inp, const float* mask, const float* gout, avs_bf16* dpred, int rows,
+                     int audio, int L, int C, int H, int W, float nmask, avs_stream_t stream);
+
+/* ---- bidirectional InfoNCE (forward_contrastive, cav_mae_base.py:641-661) */
+int avs_l2norm_fwd(const float* x, float* xn, float* norm, int rows, int D, avs_stream_t stream);
+int avs_l2norm_bwd(const float* dxn, const float* xn, const float* norm, float* dx, int rows, int D, float scale,
+                   avs_stream_t stream);
+int avs_gemm_f32_small(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
+                       long long scm, int M, int N, int K, float alpha, avs_stream_t stream);
+int avs_infonce_fwd(const float* total, float* stats, float* out, int N, avs_stream_t stream);
+int avs_infonce_dlogits(const float* total, const float* stats, const float* gout, float weight, float* dtotal, int N,
+                        avs_stream_t stream);
+
+/* ---- weights: bf16 shadow copies and the fused Adam step (torch.optim.Adam as built at
+ * src/traintest_cavmae_base.py:64-66) */
+int avs_transpose_bf16(const avs_bf16* in, avs_bf16* out, int R, int C, avs_stream_t stream);
+int avs_cast_bf16(const float* x, avs_bf16* y, long long n, avs_stream_t stream);
+int avs_adam(float* p, const float* g, float* m, float* v, avs_bf16* p_bf16, long long n, float lr, float beta1,
+             float beta2, float eps, float weight_decay, int step, float grad_scale, avs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

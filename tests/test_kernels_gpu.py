@@ -1,0 +1,357 @@
+"""Per-kernel numerics on a real MI355X: every HIP kernel (called through the C ABI) against a plain
+PyTorch fp32/fp64 reference of the same op on the same inputs.  bf16-operand kernels are compared against the
+reference evaluated on the SAME bf16-rounded operands (so the tolerance covers only accumulation order and the
+bf16 rounding of the output)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from avsiam_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available()
+    torch.manual_seed(0)
+
+
+def ops():
+    from avsiam_amd import ops as o
+    return o
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("D,rows", [(768, 1000), (512, 333), (1024, 70)])
+def test_layernorm(D, rows):
+    o = ops()
+    x = torch.randn(rows, D, device=DEV) * 2 + 0.3
+    g = [torch.randn(D, device=DEV) * 0.1 + 1 for _ in range(2)]
+    b = [torch.randn(D, device=DEV) * 0.1 for _ in range(2)]
+    mod = (torch.rand(rows, device=DEV) > 0.5).to(torch.uint8)
+    perm = torch.randperm(rows, device=DEV).to(torch.int32)
+    y = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+    o.layernorm_fwd(x, g[0], b[0], y, mean, rstd, rows, 1e-5, g[1], b[1], mod, perm)
+    xr = x.double().requires_grad_(True)
+    gr = [t.double().requires_grad_(True) for t in g]
+    br = [t.double().requires_grad_(True) for t in b]
+    y0 = F.layer_norm(xr, (D,), gr[0], br[0], 1e-5)
+    y1 = F.layer_norm(xr, (D,), gr[1], br[1], 1e-5)
+    yr = torch.where(mod.bool()[:, None], y1, y0)
+    got = y.double()[perm.long()]                     # output row r was redirected to y[out_map[r]]
+    assert rel_err(got, yr) < 4e-3
+    # backward
+    dy_nat = torch.randn(rows, D, device=DEV)
+    dy = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    dy[perm.long()] = bf(dy_nat)
+    dres = torch.randn(rows, D, device=DEV)
+    dx = torch.empty(rows, D, device=DEV)
+    dg = [torch.zeros(D, device=DEV) for _ in range(2)]
+    db = [torch.zeros(D, device=DEV) for _ in range(2)]
+    ws = torch.empty(o.layernorm_ws(rows, D), device=DEV)
+    o.layernorm_bwd(dy, x, mean, rstd, g[0], dx, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres)
+    (yr * bf(dy_nat).double()).sum().backward()
+    assert rel_err(dx, xr.grad + dres.double()) < 1e-4
+    for i in range(2):
+        assert rel_err(dg[i], gr[i].grad) < 1e-4
+        assert rel_err(db[i], br[i].grad) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(333, 256, 768), (1000, 768, 3072), (4099, 2304, 768), (128, 512, 256)])
+def test_gemm_nt_epilogues(M, N, K):
+    o = ops()
+    A = bf(torch.randn(M, K, device=DEV))
+    W = bf(torch.randn(N, K, device=DEV) * 0.05)
+    bias = torch.randn(N, device=DEV)
+    ref = A.double() @ W.double().t()
+    out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm_nt(A, W, out, M, bias=bias)
+    assert rel_err(out, ref + bias.double()) < 4e-3
+    # fp32 out + residual (row-gathered) + alpha
+    res = torch.randn(50, N, device=DEV)
+    idx = torch.randint(0, 50, (M,), device=DEV, dtype=torch.int32)
+    outf = torch.zeros(M, N, device=DEV)
+    o.gemm_nt(A, W, outf, M, bias=bias, res=res, res_idx=idx, alpha=2.0)
+    assert rel_err(outf, 2 * (ref + bias.double() + res.double()[idx.long()])) < 1e-5
+    res2 = torch.randn(M, N, device=DEV)
+    o.gemm_nt(A, W, outf, M, bias=bias, res=res2)
+    assert rel_err(outf, ref + bias.double() + res2.double()) < 1e-5
+    # gelu dual output
+    pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    act = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm_nt(A, W, pre, M, bias=bias, out2=act, act=1)
+    assert rel_err(pre, ref + bias.double()) < 4e-3
+    assert rel_err(act, F.gelu(ref + bias.double())) < 5e-3
+    # gelu backward epilogue
+    dpre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm_nt(A, W, dpre, M, aux=pre, act=2)
+    p = pre.double().requires_grad_(True)
+    F.gelu(p).backward(ref)
+    assert rel_err(dpre, p.grad) < 5e-3
+
+
+@pytest.mark.parametrize("M,N1,N2,splits", [(64, 128, 128, 1), (1000, 256, 768, 0), (4099, 768, 256, 3), (333, 2304, 768, 0)])
+def test_gemm_tn(M, N1, N2, splits):
+    o = ops()
+    Mp = o.pad_rows(M, 64)
+    A = torch.zeros(Mp, N1, device=DEV, dtype=torch.bfloat16)
+    B = torch.zeros(Mp, N2, device=DEV, dtype=torch.bfloat16)
+    A[:M] = bf(torch.randn(M, N1, device=DEV))
+    B[:M] = bf(torch.randn(M, N2, device=DEV))
+    C = torch.ones(N1, N2, device=DEV)
+    o.gemm_tn(A, B, C, M, splits)
+    ref = A.double().t() @ B.double() + 1
+    assert rel_err(C, ref) < 1e-5
+
+
+def _attn_ref(qkv, lens, H):
+    D = qkv.shape[1] // 3
+    hd = D // H
+    outs = []
+    row = 0
+    for L in lens:
+        x = qkv[row:row + L].reshape(L, 3, H, hd).permute(1, 2, 0, 3)
+        q, k, v = x[0], x[1], x[2]
+        a = (q @ k.transpose(-1, -2)) * hd ** -0.5
+        outs.append((a.softmax(-1) @ v).permute(1, 0, 2).reshape(L, D))
+        row += L
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("H,hd,lens", [(12, 64, [39, 128, 177, 512, 1, 65]), (16, 32, [708, 33, 200]), (2, 64, [300])])
+def test_attention_fwd_bwd(H, hd, lens):
+    o = ops()
+    D = H * hd
+    rows = sum(lens)
+    rp = o.pad_rows(rows)
+    qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
+    qkv[:rows] = bf(torch.randn(rows, 3 * D, device=DEV))
+    tiles = o.AttnTiles(lens, DEV)
+    out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(H, rp, device=DEV)
+    o.attn_fwd(qkv, tiles, H, out, lse)
+    qr = qkv[:rows].double().requires_grad_(True)
+    ref = _attn_ref(qr, lens, H)
+    assert rel_err(out[:rows], ref) < 6e-3
+    dout = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    dout[:rows] = bf(torch.randn(rows, D, device=DEV))
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.zeros_like(lse)
+    o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv)
+    (ref * dout[:rows].double()).sum().backward()
+    g = qr.grad
+    for i, name in enumerate("qkv"):
+        e = rel_err(dqkv[:rows, i * D:(i + 1) * D], g[:, i * D:(i + 1) * D])
+        assert e < 1.5e-2, (name, e)
+    assert dqkv[rows:].abs().max().item() == 0
+
+
+def test_attention_spiked_scores():
+    """Large score spread: forces online-softmax rescaling across key tiles (max grows late)."""
+    o = ops()
+    H, hd, L = 2, 64, 200
+    D = H * hd
+    rp = o.pad_rows(L)
+    x = torch.randn(L, 3 * D, device=DEV)
+    x[150, D:2 * D] *= 8.0          # one late key dominates
+    x[10, :D] *= 6.0
+    qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
+    qkv[:L] = bf(x)
+    tiles = o.AttnTiles([L], DEV)
+    out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(H, rp, device=DEV)
+    o.attn_fwd(qkv, tiles, H, out, lse)
+    ref = _attn_ref(qkv[:L].double(), [L], H)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out[:L], ref) < 8e-3
+
+
+def test_im2col_and_patch_embed_matches_conv():
+    o = ops()
+    B, Tlen, mel = 3, 256, 128
+    a = torch.randn(B, Tlen, mel, device=DEV)
+    tP = Tlen // 16
+    La = tP * (mel // 16)
+    row_b = torch.arange(B, device=DEV).repeat_interleave(La).to(torch.int32)
+    row_tok = torch.arange(La, device=DEV).repeat(B).to(torch.int32)
+    out = torch.zeros(B * La, 256, device=DEV, dtype=torch.bfloat16)
+    o.im2col_audio(a, row_b, row_tok, out, B * La, tP)
+    w = torch.randn(64, 1, 16, 16, device=DEV)
+    img = bf(a).float().unsqueeze(1).transpose(2, 3)
+    ref = F.conv2d(img.double(), w.double(), stride=16).flatten(2).transpose(1, 2).reshape(B * La, 64)
+    got = out.double() @ w.double().reshape(64, 256).t()
+    assert rel_err(got, ref) < 1e-6
+    v = torch.randn(2, 3, 224, 224, device=DEV)
+    rows = 2 * 196
+    row_img = torch.arange(2, device=DEV).repeat_interleave(196).to(torch.int32)
+    row_tok = torch.arange(196, device=DEV).repeat(2).to(torch.int32)
+    outv = torch.zeros(rows, 768, device=DEV, dtype=torch.bfloat16)
+    o.im2col_video(v, row_img, row_tok, outv, rows)
+    wv = torch.randn(32, 3, 16, 16, device=DEV)
+    refv = F.conv2d(bf(v).double(), wv.double(), stride=16).flatten(2).transpose(1, 2).reshape(rows, 32)
+    gotv = outv.double() @ wv.double().reshape(32, 768).t()
+    assert rel_err(gotv, refv) < 1e-6
+
+
+def test_unshuffle_roundtrip():
+    o = ops()
+    B, T, La, Lv, D, ka, kv = 3, 2, 32, 16, 512, 8, 4
+    Ltot = La + T * Lv
+    n_enc = ka + T * kv
+    x = torch.randn(B * n_enc, D, device=DEV)
+    src = torch.full((B, Ltot), -1, dtype=torch.int32, device=DEV)
+    for b in range(B):
+        pa = torch.randperm(La, device=DEV)[:ka]
+        src[b, pa] = (b * n_enc + torch.arange(ka, device=DEV)).int()
+        for t in range(T):
+            pv = torch.randperm(Lv, device=DEV)[:kv]
+            src[b, La + t * Lv + pv] = (b * n_enc + ka + t * kv + torch.arange(kv, device=DEV)).int()
+    pos = torch.cat([torch.arange(La), La + torch.arange(Lv).repeat(T)]).repeat(B).to(torch.int32).to(DEV)
+    mod = torch.cat([torch.zeros(La), torch.ones(T * Lv)]).repeat(B).to(torch.uint8).to(DEV)
+    mt, pa_, pv_, ma, mv = (torch.randn(n, device=DEV) for n in (D, La * D, Lv * D, D, D))
+    out = torch.empty(B * Ltot, D, device=DEV)
+    srcf = src.reshape(-1).contiguous()
+    o.unshuffle_fwd(x, srcf, pos, mod, mt, pa_, pv_, ma, mv, out, B * Ltot)
+    base = torch.where((srcf >= 0)[:, None], x[srcf.clamp(min=0).long()], mt[None])
+    posall = torch.cat([pa_.reshape(La, D), pv_.reshape(Lv, D)])
+    ref = base + posall[pos.long()] + torch.where(mod.bool()[:, None], mv[None], ma[None])
+    assert torch.allclose(out, ref, atol=1e-6)
+    dout = torch.randn(B * Ltot, D, device=DEV)
+    dx = torch.zeros_like(x)
+    dpa, dpv, dm, dma, dmv = (torch.zeros(n, device=DEV) for n in (La * D, Lv * D, D, D, D))
+    o.unshuffle_bwd(dout, srcf, B, T, La, Lv, dx, dpa, dpv, dm, dma, dmv)
+    kept = srcf >= 0
+    dx_ref = torch.zeros_like(x)
+    dx_ref[srcf[kept].long()] = dout[kept]
+    assert torch.allclose(dx, dx_ref)
+    assert rel_err(dm, dout[~kept].sum(0)) < 1e-5
+    assert rel_err(dma, dout[~mod.bool()].sum(0)) < 1e-5
+    assert rel_err(dmv, dout[mod.bool()].sum(0)) < 1e-5
+    dpos_ref = torch.zeros(La + Lv, D, device=DEV).index_add_(0, pos.long(), dout)
+    assert rel_err(torch.cat([dpa, dpv]), dpos_ref.reshape(-1)) < 1e-5
+
+
+def test_segment_mean_colsum_scatter_cast_transpose():
+    o = ops()
+    D = 768
+    lens = [5, 100, 39, 1]
+    rows = sum(lens)
+    y = bf(torch.randn(rows, D, device=DEV))
+    seg = torch.tensor([0, 5, 105, 144, 145], dtype=torch.int32, device=DEV)
+    reps = torch.empty(4, D, device=DEV)
+    o.segment_mean_fwd(y, seg, reps, 4)
+    ref = torch.stack([y[seg[i]:seg[i + 1]].double().mean(0) for i in range(4)])
+    assert rel_err(reps, ref) < 1e-6
+    dreps = torch.randn(4, D, device=DEV)
+    dy = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    o.segment_mean_bwd(dreps, seg, dy, 4)
+    refdy = torch.cat([(dreps[i] / lens[i]).expand(lens[i], D) for i in range(4)])
+    assert rel_err(dy, refdy) < 4e-3
+    cs = torch.zeros(D, device=DEV)
+    o.colsum(y, cs, rows)
+    assert rel_err(cs, y.double().sum(0)) < 1e-5
+    idx = torch.randint(0, 7, (rows,), device=DEV, dtype=torch.int32)
+    dst = torch.zeros(7, D, device=DEV)
+    o.scatter_add_rows(y, idx, dst, rows, 2.0)
+    refd = torch.zeros(7, D, device=DEV, dtype=torch.double).index_add_(0, idx.long(), 2 * y.double())
+    assert rel_err(dst, refd) < 1e-5
+    w = torch.randn(300, 200, device=DEV)
+    wb = torch.empty(300, 200, device=DEV, dtype=torch.bfloat16)
+    o.cast_bf16(w, wb, w.numel())
+    assert torch.equal(wb, bf(w))
+    wt = torch.empty(200, 300, device=DEV, dtype=torch.bfloat16)
+    o.transpose_bf16(wb, wt)
+    assert torch.equal(wt, wb.t().contiguous())
+    xs = torch.randn(1024, device=DEV)
+    ys = torch.empty(1024, device=DEV, dtype=torch.bfloat16)
+    o.cast_scale(xs, ys, 1024, 2.0)
+    assert torch.equal(ys, bf(xs * 2))
+
+
+@pytest.mark.parametrize("audio", [True, False])
+def test_mae_loss(audio):
+    o = ops()
+    from oracle import ref_cpu
+    from avsiam_amd.config import AVSiamConfig
+    cfg = AVSiamConfig(audio_tokens=128)
+    B = 3
+    if audio:
+        inp = torch.randn(B, 256, 128, device=DEV)
+        L, P = 128, 256
+    else:
+        inp = torch.randn(B, 3, 224, 224, device=DEV)
+        L, P = 196, 768
+    pred = torch.randn(B * L, P, device=DEV)
+    mask = (torch.rand(B * L, device=DEV) > 0.25).float()
+    row_loss = torch.empty(B * L, device=DEV); loss = torch.empty(1, device=DEV)
+    nmask = float(mask.sum().item())
+    o.mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask)
+    pr = pred.cpu().reshape(B, L, P).requires_grad_(True)
+    ref = ref_cpu.mae_loss(cfg, inp.cpu(), pr, mask.cpu().reshape(B, L), 'a' if audio else 'v')
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    g = torch.tensor([1.7], device=DEV)
+    dpred = torch.empty(B * L, P, device=DEV, dtype=torch.bfloat16)
+    o.mae_loss_bwd(pred, inp, mask, g, dpred, audio, L, nmask)
+    (ref * 1.7).backward()
+    assert rel_err(dpred.cpu(), pr.grad.reshape(B * L, P)) < 4e-3
+
+
+@pytest.mark.parametrize("N", [4, 6, 64, 130])
+def test_infonce(N):
+    o = ops()
+    from oracle import ref_cpu
+    D = 768
+    a = torch.randn(N, D, device=DEV); v = torch.randn(N, D, device=DEV) + 0.5 * a
+    an, vn = torch.empty_like(a), torch.empty_like(v)
+    na, nv = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    o.l2norm_fwd(a, an, na); o.l2norm_fwd(v, vn, nv)
+    total = torch.empty(N, N, device=DEV)
+    o.gemm_f32_small(an, vn, total, N, N, D, (D, 1), (1, D), 1 / 0.05)
+    stats = torch.empty(N, 4, device=DEV); out = torch.empty(2, device=DEV)
+    o.infonce_fwd(total, stats, out)
+    ar, vr = a.cpu().double().requires_grad_(True), v.cpu().double().requires_grad_(True)
+    nce, acc, tot = ref_cpu.contrastive(ar, vr)
+    assert rel_err(total.cpu(), tot.detach()) < 1e-5
+    assert abs(out[0].item() - nce.item()) < 1e-5 * abs(nce.item()) + 1e-6
+    assert abs(out[1].item() - acc.item()) < 1e-6
+    g = torch.tensor([0.9], device=DEV)
+    dtotal = torch.empty_like(total)
+    o.infonce_dlogits(total, stats, g, 1.0, dtotal)
+    dan, dvn = torch.empty_like(a), torch.empty_like(v)
+    o.gemm_f32_small(dtotal, vn, dan, N, D, N, (N, 1), (D, 1), 1 / 0.05)
+    o.gemm_f32_small(dtotal, an, dvn, N, D, N, (1, N), (D, 1), 1 / 0.05)
+    da, dv = torch.empty_like(a), torch.empty_like(v)
+    o.l2norm_bwd(dan, an, na, da); o.l2norm_bwd(dvn, vn, nv, dv)
+    (nce * 0.9).backward()
+    assert rel_err(da.cpu(), ar.grad) < 1e-3      # fp32 exp of +-20 logits vs an fp64 reference
+    assert rel_err(dv.cpu(), vr.grad) < 1e-3
+
+
+def test_adam_matches_torch():
+    o = ops()
+    n = 4096 + 64
+    p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV)
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref_p], 2e-4, weight_decay=5e-7, betas=(0.95, 0.999))
+    m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    pb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        gs = g * step
+        ref_p.grad = gs.clone()
+        opt.step()
+        o.adam(p, gs, m, v, pb, n, 2e-4, step)
+        assert torch.allclose(p, ref_p.data, rtol=1e-5, atol=1e-7), step
+    assert torch.equal(pb, bf(p))
