@@ -1,0 +1,133 @@
+"""Flat parameter arena: all 723 tensors of CAVMAE_BASE in ONE fp32 HBM buffer.
+
+Layout (elements, each tensor aligned to 64):  [ pass-1 only | both passes | pass-2 only | dead ]
+so the live set of each pass of the training step (/root/reference/src/traintest_cavmae_base.py:131-152) is one
+contiguous range.  That buys, per pass: one gradient zero-fill, one RCCL all-reduce over exactly the live
+gradients (86.4 M / 212.1 M parameters instead of the 248 M everything-buckets DDP registers),
+one fused Adam launch, and one fp32->bf16 shadow refresh.  The reference module tree sees the arena through
+nn.Parameter views, so state_dict()/parameters() keep the reference's 963-key schema.
+
+Shadows used by the kernels:  pb   bf16 copy of the live range (GEMM B operands [N,K] as stored by nn.Linear)
+                              wt   bf16 transposed copies [K,N] of the Linear weights whose input needs a gradient
+                                   (B operand of the dgrad GEMM)
+"""
+import math
+
+import torch
+
+from .config import AVSiamConfig
+from .param_spec import P1, P2, build_spec
+
+ALIGN = 64
+
+
+def _is_matrix(info):
+    return info.kind in ("linear_w", "conv_w")
+
+
+def _needs_transpose(info):
+    # Linear layers whose input gradient is needed; the patch-embed convs take raw pixels (no dgrad)
+    return info.kind == "linear_w" and info.live != 0
+
+
+class ParamArena:
+    def __init__(self, cfg: AVSiamConfig):
+        self.cfg = cfg
+        spec = build_spec(cfg)
+        order = ([s for s in spec if s.live == P1] + [s for s in spec if s.live == (P1 | P2)] +
+                 [s for s in spec if s.live == P2] + [s for s in spec if s.live == 0])
+        self.info = {s.name: s for s in spec}
+        self.offset = {}
+        off = 0
+        marks = {}
+        prev = None
+        for s in order:
+            cls = s.live
+            if cls != prev:
+                marks[cls] = off
+                prev = cls
+            self.offset[s.name] = off
+            off += (math.prod(s.shape) + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.live_end = marks.get(0, off)
+        self.range = {P1: (marks[P1], marks[P2]), P2: (marks[P1 | P2], self.live_end)}
+        self.names = [s.name for s in order]
+        # transposed-copy arena
+        self.t_offset = {}
+        toff = 0
+        for s in order:
+            if _needs_transpose(s):
+                self.t_offset[s.name] = toff
+                toff += (math.prod(s.shape) + ALIGN - 1) // ALIGN * ALIGN
+        self.t_total = toff
+        self.p = torch.zeros(self.total, dtype=torch.float32)
+        self.g = None
+        self.pb = None
+        self.wt = None
+
+    # ----- host / device management -------------------------------------------------------------
+    def load_state(self, state):
+        with torch.no_grad():
+            for name, t in state.items():
+                if name in self.offset:
+                    self.view(name).copy_(t.to(self.p.device, torch.float32))
+
+    def to(self, device):
+        self.p = self.p.to(device)
+        if self.p.is_cuda:
+            self.g = torch.zeros(self.live_end, dtype=torch.float32, device=device)
+            self.pb = torch.zeros(self.live_end, dtype=torch.bfloat16, device=device)
+            self.wt = torch.zeros(self.t_total, dtype=torch.bfloat16, device=device)
+        else:
+            self.g = self.pb = self.wt = None
+        return self
+
+    # ----- views ---------------------------------------------------------------------------------
+    def _v(self, flat, name, two_d=False):
+        s = self.info[name]
+        n = math.prod(s.shape)
+        o = self.offset[name]
+        t = flat[o:o + n]
+        if two_d:
+            return t.view(s.shape[0], n // s.shape[0]) if _is_matrix(s) else t
+        return t.view(s.shape)
+
+    def view(self, name):
+        return self._v(self.p, name)
+
+    def w(self, name):          # fp32 master, flat or [N,K]
+        return self._v(self.p, name, True)
+
+    def gw(self, name):         # gradient view, flat or [N,K]
+        return self._v(self.g, name, True)
+
+    def gview(self, name):      # gradient in the parameter's own shape
+        return self._v(self.g, name)
+
+    def wb(self, name):         # bf16 shadow [N,K]
+        return self._v(self.pb, name, True)
+
+    def wtb(self, name):        # bf16 transposed shadow [K,N]
+        s = self.info[name]
+        n = math.prod(s.shape)
+        o = self.t_offset[name]
+        return self.wt[o:o + n].view(n // s.shape[0], s.shape[0])
+
+    # ----- shadows / optimizer -------------------------------------------------------------------
+    def refresh_shadows(self, which=None, cast=True):
+        """fp32 master -> bf16 shadow (+ transposed copies) for the live range of pass `which` (None: all)."""
+        from . import ops
+        lo, hi = (self.range[P1][0], self.live_end) if which is None else self.range[which]
+        if cast:
+            ops.cast_bf16(self.p[lo:hi], self.pb[lo:hi], hi - lo)
+        for name in self.t_offset:
+            if lo <= self.offset[name] < hi:
+                ops.transpose_bf16(self.wb(name), self.wtb(name))
+
+    def zero_grad_range(self, which):
+        lo, hi = self.range[which]
+        self.g[lo:hi].zero_()
+
+    def live_slice(self, flat, which):
+        lo, hi = self.range[which]
+        return flat[lo:hi]

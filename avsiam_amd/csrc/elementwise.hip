@@ -130,33 +130,33 @@ __global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// token mean of each packed sequence (``.mean(dim=1)`` at :563,566): reps[s] = mean_{r in seg s} y[r]
-__global__ void segment_mean_fwd_kernel(const bf16_t* __restrict__ y, const int* __restrict__ seg_start, float* __restrict__ reps,
+// token mean of each packed sequence (``.mean(dim=1)`` at :563,566) on the fp32 final-norm output:
+// reps[s] = mean_{r in seg s} y[r]
+__global__ void segment_mean_fwd_kernel(const float* __restrict__ y, const int* __restrict__ seg_start, float* __restrict__ reps,
                                         int D) {
     const int s = blockIdx.x;
     const int r0 = seg_start[s], r1 = seg_start[s + 1];
     const float inv = 1.0f / (float)(r1 - r0);
-    for (int c2 = threadIdx.x * 2; c2 < D; c2 += blockDim.x * 2) {
-        float s0 = 0.f, s1 = 0.f;
+    for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
+        float4 a = make_float4(0, 0, 0, 0);
         for (int r = r0; r < r1; ++r) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(y + (size_t)r * D + c2);
-            s0 += __uint_as_float(v << 16);
-            s1 += __uint_as_float(v & 0xffff0000u);
+            const float4 v = reinterpret_cast<const float4*>(y + (size_t)r * D)[c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        reps[(size_t)s * D + c2] = s0 * inv;
-        reps[(size_t)s * D + c2 + 1] = s1 * inv;
+        reinterpret_cast<float4*>(reps + (size_t)s * D)[c] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
     }
 }
 
-// dy[r] = dreps[seg(r)] / len(seg)
-__global__ void segment_mean_bwd_kernel(const float* __restrict__ dreps, const int* __restrict__ seg_start, bf16_t* __restrict__ dy,
-                                        int D) {
+// dy[r] = scale * dreps[seg(r)] / len(seg)
+__global__ void segment_mean_bwd_kernel(const float* __restrict__ dreps, const int* __restrict__ seg_start, float* __restrict__ dy,
+                                        int D, float scale) {
     const int s = blockIdx.x;
     const int r0 = seg_start[s], r1 = seg_start[s + 1];
-    const float inv = 1.0f / (float)(r1 - r0);
-    for (int c2 = threadIdx.x * 2; c2 < D; c2 += blockDim.x * 2) {
-        const uint32_t v = pack_bf2(dreps[(size_t)s * D + c2] * inv, dreps[(size_t)s * D + c2 + 1] * inv);
-        for (int r = r0; r < r1; ++r) *reinterpret_cast<uint32_t*>(dy + (size_t)r * D + c2) = v;
+    const float inv = scale / (float)(r1 - r0);
+    for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
+        float4 v = reinterpret_cast<const float4*>(dreps + (size_t)s * D)[c];
+        v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        for (int r = r0; r < r1; ++r) reinterpret_cast<float4*>(dy + (size_t)r * D)[c] = v;
     }
 }
 
@@ -286,16 +286,17 @@ extern "C" int avs_unshuffle_bwd(const float* dout, const int* src_row, int B, i
     return 0;
 }
 
-extern "C" int avs_segment_mean_fwd(const bf16_t* y, const int* seg_start, float* reps, int nseg, int D, hipStream_t stream) {
-    AVS_CHECK_ARG(nseg > 0 && (D % 2) == 0, "segment_mean_fwd: bad args");
+extern "C" int avs_segment_mean_fwd(const float* y, const int* seg_start, float* reps, int nseg, int D, hipStream_t stream) {
+    AVS_CHECK_ARG(nseg > 0 && (D % 4) == 0, "segment_mean_fwd: bad args");
     segment_mean_fwd_kernel<<<nseg, 256, 0, stream>>>(y, seg_start, reps, D);
     AVS_LAUNCH_CHECK("segment_mean_fwd");
     return 0;
 }
 
-extern "C" int avs_segment_mean_bwd(const float* dreps, const int* seg_start, bf16_t* dy, int nseg, int D, hipStream_t stream) {
-    AVS_CHECK_ARG(nseg > 0 && (D % 2) == 0, "segment_mean_bwd: bad args");
-    segment_mean_bwd_kernel<<<nseg, 256, 0, stream>>>(dreps, seg_start, dy, D);
+extern "C" int avs_segment_mean_bwd(const float* dreps, const int* seg_start, float* dy, int nseg, int D, float scale,
+                                    hipStream_t stream) {
+    AVS_CHECK_ARG(nseg > 0 && (D % 4) == 0, "segment_mean_bwd: bad args");
+    segment_mean_bwd_kernel<<<nseg, 256, 0, stream>>>(dreps, seg_start, dy, D, scale);
     AVS_LAUNCH_CHECK("segment_mean_bwd");
     return 0;
 }

@@ -9,11 +9,11 @@
 // LayerNorm in fp32 as well.
 #include "common.h"
 
-template <int NV>
+template <int NV, bool F32IO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g0,
                                                      const float* __restrict__ b0, const float* __restrict__ g1,
                                                      const float* __restrict__ b1, const uint8_t* __restrict__ row_mod,
-                                                     const int* __restrict__ out_map, bf16_t* __restrict__ y,
+                                                     const int* __restrict__ out_map, void* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int rows, float eps) {
     constexpr int D = NV * 256;
@@ -41,14 +41,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float4* gp = reinterpret_cast<const float4*>(mod ? g1 : g0);
     const float4* bp = reinterpret_cast<const float4*>(mod ? b1 : b0);
     const int orow = out_map ? out_map[row] : row;
-    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)orow * D);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float4 g = gp[i * 64 + lane], b = bp[i * 64 + lane];
-        uint2 o;
-        o.x = pack_bf2(v[i].x * rs * g.x + b.x, v[i].y * rs * g.y + b.y);
-        o.y = pack_bf2(v[i].z * rs * g.z + b.z, v[i].w * rs * g.w + b.w);
-        yr[i * 64 + lane] = o;
+        const float4 r = make_float4(v[i].x * rs * g.x + b.x, v[i].y * rs * g.y + b.y, v[i].z * rs * g.z + b.z,
+                                     v[i].w * rs * g.w + b.w);
+        if (F32IO) {
+            reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (size_t)orow * D)[i * 64 + lane] = r;
+        } else {
+            uint2 o;
+            o.x = pack_bf2(r.x, r.y);
+            o.y = pack_bf2(r.z, r.w);
+            reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + (size_t)orow * D)[i * 64 + lane] = o;
+        }
     }
     if (lane == 0) {
         mean_out[row] = mean;
@@ -62,12 +67,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 constexpr int LN_ROWS_PER_WAVE = 16;
 constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+template <int NV, bool F32IO>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ g0, const float* __restrict__ g1,
                                                      const uint8_t* __restrict__ row_mod, const int* __restrict__ out_map,
-                                                     const float* dres, float* dx, float* __restrict__ ws, int rows) {
+                                                     const float* dres, float* dx, bf16_t* __restrict__ dx_bf16,
+                                                     float* __restrict__ ws, int rows) {
     constexpr int D = NV * 256;
     __shared__ float red[4][D];
     const int lane = threadIdx.x & 63;
@@ -85,18 +91,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const float mean = mean_in[row], rs = rstd_in[row];
         const int drow = out_map ? out_map[row] : row;
         const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
-        const uint2* dyr = reinterpret_cast<const uint2*>(dy + (size_t)drow * D);
         const float4* gp = reinterpret_cast<const float4*>(mod ? g1 : g0);
         float4 xh[NV], gy[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float4 xv = xr[i * 64 + lane];
-            const uint2 dv = dyr[i * 64 + lane];
             const float4 g = gp[i * 64 + lane];
             float4 d;
-            d.x = __uint_as_float(dv.x << 16); d.y = __uint_as_float(dv.x & 0xffff0000u);
-            d.z = __uint_as_float(dv.y << 16); d.w = __uint_as_float(dv.y & 0xffff0000u);
+            if (F32IO) {
+                d = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy) + (size_t)drow * D)[i * 64 + lane];
+            } else {
+                const uint2 dv = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(dy) + (size_t)drow * D)[i * 64 + lane];
+                d.x = __uint_as_float(dv.x << 16); d.y = __uint_as_float(dv.x & 0xffff0000u);
+                d.z = __uint_as_float(dv.y << 16); d.w = __uint_as_float(dv.y & 0xffff0000u);
+            }
             xh[i].x = (xv.x - mean) * rs; xh[i].y = (xv.y - mean) * rs;
             xh[i].z = (xv.z - mean) * rs; xh[i].w = (xv.w - mean) * rs;
             gy[i].x = d.x * g.x; gy[i].y = d.y * g.y; gy[i].z = d.z * g.z; gy[i].w = d.w * g.w;
@@ -124,6 +133,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             dxr[i * 64 + lane] = o;
+            if (dx_bf16) {
+                uint2 ob;
+                ob.x = pack_bf2(o.x, o.y);
+                ob.y = pack_bf2(o.z, o.w);
+                reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * D)[i * 64 + lane] = ob;
+            }
         }
     }
     // cross-wave reduction of the four accumulator sets, one set at a time through LDS
@@ -156,31 +171,40 @@ __global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, 
 extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, LN_ROWS_PER_BLOCK) * 4 * D; }
 
 extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
-                                 const uint8_t* row_mod, const int* out_map, bf16_t* y, float* mean, float* rstd,
+                                 const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
                                  int rows, int D, float eps, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(x && g0 && b0 && y && mean && rstd, "layernorm_fwd: null pointer");
     AVS_CHECK_ARG(!row_mod || (g1 && b1), "layernorm_fwd: row_mod given without second affine set");
     dim3 grid(ceil_div(rows, 4)), block(256);
-    if (D == 512) ln_fwd_kernel<2><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps);
-    else if (D == 768) ln_fwd_kernel<3><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps);
-    else ln_fwd_kernel<4><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps);
+#define LN_FWD(NV, F) ln_fwd_kernel<NV, F><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps)
+    if (y_f32) {
+        if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else LN_FWD(4, true);
+    } else {
+        if (D == 512) LN_FWD(2, false); else if (D == 768) LN_FWD(3, false); else LN_FWD(4, false);
+    }
+#undef LN_FWD
     AVS_LAUNCH_CHECK("layernorm_fwd");
     return 0;
 }
 
-// dg*/db* are ACCUMULATED into (+=); dx may alias dres.  ws: avs_layernorm_ws_floats(rows, D) floats.
-extern "C" int avs_layernorm_bwd(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* g0,
-                                 const float* g1, const uint8_t* row_mod, const int* out_map, const float* dres,
-                                 float* dx, float* dg0, float* db0, float* dg1, float* db1, float* ws, int rows, int D,
-                                 hipStream_t stream) {
+// dg*/db* are ACCUMULATED into (+=); dx may alias dres; dx_bf16 (optional) receives a bf16 copy of dx.
+// ws: avs_layernorm_ws_floats(rows, D) floats.
+extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd,
+                                 const float* g0, const float* g1, const uint8_t* row_mod, const int* out_map,
+                                 const float* dres, float* dx, bf16_t* dx_bf16, float* dg0, float* db0, float* dg1,
+                                 float* db1, float* ws, int rows, int D, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(dy && x && mean && rstd && g0 && dx && ws, "layernorm_bwd: null pointer");
     const int nblocks = ceil_div(rows, LN_ROWS_PER_BLOCK);
     dim3 grid(nblocks), block(256);
-    if (D == 512) ln_bwd_kernel<2><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, ws, rows);
-    else if (D == 768) ln_bwd_kernel<3><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, ws, rows);
-    else ln_bwd_kernel<4><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, ws, rows);
+#define LN_BWD(NV, F) ln_bwd_kernel<NV, F><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows)
+    if (dy_f32) {
+        if (D == 512) LN_BWD(2, true); else if (D == 768) LN_BWD(3, true); else LN_BWD(4, true);
+    } else {
+        if (D == 512) LN_BWD(2, false); else if (D == 768) LN_BWD(3, false); else LN_BWD(4, false);
+    }
+#undef LN_BWD
     AVS_LAUNCH_CHECK("layernorm_bwd");
     ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), 4), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1);
     AVS_LAUNCH_CHECK("layernorm_bwd_reduce");

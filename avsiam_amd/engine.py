@@ -1,0 +1,484 @@
+"""Host-side schedule of the AVSiam pre-training hot path on the HIP kernels.
+
+MI355X-first restructuring of ``CAVMAE_BASE.forward`` (/root/reference/src/models/cav_mae_base.py:685-741):
+
+* every sequence of a pass is PACKED into one [rows, D] token matrix.  The contrastive pass of the reference
+  issues 12 layers x (<=5 audio groups + <=5 video groups) Block calls on ragged groups (:554-558); all ops
+  but attention are token-wise and the weights are shared (Siamese), so here it is 12 layers of
+  {LN(row-selected affine) -> one QKV GEMM -> varlen attention -> proj GEMM(+residual) -> LN -> fc1(+GELU) -> fc2(+residual)}
+  over all rows at once;
+* only KEPT tokens are embedded (the reference embeds all and drops 75 %, :448-455,476-477);
+* the residual stream stays fp32 (as under the reference's autocast, where pos_embed/LayerNorm keep it fp32),
+  GEMM/attention operands are bf16 with fp32 accumulation;
+* backward is a hand-written schedule (no autograd graph): dgrad GEMMs read pre-transposed bf16 weight copies,
+  wgrad GEMMs contract over the token rows with transposing LDS reads and accumulate straight into the flat
+  gradient arena.
+
+The mask plan (which tokens each sample keeps) is an explicit input - see maskplan.py.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .arena import ParamArena
+from .config import AVSiamConfig
+from .maskplan import ContrastivePlan, MaePlan, group_sizes, group_ratio, len_keep
+from .param_spec import P1, P2
+
+BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
+LN_EPS_BLOCK, LN_EPS_FINAL = 1e-5, 1e-6       # nn.LayerNorm default in Block; timm ViT final norm
+
+
+def _z(shape, dtype, dev):
+    return torch.zeros(shape, dtype=dtype, device=dev)
+
+
+class Linear:
+    """Arena views of one nn.Linear: bf16 weight [N,K], transposed copy [K,N], fp32 bias, gradient views."""
+
+    def __init__(self, arena: ParamArena, wname, bname, need_t=True):
+        self.w = arena.wb(wname)
+        self.wt = arena.wtb(wname) if need_t else None
+        self.b = arena.w(bname)
+        self.gw = arena.gw(wname)
+        self.gb = arena.gw(bname)
+
+
+class Norm:
+    def __init__(self, arena: ParamArena, prefix):
+        self.g, self.b = arena.w(prefix + ".weight"), arena.w(prefix + ".bias")
+        self.dg, self.db = arena.gw(prefix + ".weight"), arena.gw(prefix + ".bias")
+
+
+class BlockParams:
+    """One transformer Block (cav_mae_base.py:102-211); `sfx0`/`sfx1` name the LayerNorm sets for row_mod 0/1
+    ('' plain, '_a', '_v')."""
+
+    def __init__(self, arena, prefix, sfx0, sfx1=None):
+        self.n1 = [Norm(arena, f"{prefix}.norm1{sfx0}")] + ([Norm(arena, f"{prefix}.norm1{sfx1}")] if sfx1 is not None else [])
+        self.n2 = [Norm(arena, f"{prefix}.norm2{sfx0}")] + ([Norm(arena, f"{prefix}.norm2{sfx1}")] if sfx1 is not None else [])
+        self.qkv = Linear(arena, f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias")
+        self.proj = Linear(arena, f"{prefix}.attn.proj.weight", f"{prefix}.attn.proj.bias")
+        self.fc1 = Linear(arena, f"{prefix}.mlp.fc1.weight", f"{prefix}.mlp.fc1.bias")
+        self.fc2 = Linear(arena, f"{prefix}.mlp.fc2.weight", f"{prefix}.mlp.fc2.bias")
+
+
+def _ln_fwd(x, norms, y, mean, rstd, rows, eps, row_mod=None, out_map=None):
+    n0 = norms[0]
+    n1 = norms[1] if len(norms) > 1 else None
+    ops.layernorm_fwd(x, n0.g, n0.b, y, mean, rstd, rows, eps, n1.g if n1 else None, n1.b if n1 else None,
+                      row_mod if n1 else None, out_map)
+
+
+def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None):
+    n0 = norms[0]
+    n1 = norms[1] if len(norms) > 1 else None
+    ops.layernorm_bwd(dy, x, mean, rstd, n0.g, dx, n0.dg, n0.db, ws, rows, n1.g if n1 else None, n1.dg if n1 else None,
+                      n1.db if n1 else None, row_mod if n1 else None, out_map, dres, dx_bf16)
+
+
+class Stack:
+    """`nblocks` transformer blocks over a packed [rows, D] fp32 residual stream with saved activations."""
+
+    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None):
+        assert sum(seq_lens) == rows
+        self.rows, self.D, self.H, self.hidden, self.nblocks = rows, D, H, hidden, nblocks
+        self.row_mod = row_mod
+        rp = ops.pad_rows(rows, 128)
+        self.rp = rp
+        self.tiles = ops.AttnTiles(seq_lens, dev)
+        self.x = [_z((rp, D), F32, dev) for _ in range(nblocks + 1)]     # x[i] = input of block i; x[-1] = output
+        self.xmid = [_z((rp, D), F32, dev) for _ in range(nblocks)]
+        self.ln1 = [_z((rp, D), BF16, dev) for _ in range(nblocks)]
+        self.ln2 = [_z((rp, D), BF16, dev) for _ in range(nblocks)]
+        self.qkv = [_z((rp, 3 * D), BF16, dev) for _ in range(nblocks)]
+        self.att = [_z((rp, D), BF16, dev) for _ in range(nblocks)]
+        self.fc1 = [_z((rp, hidden), BF16, dev) for _ in range(nblocks)]
+        self.act = [_z((rp, hidden), BF16, dev) for _ in range(nblocks)]
+        self.lse = [_z((H, rp), F32, dev) for _ in range(nblocks)]
+        self.stats = [[_z((rp,), F32, dev) for _ in range(4)] for _ in range(nblocks)]   # mean1 rstd1 mean2 rstd2
+        # backward scratch (shared by all blocks)
+        self.dx = [_z((rp, D), F32, dev) for _ in range(2)]
+        self.dxb = [_z((rp, D), BF16, dev) for _ in range(2)]
+        self.dfc1 = _z((rp, hidden), BF16, dev)
+        self.dln = _z((rp, D), BF16, dev)
+        self.datt = _z((rp, D), BF16, dev)
+        self.dqkv = _z((rp, 3 * D), BF16, dev)
+        self.delta = _z((H, rp), F32, dev)
+        self.lnws = _z((ops.layernorm_ws(rows, D),), F32, dev)
+
+    @property
+    def out(self):
+        return self.x[self.nblocks]
+
+    def forward(self, blocks):
+        M = self.rows
+        for i, bp in enumerate(blocks):
+            x, st = self.x[i], self.stats[i]
+            _ln_fwd(x, bp.n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
+            ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b)
+            ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i])
+            ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x)
+            _ln_fwd(self.xmid[i], bp.n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)
+            ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1)
+            ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i])
+
+    def backward(self, blocks):
+        """In: d(out) in self.dx[0] (fp32) and self.dxb[0] (bf16).  Out: d(x[0]) in the same two buffers."""
+        M = self.rows
+        dxo, dxm = self.dx
+        dbo, dbm = self.dxb
+        for i in reversed(range(self.nblocks)):
+            bp, st = blocks[i], self.stats[i]
+            # fc2: d(gelu out) fused with GELU' -> d(fc1 pre-activation)
+            ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2)
+            ops.gemm_tn(dbo, self.act[i], bp.fc2.gw, M)
+            ops.colsum(dbo, bp.fc2.gb, M)
+            # fc1
+            ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M)
+            ops.gemm_tn(self.dfc1, self.ln2[i], bp.fc1.gw, M)
+            ops.colsum(self.dfc1, bp.fc1.gb, M)
+            _ln_bwd(self.dln, self.xmid[i], st[2], st[3], bp.n2, dxm, self.lnws, M, self.row_mod, dres=dxo, dx_bf16=dbm)
+            # proj
+            ops.gemm_nt(dbm, bp.proj.wt, self.datt, M)
+            ops.gemm_tn(dbm, self.att[i], bp.proj.gw, M)
+            ops.colsum(dbm, bp.proj.gb, M)
+            ops.attn_bwd(self.qkv[i], self.tiles, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
+            # qkv
+            ops.gemm_nt(self.dqkv, bp.qkv.wt, self.dln, M)
+            ops.gemm_tn(self.dqkv, self.ln1[i], bp.qkv.gw, M)
+            ops.colsum(self.dqkv, bp.qkv.gb, M)
+            _ln_bwd(self.dln, self.x[i], st[0], st[1], bp.n1, dxo, self.lnws, M, self.row_mod, dres=dxm, dx_bf16=dbo)
+
+
+class PatchEmbedder:
+    """Kept-token patch embedding: im2col gather -> GEMM with fused (+bias +pos_embed[token]) * 2 epilogue
+    (cav_mae_base.py:444-455: conv, +pos, then `x + norm_pre(x)` with norm_pre = Identity)."""
+
+    def __init__(self, arena, dev, rows, audio, cfg):
+        self.audio, self.rows, self.cfg = audio, rows, cfg
+        pre = "vit_base.patch_embed_a" if audio else "vit_base.patch_embed"
+        self.lin = Linear(arena, pre + ".proj.weight", pre + ".proj.bias", need_t=False)
+        pname = "vit_base.pos_embed_a" if audio else "vit_base.pos_embed"
+        D = cfg.embed_dim
+        self.pos = arena.view(pname).view(-1, D)
+        self.gpos = arena.gview(pname).view(-1, D)
+        K = cfg.patch * cfg.patch * (1 if audio else cfg.in_chans)
+        rp = ops.pad_rows(rows, 128)
+        self.cols = _z((rp, K), BF16, dev)
+        self.dy = _z((rp, D), BF16, dev)
+        self.row_src = _z((rows,), I32, dev)     # sample (audio) / frame image (video) of each row
+        self.row_tok = _z((rows,), I32, dev)
+        self.row_pos = _z((rows,), I32, dev)     # row of the pos-embed table: tok (audio) / 1 + tok (video, skips cls)
+
+    def set_rows(self, row_src, row_tok):
+        self.row_src.copy_(row_src, non_blocking=True)
+        self.row_tok.copy_(row_tok, non_blocking=True)
+        torch.add(self.row_tok, 0 if self.audio else 1, out=self.row_pos)
+
+    def forward(self, inp, out):
+        """inp: audio [B,time,mel] / video [NF,3,H,W] fp32; out: fp32 [rows(+pad), D] slice of the residual stream."""
+        if self.audio:
+            ops.im2col_audio(inp, self.row_src, self.row_tok, self.cols, self.rows, self.cfg.audio_t)
+        else:
+            ops.im2col_video(inp, self.row_src, self.row_tok, self.cols, self.rows)
+        ops.gemm_nt(self.cols, self.lin.w, out, self.rows, bias=self.lin.b, res=self.pos, res_idx=self.row_pos, alpha=2.0)
+
+    def backward(self, dx):
+        """dx: fp32 [rows, D] gradient of the embedding output."""
+        D = self.cfg.embed_dim
+        ops.cast_scale(dx, self.dy, self.rows * D, 2.0)
+        ops.gemm_tn(self.dy, self.cols, self.lin.gw, self.rows)
+        ops.colsum(self.dy, self.lin.gb, self.rows)
+        ops.scatter_add_rows(self.dy, self.row_pos, self.gpos, self.rows)
+
+
+def _fold_frames(imgs, T):
+    if imgs.dim() == 4:
+        assert T == 1
+        return imgs
+    assert imgs.shape[1] == T
+    return imgs.reshape(imgs.shape[0] * T, *imgs.shape[2:])
+
+
+# =====================================================================================================
+class ContrastivePass:
+    """Pass 1 (forward_encoder_mmixed + forward_contrastive, cav_mae_base.py:508-594,641-661)."""
+
+    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, world=1, rank=0):
+        self.arena, self.cfg, self.B, self.dev, self.world, self.rank = arena, cfg, batch, dev, world, rank
+        T, D = cfg.frames, cfg.embed_dim
+        sizes = group_sizes(batch, cfg.n_groups)
+        self.sizes = sizes
+        self.keep_a = [len_keep(cfg.audio_tokens, group_ratio(g)) for g in range(len(sizes))]
+        self.keep_v = [len_keep(cfg.video_tokens, group_ratio(g)) for g in range(len(sizes))]
+        lens_a = [self.keep_a[g] for g, n in enumerate(sizes) for _ in range(n)]
+        lens_v = [self.keep_v[g] for g, n in enumerate(sizes) for _ in range(n * T)]
+        self.rows_a, self.rows_v = sum(lens_a), sum(lens_v)
+        rows = self.rows_a + self.rows_v
+        self.rows = rows
+        row_mod = torch.cat([torch.zeros(self.rows_a, dtype=U8), torch.ones(self.rows_v, dtype=U8)]).to(dev)
+        self.stack = Stack(dev, rows, D, cfg.num_heads, D * cfg.mlp_ratio, lens_a + lens_v, cfg.depth, row_mod)
+        self.blocks = [BlockParams(arena, f"vit_base.blocks.{i}", "_a", "_v") for i in range(cfg.depth)]
+        self.final = [Norm(arena, "vit_base.norm_a"), Norm(arena, "vit_base.norm")]
+        self.emb_a = PatchEmbedder(arena, dev, self.rows_a, True, cfg)
+        self.emb_v = PatchEmbedder(arena, dev, self.rows_v, False, cfg)
+        # pooling segments: B audio sequences then B video samples (T frames each), slot order = group-major
+        seg = [0]
+        for L in lens_a:
+            seg.append(seg[-1] + L)
+        k = 0
+        for g, n in enumerate(sizes):
+            for _ in range(n):
+                seg.append(seg[-1] + T * self.keep_v[g])
+        self.seg_start = torch.tensor(seg, dtype=I32, device=dev)
+        self.yf = _z((self.stack.rp, D), F32, dev)
+        self.fstat = [_z((self.stack.rp,), F32, dev) for _ in range(2)]
+        self.reps_slot = _z((2 * batch, D), F32, dev)         # [audio slots | video slots]
+        self.slot_to_row = _z((2 * batch,), torch.int64, dev)  # slot -> row of `reps` ([a samples | v samples])
+        self.reps = _z((2 * batch, D), F32, dev)
+        N = world * batch
+        self.N = N
+        self.all_reps = _z((world, 2 * batch, D), F32, dev)
+        self.A, self.V = _z((N, D), F32, dev), _z((N, D), F32, dev)
+        self.An, self.Vn = _z((N, D), F32, dev), _z((N, D), F32, dev)
+        self.na, self.nv = _z((N,), F32, dev), _z((N,), F32, dev)
+        self.total, self.dtotal = _z((N, N), F32, dev), _z((N, N), F32, dev)
+        self.nstats, self.nout = _z((N, 4), F32, dev), _z((2,), F32, dev)
+        self.dAn, self.dVn = _z((N, D), F32, dev), _z((N, D), F32, dev)
+        self.dA, self.dV = _z((N, D), F32, dev), _z((N, D), F32, dev)
+        self.dreps = _z((2 * batch, D), F32, dev)
+        self.dreps_slot = _z((2 * batch, D), F32, dev)
+
+    # ---- plan -> index arrays (host, O(rows) ints) --------------------------------------------------
+    def _set_plan(self, plan: ContrastivePlan):
+        B, T = self.B, self.cfg.frames
+        assert plan.batch == B
+        ag, vg = plan.a_group.numpy(), plan.v_group.numpy()
+        counts_a = np.bincount(ag, minlength=len(self.sizes)).tolist()
+        counts_v = np.bincount(vg, minlength=len(self.sizes)).tolist()
+        assert counts_a[:len(self.sizes)] == self.sizes and counts_v[:len(self.sizes)] == self.sizes, "plan groups do not match torch.chunk sizes"
+        order_a = np.argsort(ag, kind="stable")
+        order_v = np.argsort(vg, kind="stable")
+        src_a, tok_a = [], []
+        for s in order_a:
+            ids = plan.a_keep[s]
+            assert ids.numel() == self.keep_a[ag[s]]
+            tok_a.append(ids)
+            src_a.append(torch.full((ids.numel(),), int(s), dtype=torch.int64))
+        src_v, tok_v = [], []
+        for s in order_v:
+            for t in range(T):
+                ids = plan.v_keep[s][t]
+                assert ids.numel() == self.keep_v[vg[s]]
+                tok_v.append(ids)
+                src_v.append(torch.full((ids.numel(),), int(s) * T + t, dtype=torch.int64))
+        self.emb_a.set_rows(torch.cat(src_a).to(I32), torch.cat(tok_a).to(I32))
+        self.emb_v.set_rows(torch.cat(src_v).to(I32), torch.cat(tok_v).to(I32))
+        s2r = torch.cat([torch.from_numpy(order_a), B + torch.from_numpy(order_v)])
+        self.slot_to_row.copy_(s2r, non_blocking=True)
+
+    def forward(self, audio, imgs, plan):
+        """-> (nce [1] device tensor, c_acc [1] device tensor); leaves everything backward needs in place."""
+        cfg, st = self.cfg, self.stack
+        self._set_plan(plan)
+        x0 = st.x[0]
+        self.emb_a.forward(audio, x0[:self.rows_a])
+        self.emb_v.forward(_fold_frames(imgs, cfg.frames), x0[self.rows_a:])
+        st.forward(self.blocks)
+        _ln_fwd(st.out, self.final, self.yf, self.fstat[0], self.fstat[1], self.rows, LN_EPS_FINAL, st.row_mod)
+        ops.segment_mean_fwd(self.yf, self.seg_start, self.reps_slot, 2 * self.B)
+        self.reps.index_copy_(0, self.slot_to_row, self.reps_slot)        # slot order -> sample order
+        B, W, D = self.B, self.world, cfg.embed_dim
+        if W > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.all_reps, self.reps)         # c2: one [2,B,D] message per rank
+            self.A.copy_(self.all_reps[:, :B].reshape(W * B, D))
+            self.V.copy_(self.all_reps[:, B:].reshape(W * B, D))
+        else:
+            self.A.copy_(self.reps[:B])
+            self.V.copy_(self.reps[B:])
+        N = self.N
+        ops.l2norm_fwd(self.A, self.An, self.na)
+        ops.l2norm_fwd(self.V, self.Vn, self.nv)
+        ops.gemm_f32_small(self.An, self.Vn, self.total, N, N, D, (D, 1), (1, D), 1.0 / cfg.temperature)
+        ops.infonce_fwd(self.total, self.nstats, self.nout)
+        return self.nout[0:1], self.nout[1:2]
+
+    def backward(self, gout, weight):
+        """gout: [1] fp32 device tensor (d loss / d loss_c_weighted); weight = contrast_loss_weight."""
+        cfg, st = self.cfg, self.stack
+        B, W, D, N = self.B, self.world, cfg.embed_dim, self.N
+        ops.infonce_dlogits(self.total, self.nstats, gout, weight, self.dtotal)
+        ops.gemm_f32_small(self.dtotal, self.Vn, self.dAn, N, D, N, (N, 1), (D, 1), 1.0 / cfg.temperature)
+        ops.gemm_f32_small(self.dtotal, self.An, self.dVn, N, D, N, (1, N), (D, 1), 1.0 / cfg.temperature)
+        ops.l2norm_bwd(self.dAn, self.An, self.na, self.dA)
+        ops.l2norm_bwd(self.dVn, self.Vn, self.nv, self.dV)
+        r = self.rank
+        # GatherLayer.backward all-reduces W identical copies and keeps the own slice (gather_layer.py:35-37):
+        # that is W x the own-slice gradient, no collective needed.
+        self.dreps[:B].copy_(self.dA[r * B:(r + 1) * B])
+        self.dreps[B:].copy_(self.dV[r * B:(r + 1) * B])
+        torch.index_select(self.dreps, 0, self.slot_to_row, out=self.dreps_slot)
+        ops.segment_mean_bwd(self.dreps_slot, self.seg_start, self.yf, 2 * B, float(W))
+        _ln_bwd(self.yf, st.out, self.fstat[0], self.fstat[1], self.final, st.dx[0], st.lnws, self.rows, st.row_mod,
+                dx_bf16=st.dxb[0])
+        st.backward(self.blocks)
+        self.emb_a.backward(st.dx[0][:self.rows_a])
+        self.emb_v.backward(st.dx[0][self.rows_a:])
+
+
+# =====================================================================================================
+class MaePass:
+    """Pass 2 (forward_encoder + mm layers + forward_decoder + forward_mae_loss, cav_mae_base.py:441-504,597-638,
+    663-683,694-707)."""
+
+    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev):
+        self.arena, self.cfg, self.B, self.dev = arena, cfg, batch, dev
+        B, T, D, Dd = batch, cfg.frames, cfg.embed_dim, cfg.dec_dim
+        ka, kv, La, Lv = cfg.keep_a, cfg.keep_v, cfg.audio_tokens, cfg.video_tokens
+        self.rows_a, self.rows_v = B * ka, B * T * kv
+        self.n_enc = ka + T * kv
+        self.Ltot = La + T * Lv
+        hid = D * cfg.mlp_ratio
+        self.st_a = Stack(dev, self.rows_a, D, cfg.num_heads, hid, [ka] * B, cfg.depth)
+        self.st_v = Stack(dev, self.rows_v, D, cfg.num_heads, hid, [kv] * (B * T), cfg.depth)
+        self.st_mm = Stack(dev, B * self.n_enc, D, cfg.num_heads, hid, [self.n_enc] * B, 2)
+        self.st_dec = Stack(dev, B * self.Ltot, Dd, cfg.dec_heads, Dd * cfg.mlp_ratio, [self.Ltot] * B, cfg.dec_depth)
+        self.blk_a = [BlockParams(arena, f"ast_base.blocks.{i}", "") for i in range(cfg.depth)]      # :489
+        self.blk_v = [BlockParams(arena, f"vit_base.blocks.{i}", "_v") for i in range(cfg.depth)]   # :487
+        self.blk_mm = [BlockParams(arena, "mm_layer_1", "_a"), BlockParams(arena, "mm_layer_2", "_a")]   # :699-700
+        self.blk_dec = [BlockParams(arena, f"decoder_blocks.{i}", "") for i in range(cfg.dec_depth)]
+        self.fin_a, self.fin_v = [Norm(arena, "ast_base.norm_a")], [Norm(arena, "vit_base.norm")]   # :495,492
+        self.dec_norm = [Norm(arena, "decoder_norm")]
+        self.emb_a = PatchEmbedder(arena, dev, self.rows_a, True, cfg)
+        self.emb_v = PatchEmbedder(arena, dev, self.rows_v, False, cfg)
+        self.dec_embed = Linear(arena, "decoder_embed.weight", "decoder_embed.bias")
+        self.pred_a = Linear(arena, "decoder_pred_a.weight", "decoder_pred_a.bias")
+        self.pred_v = Linear(arena, "decoder_pred_v.weight", "decoder_pred_v.bias")
+        self.fstat_a = [_z((self.st_a.rp,), F32, dev) for _ in range(2)]
+        self.fstat_v = [_z((self.st_v.rp,), F32, dev) for _ in range(2)]
+        # static row maps: tower rows -> joint [B, n_enc] layout (torch.cat((ca, cv), dim=1), :503)
+        b = torch.arange(B).view(B, 1)
+        self.map_a = (b * self.n_enc + torch.arange(ka).view(1, ka)).reshape(-1).to(I32).to(dev)
+        bt = torch.arange(B * T).view(B * T, 1)
+        self.map_v = ((bt // T) * self.n_enc + ka + (bt % T) * kv + torch.arange(kv).view(1, kv)).reshape(-1).to(I32).to(dev)
+        rj = self.st_mm.rp
+        self.xj_b = _z((rj, D), BF16, dev)                    # bf16 copy of the mm output (decoder_embed operand)
+        self.de = _z((rj, Dd), F32, dev)                      # decoder_embed output
+        self.dde = _z((rj, Dd), F32, dev)
+        self.dde_b = _z((rj, Dd), BF16, dev)
+        # un-shuffle index arrays (src_row depends on the plan; pos/modality are static)
+        rows_d = B * self.Ltot
+        self.src_row = _z((rows_d,), I32, dev)
+        pos = torch.cat([torch.arange(La), La + torch.arange(Lv).repeat(T)]).repeat(B)
+        self.pos_row = pos.to(I32).to(dev)
+        self.dmod = torch.cat([torch.zeros(La, dtype=U8), torch.ones(T * Lv, dtype=U8)]).repeat(B).to(dev)
+        # decoder_norm output, modality-major: [B*La audio rows | pad | B*T*Lv video rows | pad]
+        self.na_rows, self.nv_rows = B * La, B * T * Lv
+        self.v_off = ops.pad_rows(self.na_rows, 128)
+        l = torch.arange(self.Ltot).view(1, -1)
+        bb = torch.arange(B).view(B, 1)
+        omap = torch.where(l < La, bb * La + l, self.v_off + bb * (T * Lv) + (l - La))
+        self.dn_map = omap.reshape(-1).to(I32).to(dev)
+        dn_rows = self.v_off + ops.pad_rows(self.nv_rows, 128)
+        self.dn = _z((dn_rows, Dd), BF16, dev)
+        self.ddn = _z((dn_rows, Dd), BF16, dev)
+        self.dn_stat = [_z((self.st_dec.rp,), F32, dev) for _ in range(2)]
+        P = cfg.patch * cfg.patch
+        self.p_a = _z((ops.pad_rows(self.na_rows), P), F32, dev)
+        self.p_v = _z((ops.pad_rows(self.nv_rows), P * cfg.in_chans), F32, dev)
+        self.dp_a = _z((ops.pad_rows(self.na_rows), P), BF16, dev)
+        self.dp_v = _z((ops.pad_rows(self.nv_rows), P * cfg.in_chans), BF16, dev)
+        self.mask_a = _z((B, La), F32, dev)
+        self.mask_v = _z((B, T * Lv), F32, dev)
+        self.rl_a, self.rl_v = _z((self.na_rows,), F32, dev), _z((self.nv_rows,), F32, dev)
+        self.losses = _z((3,), F32, dev)                       # loss_a, loss_v, loss_mae
+        self.nmask_a = float(B * (La - ka))
+        self.nmask_v = float(B * T * (Lv - kv))
+        # parameter views used by the un-shuffle
+        a = arena
+        self.tok = {k: a.view(k).reshape(-1) for k in ("mask_token", "decoder_pos_embed_a", "decoder_pos_embed_v",
+                                                      "decoder_modality_a", "decoder_modality_v")}
+        self.gtok = {k: a.gview(k).reshape(-1) for k in self.tok}
+
+    def _set_plan(self, plan: MaePlan):
+        cfg, B, T = self.cfg, self.B, self.cfg.frames
+        ka, kv, La, Lv = cfg.keep_a, cfg.keep_v, cfg.audio_tokens, cfg.video_tokens
+        assert plan.batch == B and plan.ids_keep_a.shape == (B, ka) and plan.ids_keep_v.shape == (B, T, kv)
+        self.emb_a.set_rows(torch.arange(B).repeat_interleave(ka).to(I32), plan.ids_keep_a.reshape(-1).to(I32))
+        self.emb_v.set_rows(torch.arange(B * T).repeat_interleave(kv).to(I32), plan.ids_keep_v.reshape(-1).to(I32))
+        ra, rv = plan.ids_restore_a, plan.ids_restore_v                                  # [B,La], [B,T,Lv]
+        b = torch.arange(B).view(B, 1)
+        src_a = torch.where(ra < ka, b * self.n_enc + ra, torch.full_like(ra, -1))
+        t = torch.arange(T).view(1, T, 1)
+        src_v = torch.where(rv < kv, b.view(B, 1, 1) * self.n_enc + ka + t * kv + rv, torch.full_like(rv, -1))
+        src = torch.cat([src_a, src_v.reshape(B, T * Lv)], dim=1).reshape(-1).to(I32)
+        self.src_row.copy_(src, non_blocking=True)
+        self.mask_a.copy_((ra >= ka).float(), non_blocking=True)                         # :385-388
+        self.mask_v.copy_((rv >= kv).float().reshape(B, T * Lv), non_blocking=True)
+
+    def forward(self, audio, imgs, plan):
+        cfg, B, T = self.cfg, self.B, self.cfg.frames
+        La, Lv = cfg.audio_tokens, cfg.video_tokens
+        self._set_plan(plan)
+        self.audio, self.imgs = audio, _fold_frames(imgs, T)
+        self.emb_a.forward(audio, self.st_a.x[0])
+        self.emb_v.forward(self.imgs, self.st_v.x[0])
+        self.st_a.forward(self.blk_a)
+        self.st_v.forward(self.blk_v)
+        xj = self.st_mm.x[0]
+        _ln_fwd(self.st_a.out, self.fin_a, xj, self.fstat_a[0], self.fstat_a[1], self.rows_a, LN_EPS_FINAL, out_map=self.map_a)
+        _ln_fwd(self.st_v.out, self.fin_v, xj, self.fstat_v[0], self.fstat_v[1], self.rows_v, LN_EPS_FINAL, out_map=self.map_v)
+        self.st_mm.forward(self.blk_mm)
+        rows_j = B * self.n_enc
+        ops.cast_scale(self.st_mm.out, self.xj_b, rows_j * cfg.embed_dim, 1.0)
+        ops.gemm_nt(self.xj_b, self.dec_embed.w, self.de, rows_j, bias=self.dec_embed.b)                  # :600
+        rows_d = B * self.Ltot
+        ops.unshuffle_fwd(self.de, self.src_row, self.pos_row, self.dmod, self.tok["mask_token"], self.tok["decoder_pos_embed_a"],
+                          self.tok["decoder_pos_embed_v"], self.tok["decoder_modality_a"], self.tok["decoder_modality_v"],
+                          self.st_dec.x[0], rows_d)
+        self.st_dec.forward(self.blk_dec)
+        _ln_fwd(self.st_dec.out, self.dec_norm, self.dn, self.dn_stat[0], self.dn_stat[1], rows_d, LN_EPS_BLOCK, out_map=self.dn_map)
+        ops.gemm_nt(self.dn[:self.v_off], self.pred_a.w, self.p_a, self.na_rows, bias=self.pred_a.b)       # :634
+        ops.gemm_nt(self.dn[self.v_off:], self.pred_v.w, self.p_v, self.nv_rows, bias=self.pred_v.b)       # :635
+        ops.mae_loss_fwd(self.p_a, audio, self.mask_a.view(-1), self.rl_a, self.losses[0:1], True, La, self.nmask_a)
+        ops.mae_loss_fwd(self.p_v, self.imgs, self.mask_v.view(-1), self.rl_v, self.losses[1:2], False, Lv, self.nmask_v)
+        torch.add(self.losses[0:1], self.losses[1:2], out=self.losses[2:3])                                 # :707
+        return self.losses[2:3], self.losses[0:1], self.losses[1:2], self.mask_a, self.mask_v
+
+    def backward(self, gout):
+        cfg, B, T = self.cfg, self.B, self.cfg.frames
+        La, Lv, D, Dd = cfg.audio_tokens, cfg.video_tokens, cfg.embed_dim, cfg.dec_dim
+        ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a)
+        ops.mae_loss_bwd(self.p_v, self.imgs, self.mask_v.view(-1), gout, self.dp_v, False, Lv, self.nmask_v)
+        # prediction heads
+        ops.gemm_nt(self.dp_a, self.pred_a.wt, self.ddn[:self.v_off], self.na_rows)
+        ops.gemm_tn(self.dp_a, self.dn[:self.v_off], self.pred_a.gw, self.na_rows)
+        ops.colsum(self.dp_a, self.pred_a.gb, self.na_rows)
+        ops.gemm_nt(self.dp_v, self.pred_v.wt, self.ddn[self.v_off:], self.nv_rows)
+        ops.gemm_tn(self.dp_v, self.dn[self.v_off:], self.pred_v.gw, self.nv_rows)
+        ops.colsum(self.dp_v, self.pred_v.gb, self.nv_rows)
+        sd = self.st_dec
+        rows_d = B * self.Ltot
+        _ln_bwd(self.ddn, sd.out, self.dn_stat[0], self.dn_stat[1], self.dec_norm, sd.dx[0], sd.lnws, rows_d,
+                out_map=self.dn_map, dx_bf16=sd.dxb[0])
+        sd.backward(self.blk_dec)
+        g = self.gtok
+        ops.unshuffle_bwd(sd.dx[0], self.src_row, B, T, La, Lv, self.dde, g["decoder_pos_embed_a"], g["decoder_pos_embed_v"],
+                          g["mask_token"], g["decoder_modality_a"], g["decoder_modality_v"])
+        rows_j = B * self.n_enc
+        ops.cast_scale(self.dde, self.dde_b, rows_j * Dd, 1.0)
+        sm = self.st_mm
+        ops.gemm_nt(self.dde_b, self.dec_embed.wt, sm.dx[0], rows_j)
+        ops.gemm_tn(self.dde_b, self.xj_b, self.dec_embed.gw, rows_j)
+        ops.colsum(self.dde_b, self.dec_embed.gb, rows_j)
+        ops.cast_scale(sm.dx[0], sm.dxb[0], rows_j * D, 1.0)
+        sm.backward(self.blk_mm)
+        for st, fin, fstat, omap, rows, emb, blks in ((self.st_a, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.emb_a, self.blk_a),
+                                                      (self.st_v, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.emb_v, self.blk_v)):
+            _ln_bwd(sm.dx[0], st.out, fstat[0], fstat[1], fin, st.dx[0], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0])
+            st.backward(blks)
+            emb.backward(st.dx[0])

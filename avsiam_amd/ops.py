@@ -38,7 +38,7 @@ def layernorm_ws(rows, D):
 
 def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod=None, out_map=None):
     D = x.shape[1]
-    _chk(x, F32, "ln.x", 2); _chk(y, BF16, "ln.y", 2); _chk(mean, F32, "ln.mean"); _chk(rstd, F32, "ln.rstd")
+    _chk(x, F32, "ln.x", 2); _chk(y, y.dtype if y.dtype in (BF16, F32) else BF16, "ln.y", 2); _chk(mean, F32, "ln.mean"); _chk(rstd, F32, "ln.rstd")
     _chk(g0, F32, "ln.g0"); _chk(b0, F32, "ln.b0"); _chk(g1, F32, "ln.g1"); _chk(b1, F32, "ln.b1")
     _chk(row_mod, U8, "ln.row_mod"); _chk(out_map, I32, "ln.out_map")
     assert x.shape[0] >= rows and mean.numel() >= rows and rstd.numel() >= rows and y.shape[1] == D
@@ -49,13 +49,17 @@ def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod
         assert out_map.numel() >= rows
     else:
         assert y.shape[0] >= rows
-    _lib.call("avs_layernorm_fwd", x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, D, float(eps), _stream())
+    _lib.call("avs_layernorm_fwd", x, g0, b0, g1, b1, row_mod, out_map, y, 1 if y.dtype == F32 else 0, mean, rstd, rows, D,
+              float(eps), _stream())
 
 
 def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=None, db1=None, row_mod=None,
-                  out_map=None, dres=None):
+                  out_map=None, dres=None, dx_bf16=None):
     D = x.shape[1]
-    _chk(dy, BF16, "lnb.dy", 2); _chk(x, F32, "lnb.x", 2); _chk(dx, F32, "lnb.dx", 2); _chk(dres, F32, "lnb.dres", 2)
+    _chk(dy, dy.dtype if dy.dtype in (BF16, F32) else BF16, "lnb.dy", 2); _chk(x, F32, "lnb.x", 2); _chk(dx, F32, "lnb.dx", 2)
+    _chk(dres, F32, "lnb.dres", 2); _chk(dx_bf16, BF16, "lnb.dx_bf16", 2)
+    if dx_bf16 is not None:
+        assert dx_bf16.shape[0] >= rows and dx_bf16.shape[1] == D
     _chk(ws, F32, "lnb.ws"); _chk(row_mod, U8, "lnb.row_mod"); _chk(out_map, I32, "lnb.out_map")
     for t, n in ((g0, "g0"), (g1, "g1"), (dg0, "dg0"), (db0, "db0"), (dg1, "dg1"), (db1, "db1"), (mean, "mean"), (rstd, "rstd")):
         _chk(t, F32, "lnb." + n)
@@ -65,8 +69,8 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
         assert dy.shape[0] >= rows
     if dres is not None:
         assert dres.shape[0] >= rows and dres.shape[1] == D
-    _lib.call("avs_layernorm_bwd", dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dg0, db0, dg1, db1, ws, rows, D,
-              _stream())
+    _lib.call("avs_layernorm_bwd", dy, 1 if dy.dtype == F32 else 0, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16,
+              dg0, db0, dg1, db1, ws, rows, D, _stream())
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -199,15 +203,15 @@ def unshuffle_bwd(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a
 
 
 def segment_mean_fwd(y, seg_start, reps, nseg):
-    _chk(y, BF16, "segmean.y", 2); _chk(seg_start, I32, "segmean.seg"); _chk(reps, F32, "segmean.reps", 2)
+    _chk(y, F32, "segmean.y", 2); _chk(seg_start, I32, "segmean.seg"); _chk(reps, F32, "segmean.reps", 2)
     assert seg_start.numel() >= nseg + 1 and reps.shape[0] >= nseg and reps.shape[1] == y.shape[1]
     _lib.call("avs_segment_mean_fwd", y, seg_start, reps, nseg, y.shape[1], _stream())
 
 
-def segment_mean_bwd(dreps, seg_start, dy, nseg):
-    _chk(dy, BF16, "segmeanb.dy", 2); _chk(seg_start, I32, "segmeanb.seg"); _chk(dreps, F32, "segmeanb.dreps", 2)
+def segment_mean_bwd(dreps, seg_start, dy, nseg, scale=1.0):
+    _chk(dy, F32, "segmeanb.dy", 2); _chk(seg_start, I32, "segmeanb.seg"); _chk(dreps, F32, "segmeanb.dreps", 2)
     assert seg_start.numel() >= nseg + 1 and dreps.shape[0] >= nseg and dreps.shape[1] == dy.shape[1]
-    _lib.call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], _stream())
+    _lib.call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], float(scale), _stream())
 
 
 def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask):

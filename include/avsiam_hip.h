@@ -28,15 +28,18 @@ int avs_device_cu_count(void);
 
 /* ---- LayerNorm with per-row modality affine (Block.norm1/_a/_v, norm2/_a/_v: src/models/cav_mae_base.py:120-122,
  * 135-137,151-152,169-170,190-191; final norms :492,495,563,566,631).  x fp32 [rows,D] -> y bf16.  row_mod (0/1 per
- * row, may be NULL) picks (g0,b0) or (g1,b1); out_map (may be NULL) redirects output row r to y[out_map[r]]. */
+ * row, may be NULL) picks (g0,b0) or (g1,b1); out_map (may be NULL) redirects output row r to y[out_map[r]]; y is bf16
+ * (GEMM operand) or fp32 when y_f32 (final norms that feed the fp32 residual stream / the token mean). */
 int avs_layernorm_ws_floats(int rows, int D);
 int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
-                      const uint8_t* row_mod, const int* out_map, avs_bf16* y, float* mean, float* rstd, int rows, int D,
-                      float eps, avs_stream_t stream);
-/* dx = dres + LN'(dy) (dres may be NULL; dx may alias dres); dg/db are accumulated (+=); ws: avs_layernorm_ws_floats */
-int avs_layernorm_bwd(const avs_bf16* dy, const float* x, const float* mean, const float* rstd, const float* g0,
-                      const float* g1, const uint8_t* row_mod, const int* out_map, const float* dres, float* dx, float* dg0,
-                      float* db0, float* dg1, float* db1, float* ws, int rows, int D, avs_stream_t stream);
+                      const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd, int rows,
+                      int D, float eps, avs_stream_t stream);
+/* dx = dres + LN'(dy) (dres may be NULL; dx may alias dres); dy is bf16, or fp32 when dy_f32; dx_bf16 (may be NULL) gets a
+ * bf16 copy of dx; dg/db are accumulated (+=); ws: avs_layernorm_ws_floats */
+int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* g0,
+                      const float* g1, const uint8_t* row_mod, const int* out_map, const float* dres, float* dx,
+                      avs_bf16* dx_bf16, float* dg0, float* db0, float* dg1, float* db1, float* ws, int rows, int D,
+                      avs_stream_t stream);
 
 /* ---- bf16 MFMA GEMMs (nn.Linear / PatchEmbed.proj and their backward: cav_mae_base.py:51,55,60,77,96-99,138-143,
  * 600,634-635).  nt: out = alpha*(A[M,K].B[N,K]^T + bias [*gelu'(aux)] + res[res_idx? res_idx[m] : m]); act 0 none,
@@ -78,8 +81,9 @@ int avs_unshuffle_bwd(const float* dout, const int* src_row, int B, int T, int L
                       float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D, avs_stream_t stream);
 
 /* ---- token mean per packed sequence (.mean(dim=1), cav_mae_base.py:563,566) */
-int avs_segment_mean_fwd(const avs_bf16* y, const int* seg_start, float* reps, int nseg, int D, avs_stream_t stream);
-int avs_segment_mean_bwd(const float* dreps, const int* seg_start, avs_bf16* dy, int nseg, int D, avs_stream_t stream);
+int avs_segment_mean_fwd(const float* y, const int* seg_start, float* reps, int nseg, int D, avs_stream_t stream);
+int avs_segment_mean_bwd(const float* dreps, const int* seg_start, float* dy, int nseg, int D, float scale,
+                         avs_stream_t stream);
 
 /* ---- masked-MSE with patchify on the fly (patchify + forward_mae_loss, cav_mae_base.py:343-351,663-683) */
 int avs_mae_loss_fwd(const float* pred, const float* inp, const float* mask, float* row_loss, float* loss, int rows,

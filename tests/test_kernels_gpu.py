@@ -68,6 +68,20 @@ def test_layernorm(D, rows):
     for i in range(2):
         assert rel_err(dg[i], gr[i].grad) < 1e-4
         assert rel_err(db[i], br[i].grad) < 1e-4
+    # fp32 I/O mode (final norms) + fused bf16 copy of dx
+    yf = torch.zeros(rows, D, device=DEV)
+    o.layernorm_fwd(x, g[0], b[0], yf, mean, rstd, rows, 1e-6, g[1], b[1], mod, perm)
+    y0 = F.layer_norm(x.double(), (D,), g[0].double(), b[0].double(), 1e-6)
+    y1 = F.layer_norm(x.double(), (D,), g[1].double(), b[1].double(), 1e-6)
+    assert rel_err(yf.double()[perm.long()], torch.where(mod.bool()[:, None], y1, y0)) < 1e-5
+    dyf = torch.zeros(rows, D, device=DEV)
+    dyf[perm.long()] = bf(dy_nat).float()
+    dx2 = torch.empty(rows, D, device=DEV)
+    dxb = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    o.layernorm_fwd(x, g[0], b[0], yf, mean, rstd, rows, 1e-5, g[1], b[1], mod, perm)
+    o.layernorm_bwd(dyf, x, mean, rstd, g[0], dx2, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres, dxb)
+    assert rel_err(dx2, dx) < 1e-6
+    assert torch.equal(dxb, bf(dx2))
 
 
 @pytest.mark.parametrize("M,N,K", [(333, 256, 768), (1000, 768, 3072), (4099, 2304, 768), (128, 512, 256)])
@@ -249,17 +263,18 @@ def test_segment_mean_colsum_scatter_cast_transpose():
     D = 768
     lens = [5, 100, 39, 1]
     rows = sum(lens)
-    y = bf(torch.randn(rows, D, device=DEV))
+    yf = torch.randn(rows, D, device=DEV)
+    y = bf(yf)
     seg = torch.tensor([0, 5, 105, 144, 145], dtype=torch.int32, device=DEV)
     reps = torch.empty(4, D, device=DEV)
-    o.segment_mean_fwd(y, seg, reps, 4)
-    ref = torch.stack([y[seg[i]:seg[i + 1]].double().mean(0) for i in range(4)])
+    o.segment_mean_fwd(yf, seg, reps, 4)
+    ref = torch.stack([yf[seg[i]:seg[i + 1]].double().mean(0) for i in range(4)])
     assert rel_err(reps, ref) < 1e-6
     dreps = torch.randn(4, D, device=DEV)
-    dy = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
-    o.segment_mean_bwd(dreps, seg, dy, 4)
-    refdy = torch.cat([(dreps[i] / lens[i]).expand(lens[i], D) for i in range(4)])
-    assert rel_err(dy, refdy) < 4e-3
+    dy = torch.zeros(rows, D, device=DEV)
+    o.segment_mean_bwd(dreps, seg, dy, 4, 3.0)
+    refdy = torch.cat([(3 * dreps[i] / lens[i]).expand(lens[i], D) for i in range(4)])
+    assert rel_err(dy, refdy) < 1e-6
     cs = torch.zeros(D, device=DEV)
     o.colsum(y, cs, rows)
     assert rel_err(cs, y.double().sum(0)) < 1e-5
