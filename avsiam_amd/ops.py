@@ -27,6 +27,39 @@ def _stream():
     return _lib.current_stream()
 
 
+class KernelProfiler:
+    """HIP-event timing of individual launches on torch's current stream (the stream the kernels run on).
+    Enabled by bench.py over its timed region: `ops.prof = KernelProfiler()`; read with .summary() after a sync."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def add(self, kind, e0, e1, work):
+        self.rec.setdefault(kind, []).append((e0, e1, work))
+
+    def summary(self):
+        out = {}
+        for kind, lst in self.rec.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in lst)
+            work = sum(w for _, _, w in lst)
+            out[kind] = {"launches": len(lst), "total_ms": ms, "avg_us": 1e3 * ms / len(lst), "work": work,
+                         "rate": work / (ms * 1e-3) if ms > 0 else 0.0}
+        return out
+
+
+prof = None
+
+
+def _launch(kind, work, cname, *args):
+    if prof is None:
+        return _lib.call(cname, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(cname, *args)
+    e1.record()
+    prof.add(kind, e0, e1, work)
+
+
 def pad_rows(n, mult=128):
     return (n + mult - 1) // mult * mult
 
@@ -49,7 +82,7 @@ def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod
         assert out_map.numel() >= rows
     else:
         assert y.shape[0] >= rows
-    _lib.call("avs_layernorm_fwd", x, g0, b0, g1, b1, row_mod, out_map, y, 1 if y.dtype == F32 else 0, mean, rstd, rows, D,
+    _launch("layernorm_fwd", float(rows) * D * (4 + y.element_size()), "avs_layernorm_fwd", x, g0, b0, g1, b1, row_mod, out_map, y, 1 if y.dtype == F32 else 0, mean, rstd, rows, D,
               float(eps), _stream())
 
 
@@ -69,7 +102,8 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
         assert dy.shape[0] >= rows
     if dres is not None:
         assert dres.shape[0] >= rows and dres.shape[1] == D
-    _lib.call("avs_layernorm_bwd", dy, 1 if dy.dtype == F32 else 0, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16,
+    _launch("layernorm_bwd", float(rows) * D * (dy.element_size() + 4 + 4 + (4 if dres is not None else 0) + (2 if dx_bf16 is not None else 0)),
+            "avs_layernorm_bwd", dy, 1 if dy.dtype == F32 else 0, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16,
               dg0, db0, dg1, db1, ws, rows, D, _stream())
 
 
@@ -94,7 +128,7 @@ def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None
         assert out2 is not None and out2.shape[0] >= M and out2.shape[1] == N
     if act == 2:
         assert aux is not None and aux.shape[0] >= M and aux.shape[1] == N
-    _lib.call("avs_gemm_nt_bf16", A, A.stride(0), B, B.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
+    _launch("gemm_nt_act%d" % act, 2.0 * M * N * K, "avs_gemm_nt_bf16", A, A.stride(0), B, B.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
               res_idx, aux, aux.stride(0) if aux is not None else 0, out, out.stride(0), 1 if out.dtype == F32 else 0, out2,
               out2.stride(0) if out2 is not None else 0, float(alpha), act, _stream())
 
@@ -106,7 +140,7 @@ def gemm_tn(A, B, C, M, splits=0):
     need = pad_rows(M, 64)
     assert A.shape[0] >= need and B.shape[0] >= need, "wgrad operands must be allocated (zero) to a multiple of 64 rows"
     assert C.numel() == N1 * N2
-    _lib.call("avs_gemm_tn_bf16", A, A.stride(0), B, B.stride(0), C, N2, M, N1, N2, splits, _stream())
+    _launch("gemm_tn", 2.0 * M * N1 * N2, "avs_gemm_tn_bf16", A, A.stride(0), B, B.stride(0), C, N2, M, N1, N2, splits, _stream())
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -126,6 +160,7 @@ class AttnTiles:
         self.len = torch.tensor(lens, dtype=I32, device=device)
         self.q0 = torch.tensor(q0s, dtype=I32, device=device)
         self.max_row = row
+        self.sum_sq = float(sum(L * L for L in seq_lens))        # sum of L^2: attention FLOPs = 4 * sum_sq * D
 
 
 def attn_fwd(qkv, tiles, H, out, lse):
@@ -134,7 +169,7 @@ def attn_fwd(qkv, tiles, H, out, lse):
     assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64)
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row
     assert lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    _lib.call("avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, out, out.stride(0),
+    _launch("attn_fwd", 4.0 * tiles.sum_sq * D, "avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, out, out.stride(0),
               lse, lse.shape[1], _stream())
 
 
@@ -144,7 +179,7 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
     D = qkv.shape[1] // 3
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    _lib.call("avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, out, dout,
+    _launch("attn_bwd", 10.0 * tiles.sum_sq * D, "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, out, dout,
               out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
 
 

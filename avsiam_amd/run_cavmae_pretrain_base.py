@@ -1,0 +1,103 @@
+"""Entry point with the flag surface of the reference (/root/reference/src/run_cavmae_pretrain_base.py:47-104).
+
+    torchrun --nnodes=1 --nproc_per_node=8 --master-addr 127.0.0.1 -m avsiam_amd.run_cavmae_pretrain_base \\
+        --model cav-mae --dataset audioset --target_length 1024 --batch-size 64 --lr 2e-4 --n-epochs 1 ...
+
+Flags the reference parses but its model ignores (masking ratios, mask_mode, norm_pix_loss, tr_pos: SURVEY.md section 5)
+are accepted and equally inert.  Data flags: with --data-train '' (or 'synthetic') AudioSet-shaped synthetic
+batches are used - the sqlite/wav/mp4 input pipeline (src/dataloader.py) is out of scope for this path.
+--frames is an extension (T frames per sample).
+"""
+import argparse
+import ast
+import json
+import os
+import pickle
+import time
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("--data-train", type=str, default='', help="training data json ('' or 'synthetic': synthetic tensors)")
+    parser.add_argument("--data-val", type=str, default='', help="validation data json")
+    parser.add_argument("--data-eval", type=str, default=None, help="evaluation data json")
+    parser.add_argument("--label-csv", type=str, default='', help="csv with class labels")
+    parser.add_argument("--n_class", type=int, default=527, help="number of classes")
+    parser.add_argument("--model", type=str, default='cav-mae', help="the model used")
+    parser.add_argument("--dataset", type=str, default="audioset", choices=["audioset", "esc50", "speechcommands", "fsd50k", "vggsound", "epic", "k400", "msrvtt"])
+    parser.add_argument("--dataset_mean", type=float, default=-5.081)
+    parser.add_argument("--dataset_std", type=float, default=4.4849)
+    parser.add_argument("--target_length", type=int, default=1024, help="the input length in frames")
+    parser.add_argument("--noise", type=ast.literal_eval, default=False)
+    parser.add_argument("--exp-dir", type=str, default="", help="directory to dump experiments")
+    parser.add_argument('--lr', '--learning-rate', default=0.001, type=float, metavar='LR')
+    parser.add_argument("--optim", type=str, default="adam", choices=["sgd", "adam"])
+    parser.add_argument('-b', '--batch-size', default=12, type=int, metavar='N')
+    parser.add_argument('-w', '--num_workers', default=6, type=int, metavar='NW')
+    parser.add_argument("--n-epochs", type=int, default=1)
+    parser.add_argument("--lr_patience", type=int, default=2)
+    parser.add_argument("--lr_adapt", type=ast.literal_eval, default=False)
+    parser.add_argument("--metrics", type=str, default="mAP", choices=["mAP", "acc"])
+    parser.add_argument('--warmup', type=ast.literal_eval, default='True')
+    parser.add_argument("--lrscheduler_start", default=10, type=int)
+    parser.add_argument("--lrscheduler_step", default=5, type=int)
+    parser.add_argument("--lrscheduler_decay", default=0.5, type=float)
+    parser.add_argument("--n-print-steps", type=int, default=50)
+    parser.add_argument('--save_model', type=ast.literal_eval, default=False)
+    parser.add_argument("--mixup", type=float, default=0)
+    parser.add_argument("--bal", type=str, default=None)
+    parser.add_argument("--cont_model", type=str, default=None)
+    parser.add_argument("--weight_file", type=str, default=None)
+    parser.add_argument('--norm_pix_loss', type=ast.literal_eval, default=None)
+    parser.add_argument("--pretrain_path", type=str, default='None')
+    parser.add_argument("--contrast_loss_weight", type=float, default=0.01)
+    parser.add_argument("--mae_loss_weight", type=float, default=3.0)
+    parser.add_argument('--tr_pos', type=ast.literal_eval, default=None)
+    parser.add_argument("--masking_ratio", type=float, default=0.75)
+    parser.add_argument("--masking_ratio_a", type=float, default=None)
+    parser.add_argument("--mask_mode", type=str, default='unstructured', choices=['unstructured', 'time', 'freq', 'tf'])
+    parser.add_argument("--wandb", type=int, default=0)
+    parser.add_argument('--model_name', type=str, default=None)
+    parser.add_argument('--world_size', default=1, type=int)
+    parser.add_argument('--local_rank', default=-1, type=int)
+    parser.add_argument('--dist_url', default='env://')
+    # extensions
+    parser.add_argument('--frames', default=1, type=int, help="frames per sample (extension; reference pre-training uses 1)")
+    parser.add_argument('--steps-per-epoch', dest="steps_per_epoch", default=20, type=int, help="synthetic-data epoch length")
+    return parser
+
+
+def main(argv=None):
+    import torch
+    from . import models, utils
+    from .config import AVSiamConfig
+    from .traintest_cavmae_base import train
+    print("I am process %s, running on %s: starting (%s)" % (os.getpid(), os.uname()[1], time.asctime()))
+    args = build_parser().parse_args(argv)
+    if args.masking_ratio_a is None:
+        args.masking_ratio_a = args.masking_ratio
+    args.local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    utils.init_seeds(87 + args.local_rank)                                    # :113
+    utils.init_distributed_mode(args)                                         # :114
+    print('current mae loss {:.3f}, and contrastive loss {:.3f}'.format(args.mae_loss_weight, args.contrast_loss_weight))
+    if args.data_train not in ('', 'synthetic'):
+        raise SystemExit("only synthetic AudioSet-shaped data is supported on this path (see module docstring)")
+    if args.model != 'cav-mae':
+        raise ValueError('model not supported')
+    cfg = AVSiamConfig(audio_tokens=args.target_length // 16 * 8, frames=args.frames)
+    audio_model = models.CAVMAE_BASE(audio_length=args.target_length, norm_pix_loss=args.norm_pix_loss,
+                                     modality_specific_depth=23, tr_pos=args.tr_pos, opt=args, cfg=cfg)        # :175
+    if args.exp_dir and args.rank == 0:
+        os.makedirs("%s/models" % args.exp_dir, exist_ok=True)
+        with open("%s/args.pkl" % args.exp_dir, "wb") as f:
+            pickle.dump(args, f)
+        with open(args.exp_dir + '/args.json', 'w') as f:
+            json.dump(args.__dict__, f, indent=2)
+    print('Now starting training for {:d} epochs.'.format(args.n_epochs))
+    train(audio_model, None, [None, None], [None, None], None, args, None)                                        # :212
+    if args.distributed:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

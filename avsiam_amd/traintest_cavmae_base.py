@@ -1,0 +1,139 @@
+"""The pre-training step and loop of the reference (/root/reference/src/traintest_cavmae_base.py:29-264),
+re-scheduled for the flat-arena model.
+
+Reference step (:131-152):  pass 1 contrastive-only fwd/bwd -> Adam#1 -> pass 2 MAE-only fwd/bwd (sees the updated
+weights) -> Adam#2, under fp16 autocast + GradScaler and DDP(find_unused_parameters=True).
+Here: bf16 operands with fp32 accumulation (no loss scaling needed), gradients of each pass live in one contiguous
+range -> one RCCL all-reduce + one fused Adam launch per pass; parameters a pass does not touch get no update,
+exactly like torch.optim.Adam skipping grad=None parameters.
+"""
+import datetime
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from .param_spec import P1, P2
+from .utils import AverageMeter
+
+
+def train_step(model, a_input, v_input, lr, plans=None):
+    """One reference step on one batch.  Returns the device scalars the reference logs (no host sync here):
+    (loss_pass2, loss_mae_a, loss_mae_v, loss_c, c_acc)."""
+    B = a_input.shape[0]
+    pm, pc = plans if plans is not None else model.draw_plans(B)
+    out = model(a_input, v_input, mae_loss_weight=0, contrast_loss_weight=1, mask_plan=pc)        # :132
+    loss_c, c_acc = out[4], out[7]
+    out[0].backward()                                                                             # :138
+    model.allreduce_grads(P1)
+    model.adam_step(P1, lr)                                                                       # :139
+    out = model(a_input, v_input, mae_loss_weight=1, contrast_loss_weight=0, mask_plan=pm)        # :147
+    out[0].backward()                                                                             # :150
+    model.allreduce_grads(P2)
+    model.adam_step(P2, lr)                                                                       # :151
+    return out[0], out[2], out[3], loss_c, c_acc
+
+
+class SyntheticAVLoader:
+    """AudioSet-shaped synthetic batches (there is no dataset here): a ~ N(0,1) [B, target_length, 128],
+    v ~ N(0,1) [B,(T,)3,224,224], generated on the device once and re-used."""
+
+    def __init__(self, cfg, batch_size, steps, device, seed=87):
+        from .weights import synth_inputs
+        a, v = synth_inputs(cfg, batch_size, seed)
+        self.a, self.v, self.steps = a.to(device), v.to(device), steps
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            yield self.a, self.v, None
+
+
+def validate(model, loader):
+    """validate() of the reference (:381-424): no-grad forward with both losses; masks stay random."""
+    meters = [AverageMeter() for _ in range(6)]
+    with torch.no_grad():
+        for a, v, _ in loader:
+            out = model(a, v, mae_loss_weight=1, contrast_loss_weight=1)
+            for m, i in zip(meters, (0, 1, 2, 3, 4, 7)):
+                m.update(out[i].item(), a.shape[0])
+    return tuple(m.avg for m in meters)
+
+
+def train(audio_model, train_sampler, test_loader, test_sampler, train_loader_linear, args, audio_conf):
+    """Signature of the reference ``train`` (:29).  ``train_sampler`` may be a DataLoader-like iterable yielding
+    (a_input, v_input, label); with args.data_train in ('', 'synthetic') a SyntheticAVLoader is used.  The per-epoch
+    MLP probe (linear_val, broken in the reference: SURVEY.md quick facts) is out of scope."""
+    rank = getattr(args, "rank", 0)
+    device = torch.device("cuda", getattr(args, "gpu", 0))
+    audio_model = audio_model.to(device)
+    audio_model.set_distributed(getattr(args, "world_size", 1), rank)
+    audio_model.publish_grads = False                       # gradients stay in the flat arena
+    print('Total parameter number is : {:.3f} million'.format(sum(p.numel() for p in audio_model.parameters()) / 1e6))
+    per_sample_time, per_sample_dnn_time = AverageMeter(), AverageMeter()
+    loss_av_meter, loss_a_meter, loss_v_meter, loss_c_meter = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    progress, result = [], np.zeros([args.n_epochs, 10])
+    exp_dir = args.exp_dir
+    global_step, epoch, best_loss, best_epoch = 0, 1, np.inf, 0
+    start_time = time.time()
+    lr = args.lr
+    milestones = set(range(args.lrscheduler_start, 1000, args.lrscheduler_step))      # MultiStepLR (:73-74)
+    if train_sampler is None or not hasattr(train_sampler, "__iter__"):
+        train_loader = SyntheticAVLoader(audio_model.cfg, args.batch_size, getattr(args, "steps_per_epoch", 20), device, 87 + rank)
+    else:
+        train_loader = train_sampler
+    test_loader = test_loader[0] if isinstance(test_loader, (list, tuple)) else test_loader
+    while epoch < args.n_epochs + 1:
+        begin_time = end_time = time.time()
+        print('---------------'); print(datetime.datetime.now())
+        print("current #epochs=%s, #steps=%s" % (epoch, global_step))
+        for i, (a_input, v_input, _) in enumerate(train_loader):
+            B = a_input.size(0)
+            a_input = a_input.to(device, non_blocking=True)
+            v_input = v_input.to(device, non_blocking=True)
+            dnn_start_time = time.time()
+            loss, la, lv, lc, c_acc = train_step(audio_model, a_input, v_input, lr)
+            print_step = global_step % args.n_print_steps == 0
+            if print_step:                                   # host syncs only on print steps (the reference syncs 4x per step, :160-163)
+                loss_av_meter.update(loss.item(), B); loss_a_meter.update(la.item(), B)
+                loss_v_meter.update(lv.item(), B); loss_c_meter.update(lc.item(), B)
+                per_sample_time.update((time.time() - end_time) / B)
+                per_sample_dnn_time.update((time.time() - dnn_start_time) / B)
+                print('Epoch: [{0}][{1}/{2}]\t Per Sample Total Time {3:.5f}\t Per Sample DNN Time {4:.5f}\t Train Total Loss {5:.4f}\t'
+                      'Train MAE Loss Audio {6:.4f}\t Train MAE Loss Visual {7:.4f}\t Train Contrastive Loss {8:.4f}\t Train Contrastive Acc {9:.3f}'
+                      .format(epoch, i, len(train_loader), per_sample_time.avg, per_sample_dnn_time.avg, loss_av_meter.val,
+                              loss_a_meter.val, loss_v_meter.val, loss_c_meter.val, c_acc.item()), flush=True)
+                if np.isnan(loss_av_meter.avg):
+                    print("training diverged...")
+                    return
+            end_time = time.time()
+            global_step += 1
+        ev = (0.0,) * 6
+        if test_loader is not None:
+            print('start validation')
+            ev = validate(audio_model, test_loader)
+            print("Eval Total Loss: {:.6f}  Eval Contrastive Accuracy: {:.6f}".format(ev[0], ev[5]))
+        result[epoch - 1, :] = [loss_a_meter.avg, loss_v_meter.avg, loss_c_meter.avg, loss_av_meter.avg, ev[2], ev[3], ev[4], ev[0], ev[5], lr]
+        if rank == 0 and exp_dir:
+            os.makedirs("%s/models" % exp_dir, exist_ok=True)
+            np.savetxt(exp_dir + '/result.csv', result, delimiter=',')
+            if ev[0] < best_loss:
+                best_loss, best_epoch = ev[0], epoch
+            if getattr(args, "save_model", False):
+                # DDP-style 'module.'-prefixed keys so reference consumers (run_cavmae_ft_base.py:245-248) can load it
+                sd = {"module." + k: v.detach().cpu() for k, v in audio_model.state_dict().items()}
+                torch.save(sd, "%s/models/audio_model.%d.pth" % (exp_dir, epoch))
+            progress.append([epoch, global_step, best_epoch, best_loss, time.time() - start_time])
+            with open("%s/progress.pkl" % exp_dir, "wb") as f:
+                pickle.dump(progress, f)
+        if epoch in milestones:
+            lr *= args.lrscheduler_decay
+        print('Epoch-{0} lr: {1}'.format(epoch, lr))
+        print('epoch {:d} training time: {:.3f}'.format(epoch, time.time() - begin_time))
+        epoch += 1
+        for m in (per_sample_time, per_sample_dnn_time, loss_av_meter, loss_a_meter, loss_v_meter, loss_c_meter):
+            m.reset()
