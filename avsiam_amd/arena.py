@@ -82,6 +82,13 @@ class ParamArena:
             self.g = self.pb = self.wt = None
         return self
 
+    def ensure_grads(self):
+        """Allocate the flat gradient buffer on the arena's device (CPU arenas get one lazily: only the host-side
+        DP plumbing tests need it there)."""
+        if self.g is None:
+            self.g = torch.zeros(self.live_end, dtype=torch.float32, device=self.p.device)
+        return self.g
+
     # ----- views ---------------------------------------------------------------------------------
     def _v(self, flat, name, two_d=False):
         s = self.info[name]

@@ -294,7 +294,7 @@ class ContrastivePass:
         B, W, D = self.B, self.world, cfg.embed_dim
         if W > 1:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.all_reps, self.reps)         # c2: one [2,B,D] message per rank
+            dist.all_gather_into_tensor(self.all_reps.view(W * 2 * B, D), self.reps)   # c2: one [2,B,D] message per rank
             self.A.copy_(self.all_reps[:, :B].reshape(W * B, D))
             self.V.copy_(self.all_reps[:, B:].reshape(W * B, D))
         else:
