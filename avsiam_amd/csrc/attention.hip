@@ -18,6 +18,7 @@
 //     shape as forward) and dK/dV (key-major), so no atomics and bitwise-reproducible gradients.
 // Head dims 64 (encoder, 12 heads) and 32 (decoder, 16 heads).
 #include "common.h"
+#include <type_traits>
 
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -56,18 +57,35 @@ __device__ __forceinline__ bf16x8 acc_frag(const float* v) {
     return __builtin_bit_cast(bf16x8, u);
 }
 
-// stage a [64][HD] tile: global rows (clamped to the sequence) -> LDS image
+// Staging a [64][HD] tile is split (issue early / write late): tile_load puts the next tile's global loads in flight
+// before the current tile's MFMA work, tile_store writes them into the LDS image after the barrier that retires the
+// previous tile's reads - the HBM/L2 latency hides under the compute instead of being paid per tile.
 template <int HD>
-__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* src, long long ld, int row0, int last_row, int tid) {
+struct TileRegs {
+    static constexpr int NCH = HD / 8;
+    static constexpr int PER = 64 * NCH / 256;
+    uint4 v[PER];
+};
+
+template <int HD>
+__device__ __forceinline__ void tile_load(TileRegs<HD>& t, const bf16_t* src, long long ld, int row0, int last_row, int tid) {
     constexpr int NCH = HD / 8;
-    constexpr int PER = 64 * NCH / 256;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
+    for (int i = 0; i < TileRegs<HD>::PER; ++i) {
         const int c = i * 256 + tid;
         const int row = c / NCH, ch = c % NCH;
         const int gr = min(row0 + row, last_row);
-        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)gr * ld + ch * 8);
-        *reinterpret_cast<uint4*>(tile + Img<HD>::off(row, ch)) = v;
+        t.v[i] = *reinterpret_cast<const uint4*>(src + (size_t)gr * ld + ch * 8);
+    }
+}
+
+template <int HD>
+__device__ __forceinline__ void tile_store(const TileRegs<HD>& t, char* tile, int tid) {
+    constexpr int NCH = HD / 8;
+#pragma unroll
+    for (int i = 0; i < TileRegs<HD>::PER; ++i) {
+        const int c = i * 256 + tid;
+        *reinterpret_cast<uint4*>(tile + Img<HD>::off(c / NCH, c % NCH)) = t.v[i];
     }
 }
 
@@ -113,11 +131,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    TileRegs<HD> rk, rv;
+    tile_load<HD>(rk, base + a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
     for (int k0 = 0; k0 < L; k0 += 64) {
         __syncthreads();
-        stage_tile<HD>(sK, base + a.D, a.ld, k0, L - 1, tid);
-        stage_tile<HD>(sV, base + 2 * a.D, a.ld, k0, L - 1, tid);
+        tile_store<HD>(rk, sK, tid);
+        tile_store<HD>(rv, sV, tid);
         __syncthreads();
+        if (k0 + 64 < L) {
+            tile_load<HD>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
+        }
         if (!active) continue;
         f32x16 s[2];
 #pragma unroll
@@ -128,27 +153,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int kk = 0; kk < NKK; ++kk)
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
         }
+        // running max is kept in RAW score units (sl2 > 0 keeps the order); only the last, partial key tile needs masking
+        if (k0 + 64 > L) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[kb][r] = -INFINITY;
+        }
         float mloc = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float x = key < L ? s[kb][r] * sl2 : -INFINITY;
-                s[kb][r] = x;
-                mloc = fmaxf(mloc, x);
-            }
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = fast_exp2(m_run - m_new);
+        const float alpha = fast_exp2((m_run - m_new) * sl2);
         m_run = m_new;
+        const float nm = -m_new * sl2;
         float psum = 0.f;
         float p[2][16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[kb][r] = fast_exp2(s[kb][r] - m_new);
+                p[kb][r] = fast_exp2(fmaf(s[kb][r], sl2, nm));
                 psum += p[kb][r];
             }
         l_run = l_run * alpha + psum;
@@ -181,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 w.y = pack_bf2(o[d][4 * t + 2] * inv, o[d][4 * t + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + d * 32 + 8 * t + 4 * hh) = w;
             }
-        if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+        if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run * sl2 + log2f(l_tot)) * 0.6931471805599453f;
     }
 }
 
@@ -222,14 +251,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
+    TileRegs<HD> rk, rv;
+    tile_load<HD>(rk, base + a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
     for (int k0 = 0; k0 < L; k0 += 64) {
         __syncthreads();
-        stage_tile<HD>(sK, base + a.D, a.ld, k0, L - 1, tid);
-        stage_tile<HD>(sV, base + 2 * a.D, a.ld, k0, L - 1, tid);
+        tile_store<HD>(rk, sK, tid);
+        tile_store<HD>(rv, sV, tid);
         __syncthreads();
+        if (k0 + 64 < L) {
+            tile_load<HD>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
+        }
         if (!active) continue;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        auto key_block = [&](int kb, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -241,8 +277,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float pr = key < L ? fast_exp2(s[r] * sl2 - lse2) : 0.f;
+                float pr = fast_exp2(fmaf(s[r], sl2, -lse2));
+                if (TAIL && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) pr = 0.f;
                 ds[r] = pr * (dp[r] - delta);
             }
 #pragma unroll
@@ -252,6 +288,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 for (int d = 0; d < NDB; ++d)
                     dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sK, kb * 32 + 16 * st, d, lane), dsf, dq[d], 0, 0, 0);
             }
+        };
+        if (k0 + 64 <= L) {                                  // full tile: no masking code at all (block-uniform branch)
+            key_block(0, std::false_type{});
+            key_block(1, std::false_type{});
+        } else {
+            key_block(0, std::true_type{});
+            key_block(1, std::true_type{});
         }
     }
     if (!active) return;
@@ -301,19 +344,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
 
+    const bf16_t* dobase = a.dout + (size_t)seq0 * a.ldo + head * HD;
+    const float* lsebase = a.lse + (size_t)head * a.rows_total + seq0;
+    const float* delbase = a.delta + (size_t)head * a.rows_total + seq0;
+    TileRegs<HD> rq, rdo;
+    float rl = 0.f, rd = 0.f;
+    tile_load<HD>(rq, base, a.ld, 0, L - 1, tid);
+    tile_load<HD>(rdo, dobase, a.ldo, 0, L - 1, tid);
+    if (tid < 64) { rl = lsebase[min(tid, L - 1)]; rd = delbase[min(tid, L - 1)]; }
     for (int q0 = 0; q0 < L; q0 += 64) {
         __syncthreads();
-        stage_tile<HD>(sQ, base, a.ld, q0, L - 1, tid);
-        stage_tile<HD>(sDO, a.dout + (size_t)seq0 * a.ldo + head * HD, a.ldo, q0, L - 1, tid);
-        if (tid < 64) {
-            const int qr = min(q0 + tid, L - 1);
-            sLse[tid] = a.lse[(size_t)head * a.rows_total + seq0 + qr] * 1.4426950408889634f;
-            sDel[tid] = a.delta[(size_t)head * a.rows_total + seq0 + qr];
-        }
+        tile_store<HD>(rq, sQ, tid);
+        tile_store<HD>(rdo, sDO, tid);
+        if (tid < 64) { sLse[tid] = rl * 1.4426950408889634f; sDel[tid] = rd; }
         __syncthreads();
+        if (q0 + 64 < L) {
+            tile_load<HD>(rq, base, a.ld, q0 + 64, L - 1, tid);
+            tile_load<HD>(rdo, dobase, a.ldo, q0 + 64, L - 1, tid);
+            if (tid < 64) { rl = lsebase[min(q0 + 64 + tid, L - 1)]; rd = delbase[min(q0 + 64 + tid, L - 1)]; }
+        }
         if (!active) continue;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        auto q_block = [&](int qb, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -332,7 +384,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * t + j;
-                    const float pr = (q0 + rb + j) < L ? fast_exp2(s[r] * sl2 - ls[j]) : 0.f;
+                    float pr = fast_exp2(fmaf(s[r], sl2, -ls[j]));
+                    if (TAIL && (q0 + rb + j) >= L) pr = 0.f;
                     p[r] = pr;
                     ds[r] = pr * (dp[r] - dl[j]);
                 }
@@ -347,6 +400,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
                     dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, qb * 32 + 16 * st, d, lane), dsf, dk[d], 0, 0, 0);
                 }
             }
+        };
+        if (q0 + 64 <= L) {                                  // full query tile: no masking code (block-uniform branch)
+            q_block(0, std::false_type{});
+            q_block(1, std::false_type{});
+        } else {
+            q_block(0, std::true_type{});
+            q_block(1, std::true_type{});
         }
     }
     if (!active) return;

@@ -57,22 +57,33 @@ __global__ void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const in
     for (int c = threadIdx.x; c < D; c += blockDim.x) atomicAdd(d + c, scale * bf2f(src[(size_t)r * D + c]));
 }
 
-// out[c] += sum_r x[r, c]  (bias gradients).  Each block reduces COLSUM_ROWS rows in registers, one atomic per
-// column per block.
-constexpr int COLSUM_ROWS = 256;
-__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* out, int rows, int C) {
-    const int c2 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    if (c2 >= C) return;
+// out[c] += sum_r x[r, c]  (bias gradients).  A block owns 64 columns x COLSUM_ROWS rows: 8 threads cover the 64
+// columns with one 16-byte load each (a full 128-B line per row), 32 row-lanes stride the rows; partial sums are
+// combined through LDS and leave as one atomic per column per block.
+constexpr int COLSUM_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* out, int rows, int C) {
+    __shared__ float red[32][65];
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + cg * 8;
     const int r0 = blockIdx.y * COLSUM_ROWS;
     const int r1 = min(rows, r0 + COLSUM_ROWS);
-    float s0 = 0.f, s1 = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(x + (size_t)r * C + c2);
-        s0 += __uint_as_float(v << 16);
-        s1 += __uint_as_float(v & 0xffff0000u);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = r0 + rl; r < r1; r += 32) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)r * C + c0);
+        acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+        acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+        acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
+        acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
     }
-    atomicAdd(out + c2, s0);
-    atomicAdd(out + c2 + 1, s1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+        atomicAdd(out + blockIdx.x * 64 + threadIdx.x, s);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -260,9 +271,9 @@ extern "C" int avs_scatter_add_rows(const bf16_t* src, const int* idx, float* ds
 }
 
 extern "C" int avs_colsum_bf16(const bf16_t* x, float* out, int rows, int C, hipStream_t stream) {
-    AVS_CHECK_ARG(rows > 0 && (C % 2) == 0 && x && out, "colsum: bad args");
-    dim3 grid(ceil_div(C / 2, 128), ceil_div(rows, COLSUM_ROWS));
-    colsum_bf16_kernel<<<grid, 128, 0, stream>>>(x, out, rows, C);
+    AVS_CHECK_ARG(rows > 0 && (C % 64) == 0 && x && out, "colsum: C must be a multiple of 64");
+    dim3 grid(C / 64, ceil_div(rows, COLSUM_ROWS));
+    colsum_bf16_kernel<<<grid, 256, 0, stream>>>(x, out, rows, C);
     AVS_LAUNCH_CHECK("colsum");
     return 0;
 }

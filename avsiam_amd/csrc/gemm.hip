@@ -11,12 +11,12 @@
 // lane-linear so the bank-conflict swizzle is applied to the per-lane SOURCE address and again on the read.
 // fp32 accumulation on v_mfma_f32_16x16x32_bf16 (nt) / v_mfma_f32_32x32x16_bf16 (tn).
 #include "common.h"
+#include <stdlib.h>
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;     // one operand tile (either orientation) = 16 KiB
 
 struct GemmNtArgs {
     const bf16_t* A; long long lda;
@@ -37,43 +37,54 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];     // [buf][A|B]
+// Tile configurations (NWM = 2 waves along M, NWN waves along N; each wave MI x 4 MFMA tiles of 16x16):
+//   <NWN=2, MI=4>: 128x128 tile, 256 threads,  64 KiB LDS, 2 workgroups/CU  - small problems (fills the chip with few rows)
+//   <NWN=4, MI=8>: 256x256 tile, 512 threads, 128 KiB LDS, 1 workgroup/CU   - halves the L2->LDS bytes per FLOP, which is
+//                  what bounds the 128^2 tile (at full MFMA rate it would need more than the L2 can deliver)
+template <int ACT, int NWN, int MI>
+__global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
+    constexpr int NT = 128 * NWN;                 // threads
+    constexpr int TBM = 2 * MI * 16;              // tile rows (A / activations)
+    constexpr int TBN = NWN * 64;                 // tile cols (B rows / weights)
+    constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int CA = TBM * 8 / NT, CB = TBN * 8 / NT;   // 16-byte chunks staged per thread per K-step
+    extern __shared__ __attribute__((aligned(16))) char smem[];            // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nt_n = a.N / BN;
-    const int nt_m = (a.M + BM - 1) / BM;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int nt_n = a.N / TBN;
+    const int nt_m = (a.M + TBM - 1) / TBM;
     const int wg = xcd_remap(blockIdx.x, nt_m * nt_n);
-    const int m0 = (wg / nt_n) * BM, n0 = (wg % nt_n) * BN;
+    const int m0 = (wg / nt_n) * TBM, n0 = (wg % nt_n) * TBN;
 
-    // per-thread source pointers of the 4+4 16-byte chunks it stages per K-step
-    const bf16_t* srcA[4];
-    const bf16_t* srcB[4];
+    const bf16_t* srcA[CA];
+    const bf16_t* srcB[CB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = i * 256 + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
-        const int ra = min(m0 + row, a.M - 1);
-        srcA[i] = a.A + (size_t)ra * a.lda + c * 8;
+    for (int i = 0; i < CA; ++i) {
+        const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
+        srcA[i] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
         srcB[i] = a.B + (size_t)(n0 + row) * a.ldb + c * 8;
     }
     auto stage = [&](int buf, int k0) {
-        char* sa = smem + buf * 2 * TILE_BYTES;
-        char* sb = sa + TILE_BYTES;
+        char* sa = smem + buf * BUF_BYTES;
+        char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + k0), (LDS_AS void*)(sa + off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + k0), (LDS_AS void*)(sb + off), 16, 0, 0);
-        }
+        for (int i = 0; i < CA; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + k0), (LDS_AS void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + k0), (LDS_AS void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][MI];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets: row = base + (lane&15), chunk = kk*4 + (lane>>4), swizzled with row&7 == lane&7
     const int fr = lane & 15, fq = lane >> 4;
@@ -85,40 +96,49 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs a) {
     for (int t = 0; t < nk; ++t) {
         __syncthreads();                                   // tile t landed (vmcnt(0)) and buffer (t+1)&1 is free
         if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
-        const char* sa = smem + (t & 1) * 2 * TILE_BYTES + wm * 64 * 128;
-        const char* sb = smem + (t & 1) * 2 * TILE_BYTES + TILE_BYTES + wn * 64 * 128;
+        const char* sa = smem + (t & 1) * BUF_BYTES + wm * (MI * 16) * 128;
+        const char* sb = smem + (t & 1) * BUF_BYTES + A_BYTES + wn * 64 * 128;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int off = kk ? off_k1 : off_k0;
-            bf16x8 wf[4], xf[4];
+            bf16x8 wf[4], xf[MI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + off);
-                xf[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + off);
-            }
+            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + off);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + off);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 
-    // epilogue straight from the accumulators: the weight tile was the MFMA A operand, so a lane holds 4
-    // consecutive output columns n of one row m -> 8/16-byte stores.
+    // Epilogue, staged through LDS (free once the main loop is done).  The accumulators hold 16-row x 4-column
+    // patches per lane; written as they stand, one store instruction would touch 16 rows x 32 B.  Each wave instead
+    // transposes one 16x64 fp32 sub-tile at a time through a private LDS patch (272-B row stride: conflict-free) and
+    // then owns (row = i*4 + lane/16, 4 consecutive columns = (lane%16)*4): every global access - residual read,
+    // GELU' operand read, output stores - is a full contiguous row segment (128 B bf16 / 256 B fp32 per row).
+    __syncthreads();
+    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    const int cc = (lane & 15) * 4, rq = lane >> 4;
+    const int n = n0 + wn * 64 + cc;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + n);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + fr;
-        if (m >= a.M) continue;
-        const long long rrow = a.res ? (a.res_idx ? (long long)a.res_idx[m] : (long long)m) : 0;
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
-            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
+        for (int ni = 0; ni < 4; ++ni)
+            *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = i * 4 + rq;
+            const float4 t = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
+            const int m = m0 + wm * (MI * 16) + mi * 16 + rr;
+            if (m >= a.M) continue;
+            float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
             if (ACT == 2) {
                 const uint2 p = *reinterpret_cast<const uint2*>(a.aux + (size_t)m * a.ldaux + n);
                 v[0] *= gelu_erf_grad(__uint_as_float(p.x << 16));
@@ -127,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs a) {
                 v[3] *= gelu_erf_grad(__uint_as_float(p.y & 0xffff0000u));
             }
             if (a.res) {
+                const long long rrow = a.res_idx ? (long long)a.res_idx[m] : (long long)m;
                 const float4 r = *reinterpret_cast<const float4*>(a.res + rrow * a.ldr + n);
                 v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
             }
@@ -165,47 +186,59 @@ struct GemmTnArgs {
     int stages_per_split;
 };
 
+template <int ROWB>
 __device__ __forceinline__ bf16x8 lds_tr_frag(const char* base) {
     // rows r..r+3 then r+4..r+7 of the same 16 columns -> 8 consecutive k of one column per lane
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(base));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(base + 4 * 256));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(base + 4 * ROWB));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+// <NWC=2, MI=2>: 128x128 output tile, 256 threads, 64 KiB LDS;  <NWC=4, MI=4>: 256x256 tile, 512 threads, 128 KiB LDS.
+template <int NWC, int MI>
+__global__ __launch_bounds__(128 * NWC) void gemm_tn_kernel(GemmTnArgs a) {
+    constexpr int NT = 128 * NWC;
+    constexpr int T1 = 2 * MI * 32, T2 = NWC * 64;          // output tile: T1 (columns of A) x T2 (columns of B)
+    constexpr int RA = T1 * 2, RB = T2 * 2;                 // LDS row bytes of the staged [64 rows][T] tiles
+    constexpr int A_BYTES = 64 * RA, B_BYTES = 64 * RB, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int CA = 64 * (T1 / 8) / NT, CB = 64 * (T2 / 8) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int n2_0 = blockIdx.x * 128, n1_0 = blockIdx.y * 128;
+    const int wr = wave / NWC, wc = wave % NWC;
+    const int n2_0 = blockIdx.x * T2, n1_0 = blockIdx.y * T1;
     const int nstages = (a.M + BK - 1) / BK;
     const int s_begin = blockIdx.z * a.stages_per_split;
     const int s_end = min(nstages, s_begin + a.stages_per_split);
     if (s_begin >= s_end) return;
 
-    const bf16_t* srcA[4];
-    const bf16_t* srcB[4];
+    const bf16_t* srcA[CA];
+    const bf16_t* srcB[CB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = i * 256 + tid, row = p >> 4, c = (p & 15) ^ ((row & 3) << 2);
+    for (int i = 0; i < CA; ++i) {
+        const int p = i * NT + tid, row = p / (T1 / 8), c = (p % (T1 / 8)) ^ ((row & 3) << 2);
         srcA[i] = a.A + (size_t)row * a.lda + n1_0 + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int p = i * NT + tid, row = p / (T2 / 8), c = (p % (T2 / 8)) ^ ((row & 3) << 2);
         srcB[i] = a.B + (size_t)row * a.ldb + n2_0 + c * 8;
     }
     auto stage = [&](int buf, int s) {
-        char* sa = smem + buf * 2 * TILE_BYTES;
-        char* sb = sa + TILE_BYTES;
+        char* sa = smem + buf * BUF_BYTES;
+        char* sb = sa + A_BYTES;
         const size_t ra = (size_t)s * BK * a.lda, rb = (size_t)s * BK * a.ldb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + ra), (LDS_AS void*)(sa + off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + rb), (LDS_AS void*)(sb + off), 16, 0, 0);
-        }
+        for (int i = 0; i < CA; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + ra), (LDS_AS void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + rb), (LDS_AS void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -217,10 +250,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs a) {
     const int h = lane >> 5, cb = (lane >> 4) & 1, li = lane & 15, q = li >> 2, p4 = li & 3;
     const int trow = 8 * h + q;
     const int tcol = 16 * cb + 4 * p4;                      // + column block base (multiple of 32)
-    auto tr_off = [&](int colbase, int ks) {
+    auto tr_off = [&](int colbase, int ks, int rowb) {
         const int col = colbase + tcol;
         const int chunk = (col >> 3) ^ (q << 2);            // row&3 == q for every row this lane addresses
-        return (ks * 16 + trow) * 256 + (chunk << 4) + (col & 7) * 2;
+        return (ks * 16 + trow) * rowb + (chunk << 4) + (col & 7) * 2;
     };
 
     stage(0, s_begin);
@@ -228,38 +261,47 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTnArgs a) {
         const int t = s - s_begin;
         __syncthreads();
         if (s + 1 < s_end) stage((t + 1) & 1, s + 1);
-        const char* sa = smem + (t & 1) * 2 * TILE_BYTES;
-        const char* sb = sa + TILE_BYTES;
+        const char* sa = smem + (t & 1) * BUF_BYTES;
+        const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[MI], bfr[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = lds_tr_frag(sa + tr_off(wr * 64 + i * 32, ks));
-                bfr[i] = lds_tr_frag(sb + tr_off(wc * 64 + i * 32, ks));
-            }
+            for (int i = 0; i < MI; ++i) af[i] = lds_tr_frag<RA>(sa + tr_off(wr * (MI * 32) + i * 32, ks, RA));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) bfr[i] = lds_tr_frag<RB>(sb + tr_off(wc * 64 + i * 32, ks, RB));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n2 = n2_0 + wc * 64 + j * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n1 = n1_0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int n1 = n1_0 + wr * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 atomicAdd(a.C + (size_t)n1 * a.ldc + n2, acc[i][j][r]);
             }
         }
 }
 
 // ===================================================================================================
+static int g_force_tile = -1;          // -1: read AVSIAM_GEMM_TILE once; 0 auto; 128 / 256 force a tile (tuning + tests)
+
+extern "C" int avs_gemm_set_tile(int tile) {
+    AVS_CHECK_ARG(tile == 0 || tile == 128 || tile == 256, "gemm_set_tile: tile must be 0 (auto), 128 or 256");
+    g_force_tile = tile;
+    return 0;
+}
+
 extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
                                 const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
                                 long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
@@ -269,10 +311,36 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % 4) == 0, "gemm_nt: leading dimensions must keep 16-byte alignment");
     AVS_CHECK_ARG(act >= 0 && act <= 2 && (act != 1 || out2) && (act != 2 || aux), "gemm_nt: bad activation arguments");
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act};
-    const int nwg = ceil_div(M, BM) * (N / BN);
-    if (act == 0) gemm_nt_kernel<0><<<nwg, 256, 0, stream>>>(a);
-    else if (act == 1) gemm_nt_kernel<1><<<nwg, 256, 0, stream>>>(a);
-    else gemm_nt_kernel<2><<<nwg, 256, 0, stream>>>(a);
+    // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
+    if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
+    const int force = g_force_tile;
+    const int big_tiles = ceil_div(M, 256) * (N / 256);
+    const bool big = force == 256 ? (N % 256) == 0 : force == 128 ? false : ((N % 256) == 0 && big_tiles >= 224);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipSuccess;
+        const void* big_k[3] = {(const void*)gemm_nt_kernel<0, 4, 8>, (const void*)gemm_nt_kernel<1, 4, 8>, (const void*)gemm_nt_kernel<2, 4, 8>};
+        const void* small_k[3] = {(const void*)gemm_nt_kernel<0, 2, 4>, (const void*)gemm_nt_kernel<1, 2, 4>, (const void*)gemm_nt_kernel<2, 2, 4>};
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) {
+            e = hipFuncSetAttribute(big_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            if (e == hipSuccess) e = hipFuncSetAttribute(small_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        }
+        if (e != hipSuccess) {
+            avs_set_error("gemm_nt: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return -1;
+        }
+        attr_done = true;
+    }
+    if (big) {
+        if (act == 0) gemm_nt_kernel<0, 4, 8><<<big_tiles, 512, 131072, stream>>>(a);
+        else if (act == 1) gemm_nt_kernel<1, 4, 8><<<big_tiles, 512, 131072, stream>>>(a);
+        else gemm_nt_kernel<2, 4, 8><<<big_tiles, 512, 131072, stream>>>(a);
+    } else {
+        const int nwg = ceil_div(M, BM) * (N / BN);
+        if (act == 0) gemm_nt_kernel<0, 2, 4><<<nwg, 256, 65536, stream>>>(a);
+        else if (act == 1) gemm_nt_kernel<1, 2, 4><<<nwg, 256, 65536, stream>>>(a);
+        else gemm_nt_kernel<2, 2, 4><<<nwg, 256, 65536, stream>>>(a);
+    }
     AVS_LAUNCH_CHECK("gemm_nt");
     return 0;
 }
@@ -281,16 +349,30 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
                                 int M, int N1, int N2, int splits, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && (N1 % 128) == 0 && (N2 % 128) == 0, "gemm_tn: need N1%%128==0 and N2%%128==0 (N1=%d N2=%d)", N1, N2);
     AVS_CHECK_ARG(A && B && C && (lda % 8) == 0 && (ldb % 8) == 0, "gemm_tn: bad operands");
-    const int nstages = ceil_div(M, BK);
-    if (splits <= 0) {                                      // fill >= ~2 waves of workgroups over 256 CUs
-        const int tiles = (N1 / 128) * (N2 / 128);
-        splits = ceil_div(512, tiles);
+    if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) {
+            avs_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return -1;
+        }
+        attr_done = true;
     }
+    const int nstages = ceil_div(M, BK);
+    const bool can_big = (N1 % 256) == 0 && (N2 % 256) == 0;
+    // 256^2 tiles need a long contraction to amortise their 256 KiB atomic epilogue per split
+    const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256);
+    const int T = big ? 256 : 128;
+    const int tiles = (N1 / T) * (N2 / T);
+    if (splits <= 0) splits = ceil_div(big ? 256 : 512, tiles);      // ~1 (256^2) / ~2 (128^2) workgroups per CU
     if (splits > nstages) splits = nstages;
     const int per = ceil_div(nstages, splits);
     splits = ceil_div(nstages, per);
     GemmTnArgs a{A, lda, B, ldb, C, ldc, M, N1, N2, per};
-    gemm_tn_kernel<<<dim3(N2 / 128, N1 / 128, splits), 256, 0, stream>>>(a);
+    if (big) gemm_tn_kernel<4, 4><<<dim3(N2 / 256, N1 / 256, splits), 512, 131072, stream>>>(a);
+    else gemm_tn_kernel<2, 2><<<dim3(N2 / 128, N1 / 128, splits), 256, 65536, stream>>>(a);
     AVS_LAUNCH_CHECK("gemm_tn");
     return 0;
 }

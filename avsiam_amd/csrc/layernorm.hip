@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // (plain stores, deterministic); ln_bwd_reduce_kernel sums the slabs into the gradient arena.
 constexpr int LN_ROWS_PER_WAVE = 16;
 constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
+constexpr int LN_SETS = 5;                   // dgamma0, dbeta0, dgamma1, dbeta1, column-sum of dx
+constexpr int LN_REDUCE_CHUNKS = 64;
 
 template <int NV, bool F32IO>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
@@ -78,10 +80,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     __shared__ float red[4][D];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float4 dg0[NV], db0[NV], dg1[NV], db1[NV];
+    float4 dg0[NV], db0[NV], dg1[NV], db1[NV], dc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        dg0[i] = make_float4(0, 0, 0, 0); db0[i] = dg0[i]; dg1[i] = dg0[i]; db1[i] = dg0[i];
+        dg0[i] = make_float4(0, 0, 0, 0); db0[i] = dg0[i]; dg1[i] = dg0[i]; db1[i] = dg0[i]; dc[i] = dg0[i];
     }
     const int row0 = blockIdx.x * LN_ROWS_PER_BLOCK + wave * LN_ROWS_PER_WAVE;
     for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             dxr[i * 64 + lane] = o;
+            dc[i].x += o.x; dc[i].y += o.y; dc[i].z += o.z; dc[i].w += o.w;      // column sum of dx (bias grad of the producer Linear)
             if (dx_bf16) {
                 uint2 ob;
                 ob.x = pack_bf2(o.x, o.y);
@@ -141,14 +144,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             }
         }
     }
-    // cross-wave reduction of the four accumulator sets, one set at a time through LDS
-    float* slab = ws + (size_t)blockIdx.x * 4 * D;
+    // cross-wave reduction of the five accumulator sets, one set at a time through LDS
+    float* slab = ws + (size_t)blockIdx.x * LN_SETS * D;
 #pragma unroll
-    for (int set = 0; set < 4; ++set) {
+    for (int set = 0; set < LN_SETS; ++set) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const float4 a = set == 0 ? dg0[i] : set == 1 ? db0[i] : set == 2 ? dg1[i] : db1[i];
+            const float4 a = set == 0 ? dg0[i] : set == 1 ? db0[i] : set == 2 ? dg1[i] : set == 3 ? db1[i] : dc[i];
             reinterpret_cast<float4*>(red[wave])[i * 64 + lane] = a;
         }
         __syncthreads();
@@ -156,19 +159,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
+// Sum the per-block slabs: grid (D/256, set, chunk); each chunk of blocks is summed in registers and added with one
+// atomic per column (LN_REDUCE_CHUNKS adders per address).
 __global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, int D, float* dg0, float* db0,
-                                     float* dg1, float* db1) {
+                                     float* dg1, float* db1, float* dcol) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int set = blockIdx.y;
     if (c >= D) return;
-    float* dst = set == 0 ? dg0 : set == 1 ? db0 : set == 2 ? dg1 : db1;
+    float* dst = set == 0 ? dg0 : set == 1 ? db0 : set == 2 ? dg1 : set == 3 ? db1 : dcol;
     if (!dst) return;
+    const int per = (nblocks + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
+    if (b0 >= b1) return;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += ws[((size_t)b * 4 + set) * D + c];
-    dst[c] += s;
+    for (int b = b0; b < b1; ++b) s += ws[((size_t)b * LN_SETS + set) * D + c];
+    atomicAdd(dst + c, s);
 }
 
-extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, LN_ROWS_PER_BLOCK) * 4 * D; }
+extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, LN_ROWS_PER_BLOCK) * LN_SETS * D; }
 
 extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
                                  const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
@@ -188,12 +196,13 @@ extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b
     return 0;
 }
 
-// dg*/db* are ACCUMULATED into (+=); dx may alias dres; dx_bf16 (optional) receives a bf16 copy of dx.
+// dg*/db* are ACCUMULATED into (+=); dx may alias dres; dx_bf16 (optional) receives a bf16 copy of dx; dcol (optional)
+// accumulates the column sum of dx (the bias gradient of the Linear whose output gradient dx is).
 // ws: avs_layernorm_ws_floats(rows, D) floats.
 extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd,
                                  const float* g0, const float* g1, const uint8_t* row_mod, const int* out_map,
                                  const float* dres, float* dx, bf16_t* dx_bf16, float* dg0, float* db0, float* dg1,
-                                 float* db1, float* ws, int rows, int D, hipStream_t stream) {
+                                 float* db1, float* dcol, float* ws, int rows, int D, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(dy && x && mean && rstd && g0 && dx && ws, "layernorm_bwd: null pointer");
     const int nblocks = ceil_div(rows, LN_ROWS_PER_BLOCK);
@@ -206,7 +215,8 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
     }
 #undef LN_BWD
     AVS_LAUNCH_CHECK("layernorm_bwd");
-    ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), 4), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1);
+    const int chunks = nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;
+    ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), LN_SETS, chunks), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1, dcol);
     AVS_LAUNCH_CHECK("layernorm_bwd_reduce");
     return 0;
 }

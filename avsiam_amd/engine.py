@@ -72,11 +72,12 @@ def _ln_fwd(x, norms, y, mean, rstd, rows, eps, row_mod=None, out_map=None):
                       row_mod if n1 else None, out_map)
 
 
-def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None):
+def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None, dcol=None):
+    """dcol: bias gradient of the Linear whose output gradient is the dx produced here (column sum fused in-kernel)."""
     n0 = norms[0]
     n1 = norms[1] if len(norms) > 1 else None
     ops.layernorm_bwd(dy, x, mean, rstd, n0.g, dx, n0.dg, n0.db, ws, rows, n1.g if n1 else None, n1.dg if n1 else None,
-                      n1.db if n1 else None, row_mod if n1 else None, out_map, dres, dx_bf16)
+                      n1.db if n1 else None, row_mod if n1 else None, out_map, dres, dx_bf16, dcol)
 
 
 class Stack:
@@ -125,8 +126,11 @@ class Stack:
             ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1)
             ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i])
 
-    def backward(self, blocks):
-        """In: d(out) in self.dx[0] (fp32) and self.dxb[0] (bf16).  Out: d(x[0]) in the same two buffers."""
+    def backward(self, blocks, last_fc2_bias_done=False):
+        """In: d(out) in self.dx[0] (fp32) and self.dxb[0] (bf16).  Out: d(x[0]) in the same two buffers.
+        Bias gradients of fc2 / proj are column sums of the residual-stream gradient and come out of the LayerNorm
+        backward that produces it (`dcol`); `last_fc2_bias_done` says the caller's LN backward already did that for
+        the last block."""
         M = self.rows
         dxo, dxm = self.dx
         dbo, dbm = self.dxb
@@ -135,22 +139,24 @@ class Stack:
             # fc2: d(gelu out) fused with GELU' -> d(fc1 pre-activation)
             ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2)
             ops.gemm_tn(dbo, self.act[i], bp.fc2.gw, M)
-            ops.colsum(dbo, bp.fc2.gb, M)
+            if i == self.nblocks - 1 and not last_fc2_bias_done:
+                ops.colsum(dbo, bp.fc2.gb, M)
             # fc1
             ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M)
             ops.gemm_tn(self.dfc1, self.ln2[i], bp.fc1.gw, M)
             ops.colsum(self.dfc1, bp.fc1.gb, M)
-            _ln_bwd(self.dln, self.xmid[i], st[2], st[3], bp.n2, dxm, self.lnws, M, self.row_mod, dres=dxo, dx_bf16=dbm)
+            _ln_bwd(self.dln, self.xmid[i], st[2], st[3], bp.n2, dxm, self.lnws, M, self.row_mod, dres=dxo, dx_bf16=dbm,
+                    dcol=bp.proj.gb)
             # proj
             ops.gemm_nt(dbm, bp.proj.wt, self.datt, M)
             ops.gemm_tn(dbm, self.att[i], bp.proj.gw, M)
-            ops.colsum(dbm, bp.proj.gb, M)
             ops.attn_bwd(self.qkv[i], self.tiles, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
             # qkv
             ops.gemm_nt(self.dqkv, bp.qkv.wt, self.dln, M)
             ops.gemm_tn(self.dqkv, self.ln1[i], bp.qkv.gw, M)
             ops.colsum(self.dqkv, bp.qkv.gb, M)
-            _ln_bwd(self.dln, self.x[i], st[0], st[1], bp.n1, dxo, self.lnws, M, self.row_mod, dres=dxm, dx_bf16=dbo)
+            _ln_bwd(self.dln, self.x[i], st[0], st[1], bp.n1, dxo, self.lnws, M, self.row_mod, dres=dxm, dx_bf16=dbo,
+                    dcol=blocks[i - 1].fc2.gb if i > 0 else None)
 
 
 class PatchEmbedder:
@@ -324,8 +330,8 @@ class ContrastivePass:
         torch.index_select(self.dreps, 0, self.slot_to_row, out=self.dreps_slot)
         ops.segment_mean_bwd(self.dreps_slot, self.seg_start, self.yf, 2 * B, float(W))
         _ln_bwd(self.yf, st.out, self.fstat[0], self.fstat[1], self.final, st.dx[0], st.lnws, self.rows, st.row_mod,
-                dx_bf16=st.dxb[0])
-        st.backward(self.blocks)
+                dx_bf16=st.dxb[0], dcol=self.blocks[-1].fc2.gb)
+        st.backward(self.blocks, last_fc2_bias_done=True)
         self.emb_a.backward(st.dx[0][:self.rows_a])
         self.emb_v.backward(st.dx[0][self.rows_a:])
 
@@ -464,8 +470,8 @@ class MaePass:
         sd = self.st_dec
         rows_d = B * self.Ltot
         _ln_bwd(self.ddn, sd.out, self.dn_stat[0], self.dn_stat[1], self.dec_norm, sd.dx[0], sd.lnws, rows_d,
-                out_map=self.dn_map, dx_bf16=sd.dxb[0])
-        sd.backward(self.blk_dec)
+                out_map=self.dn_map, dx_bf16=sd.dxb[0], dcol=self.blk_dec[-1].fc2.gb)
+        sd.backward(self.blk_dec, last_fc2_bias_done=True)
         g = self.gtok
         ops.unshuffle_bwd(sd.dx[0], self.src_row, B, T, La, Lv, self.dde, g["decoder_pos_embed_a"], g["decoder_pos_embed_v"],
                           g["mask_token"], g["decoder_modality_a"], g["decoder_modality_v"])
@@ -479,6 +485,7 @@ class MaePass:
         sm.backward(self.blk_mm)
         for st, fin, fstat, omap, rows, emb, blks in ((self.st_a, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.emb_a, self.blk_a),
                                                       (self.st_v, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.emb_v, self.blk_v)):
-            _ln_bwd(sm.dx[0], st.out, fstat[0], fstat[1], fin, st.dx[0], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0])
-            st.backward(blks)
+            _ln_bwd(sm.dx[0], st.out, fstat[0], fstat[1], fin, st.dx[0], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0],
+                    dcol=blks[-1].fc2.gb)
+            st.backward(blks, last_fc2_bias_done=True)
             emb.backward(st.dx[0])

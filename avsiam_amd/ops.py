@@ -87,10 +87,11 @@ def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod
 
 
 def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=None, db1=None, row_mod=None,
-                  out_map=None, dres=None, dx_bf16=None):
+                  out_map=None, dres=None, dx_bf16=None, dcol=None):
     D = x.shape[1]
     _chk(dy, dy.dtype if dy.dtype in (BF16, F32) else BF16, "lnb.dy", 2); _chk(x, F32, "lnb.x", 2); _chk(dx, F32, "lnb.dx", 2)
-    _chk(dres, F32, "lnb.dres", 2); _chk(dx_bf16, BF16, "lnb.dx_bf16", 2)
+    _chk(dres, F32, "lnb.dres", 2); _chk(dx_bf16, BF16, "lnb.dx_bf16", 2); _chk(dcol, F32, "lnb.dcol")
+    assert dcol is None or dcol.numel() == D
     if dx_bf16 is not None:
         assert dx_bf16.shape[0] >= rows and dx_bf16.shape[1] == D
     _chk(ws, F32, "lnb.ws"); _chk(row_mod, U8, "lnb.row_mod"); _chk(out_map, I32, "lnb.out_map")
@@ -104,7 +105,7 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
         assert dres.shape[0] >= rows and dres.shape[1] == D
     _launch("layernorm_bwd", float(rows) * D * (dy.element_size() + 4 + 4 + (4 if dres is not None else 0) + (2 if dx_bf16 is not None else 0)),
             "avs_layernorm_bwd", dy, 1 if dy.dtype == F32 else 0, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16,
-              dg0, db0, dg1, db1, ws, rows, D, _stream())
+            dg0, db0, dg1, db1, dcol, ws, rows, D, _stream())
 
 
 # ---------------------------------------------------------------------------------------------------

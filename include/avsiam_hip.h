@@ -35,11 +35,12 @@ int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const fl
                       const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd, int rows,
                       int D, float eps, avs_stream_t stream);
 /* dx = dres + LN'(dy) (dres may be NULL; dx may alias dres); dy is bf16, or fp32 when dy_f32; dx_bf16 (may be NULL) gets a
- * bf16 copy of dx; dg/db are accumulated (+=); ws: avs_layernorm_ws_floats */
+ * bf16 copy of dx; dg/db are accumulated (+=); dcol (may be NULL) accumulates the column sum of dx, i.e. the bias gradient
+ * of the Linear that produced this residual branch; ws: avs_layernorm_ws_floats */
 int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* g0,
                       const float* g1, const uint8_t* row_mod, const int* out_map, const float* dres, float* dx,
-                      avs_bf16* dx_bf16, float* dg0, float* db0, float* dg1, float* db1, float* ws, int rows, int D,
-                      avs_stream_t stream);
+                      avs_bf16* dx_bf16, float* dg0, float* db0, float* dg1, float* db1, float* dcol, float* ws, int rows,
+                      int D, avs_stream_t stream);
 
 /* ---- bf16 MFMA GEMMs (nn.Linear / PatchEmbed.proj and their backward: cav_mae_base.py:51,55,60,77,96-99,138-143,
  * 600,634-635).  nt: out = alpha*(A[M,K].B[N,K]^T + bias [*gelu'(aux)] + res[res_idx? res_idx[m] : m]); act 0 none,
@@ -48,6 +49,8 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
                      const float* bias, const float* res, long long ldr, const int* res_idx, const avs_bf16* aux,
                      long long ldaux, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
                      int act, avs_stream_t stream);
+/* tile selection of the nt kernel: 0 = automatic (256x256 when that alone fills the chip, else 128x128), 128, 256 */
+int avs_gemm_set_tile(int tile);
 /* tn (weight gradient): C[N1,N2] += A[M,N1]^T . B[M,N2], fp32 atomics; A and B must be allocated and ZERO up to the
  * next multiple of 64 rows; N1%128==0, N2%128==0; splits<=0 picks a split of the contraction that fills the chip. */
 int avs_gemm_tn_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, float* C, long long ldc, int M,

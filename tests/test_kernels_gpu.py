@@ -79,9 +79,11 @@ def test_layernorm(D, rows):
     dx2 = torch.empty(rows, D, device=DEV)
     dxb = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
     o.layernorm_fwd(x, g[0], b[0], yf, mean, rstd, rows, 1e-5, g[1], b[1], mod, perm)
-    o.layernorm_bwd(dyf, x, mean, rstd, g[0], dx2, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres, dxb)
+    dcol = torch.ones(D, device=DEV)
+    o.layernorm_bwd(dyf, x, mean, rstd, g[0], dx2, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres, dxb, dcol)
     assert rel_err(dx2, dx) < 1e-6
     assert torch.equal(dxb, bf(dx2))
+    assert rel_err(dcol, 1 + dx2.double().sum(0)) < 1e-5           # fused column sum (bias gradient), accumulated
 
 
 @pytest.mark.parametrize("M,N,K", [(333, 256, 768), (1000, 768, 3072), (4099, 2304, 768), (128, 512, 256)])
