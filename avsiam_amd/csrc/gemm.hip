@@ -27,6 +27,7 @@ struct GemmNtArgs {
     const bf16_t* aux; long long ldaux;
     void* out; long long ldo; int out_f32;
     bf16_t* out2; long long ldo2;
+    int debug;                               // tuning aid (AVSIAM_GEMM_DEBUG): bit0 = skip the epilogue's global stores (timing only)
     float alpha; int act;                    // 0 none | 1 gelu (out = pre-activation, out2 = gelu) | 2 gelu-backward (aux = pre-activation)
 };
 
@@ -35,6 +36,140 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // neighbouring tiles (same A panel) hit the same L2.  Bijective for any nwg.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Epilogue, staged through LDS (free once the main loop is done).  The accumulators hold 16-row x 4-column patches
+// per lane; written as they stand, one store instruction would touch 16 rows x 32 B, and the per-CU store path is
+// ISSUE-bound (a measured ~10 B/clk/CU with 8-byte stores made the epilogue cost 20-50 % of these GEMMs).  Each wave
+// therefore transposes one 16x64 fp32 sub-tile at a time through a private LDS patch (272-B row stride: conflict-free)
+// and re-reads it so that every lane owns 16 BYTES of one output row:
+//   fp32 output: row = i*4 + lane/16, 4 columns (lane%16)*4        -> dwordx4 stores, 256-B row segments
+//   bf16 output: row = i*8 + lane/8,  8 columns (lane%8)*8         -> dwordx4 stores, 128-B row segments
+// Residual reads (fp32) and the GELU' operand read (bf16) use the same ownership, i.e. are 16 B per lane as well.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+template <typename T>
+__device__ __forceinline__ void st_out(T* p, T v, int nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+__device__ __forceinline__ void epi_apply4(const GemmNtArgs& a, int ACT, float (&v)[4], const float4& bias4, uint2 p,
+                                           const float* resp) {
+    v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
+    if (ACT == 2) {
+        v[0] *= gelu_erf_grad(__uint_as_float(p.x << 16));
+        v[1] *= gelu_erf_grad(__uint_as_float(p.x & 0xffff0000u));
+        v[2] *= gelu_erf_grad(__uint_as_float(p.y << 16));
+        v[3] *= gelu_erf_grad(__uint_as_float(p.y & 0xffff0000u));
+    }
+    if (resp) {
+        const float4 r = *reinterpret_cast<const float4*>(resp);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    v[0] *= a.alpha; v[1] *= a.alpha; v[2] *= a.alpha; v[3] *= a.alpha;
+}
+
+template <int ACT, int MI>
+__device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], char* smem, int wave, int lane, int mw0, int nw0) {
+    const int fr = lane & 15, fq = lane >> 4;
+    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    if (a.out_f32) {
+        const int cc = (lane & 15) * 4, rq = lane >> 4;
+        const int n = nw0 + cc;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + n);
+        // The residual rows are read into registers half a sub-tile ahead of their use (one latency per half instead of
+        // one per row: a load in the epilogue is synchronous, a store is not).
+        constexpr int HALF = 2;                              // sub-tile rows are pre-read 2 x 16 at a time (32 VGPRs)
+#pragma unroll
+        for (int hf = 0; hf < MI / HALF; ++hf) {
+            float4 rs[HALF][4];
+            if (a.res) {
+#pragma unroll
+                for (int mj = 0; mj < HALF; ++mj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = min(mw0 + (hf * HALF + mj) * 16 + i * 4 + rq, a.M - 1);
+                        const long long rrow = a.res_idx ? (long long)a.res_idx[m] : (long long)m;
+                        rs[mj][i] = *reinterpret_cast<const float4*>(a.res + rrow * a.ldr + n);
+                    }
+            }
+#pragma unroll
+            for (int mj = 0; mj < HALF; ++mj) {
+                const int mi = hf * HALF + mj;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = i * 4 + rq;
+                    const float4 t = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
+                    const int m = mw0 + mi * 16 + rr;
+                    if (m >= a.M || (a.debug & 1)) continue;
+                    float v[4] = {t.x, t.y, t.z, t.w};
+                    uint2 ax = make_uint2(0, 0);
+                    if (ACT == 2) ax = *reinterpret_cast<const uint2*>(a.aux + (size_t)m * a.ldaux + n);
+                    epi_apply4(a, ACT, v, bias4, ax, a.res ? &rs[mj][i].x : nullptr);
+                    st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n), f32x4{v[0], v[1], v[2], v[3]}, a.debug & 2);
+                    if (ACT == 1) {
+                        uint2 o;
+                        o.x = pack_bf2(gelu_erf(v[0]), gelu_erf(v[1]));
+                        o.y = pack_bf2(gelu_erf(v[2]), gelu_erf(v[3]));
+                        *reinterpret_cast<uint2*>(a.out2 + (size_t)m * a.ldo2 + n) = o;
+                    }
+                }
+            }
+        }
+    } else {
+        const int cc = (lane & 7) * 8, rq = lane >> 3;
+        const int n = nw0 + cc;
+        float4 bias_lo = make_float4(0.f, 0.f, 0.f, 0.f), bias_hi = bias_lo;
+        if (a.bias) {
+            bias_lo = *reinterpret_cast<const float4*>(a.bias + n);
+            bias_hi = *reinterpret_cast<const float4*>(a.bias + n + 4);
+        }
+        constexpr int GRP = 4;                               // GELU' operands are pre-read 4 x 16 rows at a time (32 VGPRs)
+        uint4 axs[GRP][2];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (ACT == 2 && (mi % GRP) == 0) {
+#pragma unroll
+                for (int mj = 0; mj < GRP; ++mj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int m = min(mw0 + (mi + mj) * 16 + i * 8 + rq, a.M - 1);
+                        axs[mj][i] = *reinterpret_cast<const uint4*>(a.aux + (size_t)m * a.ldaux + n);
+                    }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rr = i * 8 + rq;
+                const float4 t0 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
+                const float4 t1 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc + 4);
+                const int m = mw0 + mi * 16 + rr;
+                if (m >= a.M || (a.debug & 1)) continue;
+                float v0[4] = {t0.x, t0.y, t0.z, t0.w}, v1[4] = {t1.x, t1.y, t1.z, t1.w};
+                const long long rrow = a.res ? (a.res_idx ? (long long)a.res_idx[m] : (long long)m) : 0;
+                uint4 ax = make_uint4(0, 0, 0, 0);
+                if (ACT == 2) ax = axs[mi % GRP][i];
+                const float* resp = a.res ? a.res + rrow * a.ldr + n : nullptr;
+                epi_apply4(a, ACT, v0, bias_lo, make_uint2(ax.x, ax.y), resp);
+                epi_apply4(a, ACT, v1, bias_hi, make_uint2(ax.z, ax.w), resp ? resp + 4 : nullptr);
+                uint4 o;
+                o.x = pack_bf2(v0[0], v0[1]); o.y = pack_bf2(v0[2], v0[3]);
+                o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
+                st_out(reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n), u32x4{o.x, o.y, o.z, o.w}, a.debug & 2);
+                if (ACT == 1) {
+                    uint4 g;
+                    g.x = pack_bf2(gelu_erf(v0[0]), gelu_erf(v0[1])); g.y = pack_bf2(gelu_erf(v0[2]), gelu_erf(v0[3]));
+                    g.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); g.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
+                    st_out(reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n), u32x4{g.x, g.y, g.z, g.w}, a.debug & 2);
+                }
+            }
+        }
+    }
 }
 
 // Tile configurations (NWM = 2 waves along M, NWN waves along N; each wave MI x 4 MFMA tiles of 16x16):
@@ -54,21 +189,35 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
     const int wm = wave / NWN, wn = wave % NWN;
     const int nt_n = a.N / TBN;
     const int nt_m = (a.M + TBM - 1) / TBM;
-    const int wg = xcd_remap(blockIdx.x, nt_m * nt_n);
-    const int m0 = (wg / nt_n) * TBM, n0 = (wg % nt_n) * TBN;
+    const int ntiles = nt_m * nt_n;
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment read offsets: row = base + (lane&15), chunk = kk*4 + (lane>>4), swizzled with row&7 == lane&7
+    const int off_k0 = fr * 128 + (((0 + fq) ^ (lane & 7)) << 4);
+    const int off_k1 = fr * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    const int nk = a.K / BK;
 
+    // Workgroups are persistent: block b walks tiles b, b + grid, ... (grid is a multiple of 8 or covers every tile, so a
+    // block keeps its XCD class and xcd_remap keeps neighbouring tiles - same A panel - on one L2).  The first K-slab of
+    // the NEXT tile is put in flight before the epilogue of the current one, and the epilogue's stores drain under the
+    // next tile's main loop: with one 128-KiB workgroup per CU nothing else would hide those per-tile costs.
     const bf16_t* srcA[CA];
     const bf16_t* srcB[CB];
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int v) {
+        const int wg = xcd_remap(v, ntiles);
+        m0 = (wg / nt_n) * TBM;
+        n0 = (wg % nt_n) * TBN;
 #pragma unroll
-    for (int i = 0; i < CA; ++i) {
-        const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
-        srcA[i] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + c * 8;
-    }
+        for (int i = 0; i < CA; ++i) {
+            const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
+            srcA[i] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + c * 8;
+        }
 #pragma unroll
-    for (int i = 0; i < CB; ++i) {
-        const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
-        srcB[i] = a.B + (size_t)(n0 + row) * a.ldb + c * 8;
-    }
+        for (int i = 0; i < CB; ++i) {
+            const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
+            srcB[i] = a.B + (size_t)(n0 + row) * a.ldb + c * 8;
+        }
+    };
     auto stage = [&](int buf, int k0) {
         char* sa = smem + buf * BUF_BYTES;
         char* sb = sa + A_BYTES;
@@ -80,93 +229,47 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + k0), (LDS_AS void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
     };
 
-    f32x4 acc[4][MI];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment read offsets: row = base + (lane&15), chunk = kk*4 + (lane>>4), swizzled with row&7 == lane&7
-    const int fr = lane & 15, fq = lane >> 4;
-    const int off_k0 = fr * 128 + (((0 + fq) ^ (lane & 7)) << 4);
-    const int off_k1 = fr * 128 + (((4 + fq) ^ (lane & 7)) << 4);
-
-    const int nk = a.K / BK;
+    int v = blockIdx.x;
+    if (v >= ntiles) return;
+    set_tile(v);
     stage(0, 0);
-    for (int t = 0; t < nk; ++t) {
-        __syncthreads();                                   // tile t landed (vmcnt(0)) and buffer (t+1)&1 is free
-        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
-        const char* sa = smem + (t & 1) * BUF_BYTES + wm * (MI * 16) * 128;
-        const char* sb = smem + (t & 1) * BUF_BYTES + A_BYTES + wn * 64 * 128;
+    for (; v < ntiles; v += gridDim.x) {
+        f32x4 acc[4][MI];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int off = kk ? off_k1 : off_k0;
-            bf16x8 wf[4], xf[MI];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + off);
+            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nk; ++t) {
+            __syncthreads();                               // K-slab t landed (vmcnt(0)); buffer (t+1)&1 and the epilogue patches are free
+            if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+            const char* sa = smem + (t & 1) * BUF_BYTES + wm * (MI * 16) * 128;
+            const char* sb = smem + (t & 1) * BUF_BYTES + A_BYTES + wn * 64 * 128;
 #pragma unroll
-            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + off);
-            __builtin_amdgcn_s_setprio(1);
+            for (int kk = 0; kk < 2; ++kk) {
+                const int off = kk ? off_k1 : off_k0;
+                bf16x8 wf[4], xf[MI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + off);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-    }
-
-    // Epilogue, staged through LDS (free once the main loop is done).  The accumulators hold 16-row x 4-column
-    // patches per lane; written as they stand, one store instruction would touch 16 rows x 32 B.  Each wave instead
-    // transposes one 16x64 fp32 sub-tile at a time through a private LDS patch (272-B row stride: conflict-free) and
-    // then owns (row = i*4 + lane/16, 4 consecutive columns = (lane%16)*4): every global access - residual read,
-    // GELU' operand read, output stores - is a full contiguous row segment (128 B bf16 / 256 B fp32 per row).
-    __syncthreads();
-    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
-    const int cc = (lane & 15) * 4, rq = lane >> 4;
-    const int n = n0 + wn * 64 + cc;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + n);
+                for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + off);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rr = i * 4 + rq;
-            const float4 t = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
-            const int m = m0 + wm * (MI * 16) + mi * 16 + rr;
-            if (m >= a.M) continue;
-            float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
-            if (ACT == 2) {
-                const uint2 p = *reinterpret_cast<const uint2*>(a.aux + (size_t)m * a.ldaux + n);
-                v[0] *= gelu_erf_grad(__uint_as_float(p.x << 16));
-                v[1] *= gelu_erf_grad(__uint_as_float(p.x & 0xffff0000u));
-                v[2] *= gelu_erf_grad(__uint_as_float(p.y << 16));
-                v[3] *= gelu_erf_grad(__uint_as_float(p.y & 0xffff0000u));
-            }
-            if (a.res) {
-                const long long rrow = a.res_idx ? (long long)a.res_idx[m] : (long long)m;
-                const float4 r = *reinterpret_cast<const float4*>(a.res + rrow * a.ldr + n);
-                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-            }
-            v[0] *= a.alpha; v[1] *= a.alpha; v[2] *= a.alpha; v[3] *= a.alpha;
-            if (a.out_f32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                uint2 o;
-                o.x = pack_bf2(v[0], v[1]);
-                o.y = pack_bf2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = o;
-            }
-            if (ACT == 1) {
-                uint2 o;
-                o.x = pack_bf2(gelu_erf(v[0]), gelu_erf(v[1]));
-                o.y = pack_bf2(gelu_erf(v[2]), gelu_erf(v[3]));
-                *reinterpret_cast<uint2*>(a.out2 + (size_t)m * a.ldo2 + n) = o;
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
             }
         }
+        const int em = m0 + wm * (MI * 16), en = n0 + wn * 64;
+        __syncthreads();                                   // every wave is done reading the K-slab buffers
+        // the last K-slab sat in buffer (nk-1)&1; the epilogue patches go to the OTHER half... both halves are free now,
+        // so prefetch the next tile's first slab into buffer 0 and stage the epilogue through buffer 1.
+        if (v + (int)gridDim.x < ntiles) {
+            set_tile(v + gridDim.x);
+            stage(0, 0);
+        }
+        nt_epilogue<ACT, MI>(a, acc, smem + BUF_BYTES, wave, lane, em, en);
     }
 }
 
@@ -186,12 +289,34 @@ struct GemmTnArgs {
     int stages_per_split;
 };
 
+// The transposing reads are issued through inline asm: hipcc (ROCm 7.2) cannot disambiguate the ds_read_tr builtin from
+// the LDS-DMA loads still in flight for the NEXT slab and puts an s_waitcnt vmcnt(0) in front of the first read of every
+// stage - which serialises load and compute completely (measured: matrix pipe 21 % busy).  An asm statement is opaque to
+// that logic; its completion is waited for by hand (tr_wait) with a sched_barrier so no MFMA is hoisted above the wait.
+struct TrFrag { bf16x4 lo, hi; };
+
 template <int ROWB>
-__device__ __forceinline__ bf16x8 lds_tr_frag(const char* base) {
+__device__ __forceinline__ void lds_tr_issue(TrFrag& f, const char* base) {
     // rows r..r+3 then r+4..r+7 of the same 16 columns -> 8 consecutive k of one column per lane
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(base));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(base + 4 * ROWB));
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const unsigned addr = (unsigned)(size_t)(LDS_AS const char*)base;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
+                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr), "i"(4 * ROWB) : "memory");
+}
+
+__device__ __forceinline__ void tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KEEP>                                          // wait until at most KEEP of this wave's LDS reads are outstanding
+__device__ __forceinline__ void tr_wait_keep() {
+    static_assert(KEEP <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KEEP) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ bf16x8 tr_join(const TrFrag& f) {
+    return bf16x8{f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
 }
 
 // <NWC=2, MI=2>: 128x128 output tile, 256 threads, 64 KiB LDS;  <NWC=4, MI=4>: 256x256 tile, 512 threads, 128 KiB LDS.
@@ -206,9 +331,15 @@ __global__ __launch_bounds__(128 * NWC) void gemm_tn_kernel(GemmTnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / NWC, wc = wave % NWC;
-    const int n2_0 = blockIdx.x * T2, n1_0 = blockIdx.y * T1;
+    // 1-D grid, XCD-aware: logical ids are dealt so that each XCD gets a contiguous run = all output tiles of (about) one
+    // split of the contraction.  Those workgroups stream the SAME token rows of A and B at the same time, so each row
+    // slab is fetched from HBM once per XCD instead of once per tile (3-12x less HBM traffic on these shapes).
+    const int tiles2 = a.N2 / T2, tiles = (a.N1 / T1) * tiles2;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / tiles, tile = lid % tiles;
+    const int n2_0 = (tile % tiles2) * T2, n1_0 = (tile / tiles2) * T1;
     const int nstages = (a.M + BK - 1) / BK;
-    const int s_begin = blockIdx.z * a.stages_per_split;
+    const int s_begin = split * a.stages_per_split;
     const int s_end = min(nstages, s_begin + a.stages_per_split);
     if (s_begin >= s_end) return;
 
@@ -263,19 +394,29 @@ __global__ __launch_bounds__(128 * NWC) void gemm_tn_kernel(GemmTnArgs a) {
         if (s + 1 < s_end) stage((t + 1) & 1, s + 1);
         const char* sa = smem + (t & 1) * BUF_BYTES;
         const char* sb = sa + A_BYTES;
+        // fragments are double-buffered by hand: the reads of k16-step ks+1 are in flight while the MFMAs of step ks run
+        TrFrag af[2][MI], bfr[2][2];
+        auto issue = [&](int ks, TrFrag (&fa)[MI], TrFrag (&fb)[2]) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) lds_tr_issue<RA>(fa[i], sa + tr_off(wr * (MI * 32) + i * 32, ks, RA));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lds_tr_issue<RB>(fb[i], sb + tr_off(wc * 64 + i * 32, ks, RB));
+        };
+        issue(0, af[0], bfr[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[MI], bfr[2];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = lds_tr_frag<RA>(sa + tr_off(wr * (MI * 32) + i * 32, ks, RA));
-#pragma unroll
-            for (int i = 0; i < 2; ++i) bfr[i] = lds_tr_frag<RB>(sb + tr_off(wc * 64 + i * 32, ks, RB));
+            if (ks + 1 < 4) {
+                issue(ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+                tr_wait_keep<2 * (MI + 2)>();                  // the (MI+2) x 2 reads just issued may stay in flight
+            } else {
+                tr_wait_keep<0>();
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(af[ks & 1][i]), tr_join(bfr[ks & 1][j]), acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
     }
@@ -295,6 +436,12 @@ __global__ __launch_bounds__(128 * NWC) void gemm_tn_kernel(GemmTnArgs a) {
 
 // ===================================================================================================
 static int g_force_tile = -1;          // -1: read AVSIAM_GEMM_TILE once; 0 auto; 128 / 256 force a tile (tuning + tests)
+static int g_persistent = 1;           // 256^2 nt tiles: persistent workgroups (0: one workgroup per tile, for A/B tests)
+
+extern "C" int avs_gemm_set_persistent(int on) {
+    g_persistent = on ? 1 : 0;
+    return 0;
+}
 
 extern "C" int avs_gemm_set_tile(int tile) {
     AVS_CHECK_ARG(tile == 0 || tile == 128 || tile == 256, "gemm_set_tile: tile must be 0 (auto), 128 or 256");
@@ -308,9 +455,12 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
                                 float alpha, int act, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % BN) == 0 && (K % BK) == 0, "gemm_nt: need N%%128==0, K%%64==0 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out, "gemm_nt: null operand");
-    AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % 4) == 0, "gemm_nt: leading dimensions must keep 16-byte alignment");
+    AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (!out2 || (ldo2 % 8) == 0) && (!aux || (ldaux % 8) == 0),
+                  "gemm_nt: leading dimensions must keep 16-byte alignment");
     AVS_CHECK_ARG(act >= 0 && act <= 2 && (act != 1 || out2) && (act != 2 || aux), "gemm_nt: bad activation arguments");
-    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act};
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("AVSIAM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, dbg, alpha, act};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;
@@ -332,9 +482,16 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
         attr_done = true;
     }
     if (big) {
-        if (act == 0) gemm_nt_kernel<0, 4, 8><<<big_tiles, 512, 131072, stream>>>(a);
-        else if (act == 1) gemm_nt_kernel<1, 4, 8><<<big_tiles, 512, 131072, stream>>>(a);
-        else gemm_nt_kernel<2, 4, 8><<<big_tiles, 512, 131072, stream>>>(a);
+        // persistent: one 128-KiB-LDS workgroup per CU walks the tiles (grid = min(tiles, CUs))
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        }
+        const int grid = g_persistent ? (big_tiles < ncu ? big_tiles : ncu) : big_tiles;
+        if (act == 0) gemm_nt_kernel<0, 4, 8><<<grid, 512, 131072, stream>>>(a);
+        else if (act == 1) gemm_nt_kernel<1, 4, 8><<<grid, 512, 131072, stream>>>(a);
+        else gemm_nt_kernel<2, 4, 8><<<grid, 512, 131072, stream>>>(a);
     } else {
         const int nwg = ceil_div(M, BM) * (N / BN);
         if (act == 0) gemm_nt_kernel<0, 2, 4><<<nwg, 256, 65536, stream>>>(a);
@@ -363,7 +520,8 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     const int nstages = ceil_div(M, BK);
     const bool can_big = (N1 % 256) == 0 && (N2 % 256) == 0;
     // 256^2 tiles need a long contraction to amortise their 256 KiB atomic epilogue per split
-    const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256);
+    // ... and enough output tiles that the splits (each adds a full-tile atomic epilogue) stay few
+    const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256 && (N1 / 256) * (N2 / 256) >= 24);
     const int T = big ? 256 : 128;
     const int tiles = (N1 / T) * (N2 / T);
     if (splits <= 0) splits = ceil_div(big ? 256 : 512, tiles);      // ~1 (256^2) / ~2 (128^2) workgroups per CU
@@ -371,8 +529,8 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     const int per = ceil_div(nstages, splits);
     splits = ceil_div(nstages, per);
     GemmTnArgs a{A, lda, B, ldb, C, ldc, M, N1, N2, per};
-    if (big) gemm_tn_kernel<4, 4><<<dim3(N2 / 256, N1 / 256, splits), 512, 131072, stream>>>(a);
-    else gemm_tn_kernel<2, 2><<<dim3(N2 / 128, N1 / 128, splits), 256, 65536, stream>>>(a);
+    if (big) gemm_tn_kernel<4, 4><<<tiles * splits, 512, 131072, stream>>>(a);
+    else gemm_tn_kernel<2, 2><<<tiles * splits, 256, 65536, stream>>>(a);
     AVS_LAUNCH_CHECK("gemm_tn");
     return 0;
 }

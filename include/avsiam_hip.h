@@ -51,6 +51,8 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
                      int act, avs_stream_t stream);
 /* tile selection of the nt kernel: 0 = automatic (256x256 when that alone fills the chip, else 128x128), 128, 256 */
 int avs_gemm_set_tile(int tile);
+/* 1 (default): 256x256 nt tiles run as persistent workgroups (one per CU); 0: one workgroup per tile (A/B measurements) */
+int avs_gemm_set_persistent(int on);
 /* tn (weight gradient): C[N1,N2] += A[M,N1]^T . B[M,N2], fp32 atomics; A and B must be allocated and ZERO up to the
  * next multiple of 64 rows; N1%128==0, N2%128==0; splits<=0 picks a split of the contraction that fills the chip. */
 int avs_gemm_tn_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, float* C, long long ldc, int M,
