@@ -33,6 +33,8 @@ def parse_header(path=HEADER):
                 a = a.strip()
                 if "*" in a or a.startswith("avs_stream_t"):
                     kinds.append("ptr")
+                elif a.startswith("unsigned long long"):
+                    kinds.append("ull")
                 elif a.startswith("long long"):
                     kinds.append("ll")
                 elif a.startswith("float"):
@@ -45,7 +47,7 @@ def parse_header(path=HEADER):
     return protos
 
 
-_CT = {"ptr": ctypes.c_void_p, "int": ctypes.c_int, "ll": ctypes.c_longlong, "float": ctypes.c_float}
+_CT = {"ptr": ctypes.c_void_p, "int": ctypes.c_int, "ll": ctypes.c_longlong, "ull": ctypes.c_ulonglong, "float": ctypes.c_float}
 
 
 def load():

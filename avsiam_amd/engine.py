@@ -163,7 +163,7 @@ class PatchEmbedder:
     """Kept-token patch embedding: im2col gather -> GEMM with fused (+bias +pos_embed[token]) * 2 epilogue
     (cav_mae_base.py:444-455: conv, +pos, then `x + norm_pre(x)` with norm_pre = Identity)."""
 
-    def __init__(self, arena, dev, rows, audio, cfg):
+    def __init__(self, arena, dev, rows, audio, cfg, row_src=None, row_tok=None):
         self.audio, self.rows, self.cfg = audio, rows, cfg
         pre = "vit_base.patch_embed_a" if audio else "vit_base.patch_embed"
         self.lin = Linear(arena, pre + ".proj.weight", pre + ".proj.bias", need_t=False)
@@ -175,13 +175,17 @@ class PatchEmbedder:
         rp = ops.pad_rows(rows, 128)
         self.cols = _z((rp, K), BF16, dev)
         self.dy = _z((rp, D), BF16, dev)
-        self.row_src = _z((rows,), I32, dev)     # sample (audio) / frame image (video) of each row
-        self.row_tok = _z((rows,), I32, dev)
+        # sample (audio) / frame image (video) and token id of each row; may be slices of a buffer the mask-plan kernel fills
+        self.row_src = row_src if row_src is not None else _z((rows,), I32, dev)
+        self.row_tok = row_tok if row_tok is not None else _z((rows,), I32, dev)
         self.row_pos = _z((rows,), I32, dev)     # row of the pos-embed table: tok (audio) / 1 + tok (video, skips cls)
 
     def set_rows(self, row_src, row_tok):
         self.row_src.copy_(row_src, non_blocking=True)
         self.row_tok.copy_(row_tok, non_blocking=True)
+        self.rows_updated()
+
+    def rows_updated(self):
         torch.add(self.row_tok, 0 if self.audio else 1, out=self.row_pos)
 
     def forward(self, inp, out):
@@ -229,8 +233,31 @@ class ContrastivePass:
         self.stack = Stack(dev, rows, D, cfg.num_heads, D * cfg.mlp_ratio, lens_a + lens_v, cfg.depth, row_mod)
         self.blocks = [BlockParams(arena, f"vit_base.blocks.{i}", "_a", "_v") for i in range(cfg.depth)]
         self.final = [Norm(arena, "vit_base.norm_a"), Norm(arena, "vit_base.norm")]
-        self.emb_a = PatchEmbedder(arena, dev, self.rows_a, True, cfg)
-        self.emb_v = PatchEmbedder(arena, dev, self.rows_v, False, cfg)
+        self.row_src_all, self.row_tok_all = _z((rows,), I32, dev), _z((rows,), I32, dev)
+        self.emb_a = PatchEmbedder(arena, dev, self.rows_a, True, cfg, self.row_src_all[:self.rows_a], self.row_tok_all[:self.rows_a])
+        self.emb_v = PatchEmbedder(arena, dev, self.rows_v, False, cfg, self.row_src_all[self.rows_a:], self.row_tok_all[self.rows_a:])
+        # device-side plan: sequence descriptors (static except src_id = the sample a slot holds this step)
+        La, Lv = cfg.audio_tokens, cfg.video_tokens
+        nseq = batch + batch * T
+        d = np.zeros((nseq, ops.PLAN_FIELDS), dtype=np.int32)
+        self.slot_group = np.array([g for g, n in enumerate(sizes) for _ in range(n)], dtype=np.int64)
+        off = 0
+        for sl in range(batch):
+            g = self.slot_group[sl]
+            d[sl] = [La, self.keep_a[g], off, 0, -1, 0, cfg.audio_t, sl * La, 0, 0, 0, 0]
+            off += self.keep_a[g]
+        for sl in range(batch):
+            g = self.slot_group[sl]
+            for t in range(T):
+                d[batch + sl * T + t] = [Lv, self.keep_v[g], off, 0, -1, 0, 0, batch * La + (sl * T + t) * Lv, 0, 0, 0, 0]
+                off += self.keep_v[g]
+        assert off == rows
+        self.desc_host = d
+        self.desc_dev = torch.from_numpy(d).to(dev)
+        self.bits_host = np.zeros((3, nseq), dtype=np.int32)           # tmask_lo, tmask_hi, fmask per sequence
+        self.bits_dev = torch.zeros((3, nseq), dtype=I32, device=dev)
+        self.ids_dev = _z((batch * La + batch * T * Lv,), I32, dev)
+        self.last_perm = None
         # pooling segments: B audio sequences then B video samples (T frames each), slot order = group-major
         seg = [0]
         for L in lens_a:
@@ -286,10 +313,62 @@ class ContrastivePass:
         s2r = torch.cat([torch.from_numpy(order_a), B + torch.from_numpy(order_v)])
         self.slot_to_row.copy_(s2r, non_blocking=True)
 
+    def draw_device(self, seed, nprng):
+        """Draw this step's plan on the device (ops.mask_plan): the host only picks the two batch permutations
+        (torch.chunk(randperm) at cav_mae_base.py:533-538) and the structured time/frequency selections (:415-422)."""
+        cfg, B, T = self.cfg, self.B, self.cfg.frames
+        t, f = cfg.audio_t, cfg.audio_f
+        perm_a, perm_v = nprng.permutation(B), nprng.permutation(B)
+        d = self.desc_host
+        d[:B, 3] = perm_a
+        d[B:, 3] = (perm_v[:, None] * T + np.arange(T)[None, :]).reshape(-1)
+        ratios = np.array([group_ratio(int(g)) for g in self.slot_group])
+        nt = np.array([int(t * r * 0.7) for r in ratios])
+        nf = np.array([int(f * r * 0.7) for r in ratios])
+        # random.sample(range(t), n): the n smallest of t random keys
+        rank_t = np.argsort(np.argsort(nprng.random((B, t)), axis=1), axis=1)
+        rank_f = np.argsort(np.argsort(nprng.random((B, f)), axis=1), axis=1)
+        tm = (rank_t < nt[:, None]).astype(np.uint64)
+        fm = (rank_f < nf[:, None]).astype(np.uint64)
+        tbits = (tm << np.arange(t, dtype=np.uint64)[None, :]).sum(axis=1)
+        fbits = (fm << np.arange(f, dtype=np.uint64)[None, :]).sum(axis=1)
+        self.bits_host[:] = 0
+        self.bits_host[0, :B] = (tbits & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)
+        self.bits_host[1, :B] = (tbits >> np.uint64(32)).astype(np.uint32).view(np.int32)
+        self.bits_host[2, :B] = fbits.astype(np.uint32).view(np.int32)
+        self.desc_dev.copy_(torch.from_numpy(d), non_blocking=True)
+        self.bits_dev.copy_(torch.from_numpy(self.bits_host), non_blocking=True)
+        ops.mask_plan(self.desc_dev, d, seed, self.row_src_all, self.row_tok_all, self.bits_dev[0], self.bits_dev[1], self.bits_dev[2],
+                      ids_out=self.ids_dev)
+        self.emb_a.rows_updated()
+        self.emb_v.rows_updated()
+        s2r = torch.from_numpy(np.concatenate([perm_a, B + perm_v]))
+        self.slot_to_row.copy_(s2r, non_blocking=True)
+        self.last_perm = (perm_a, perm_v)
+
+    def last_plan(self):
+        """Rebuild the ContrastivePlan the device drew (tests / debugging; synchronises)."""
+        cfg, B, T = self.cfg, self.B, self.cfg.frames
+        La, Lv = cfg.audio_tokens, cfg.video_tokens
+        ids = self.ids_dev.cpu().long()
+        perm_a, perm_v = self.last_perm
+        a_group, v_group = torch.zeros(B, dtype=torch.int64), torch.zeros(B, dtype=torch.int64)
+        a_keep, v_keep = [None] * B, [None] * B
+        for sl in range(B):
+            g = int(self.slot_group[sl])
+            a_group[perm_a[sl]] = g
+            v_group[perm_v[sl]] = g
+            a_keep[int(perm_a[sl])] = ids[sl * La: sl * La + self.keep_a[g]].clone()
+            base = B * La + sl * T * Lv
+            v_keep[int(perm_v[sl])] = [ids[base + t * Lv: base + t * Lv + self.keep_v[g]].clone() for t in range(T)]
+        return ContrastivePlan(a_group, v_group, a_keep, v_keep)
+
     def forward(self, audio, imgs, plan):
-        """-> (nce [1] device tensor, c_acc [1] device tensor); leaves everything backward needs in place."""
+        """-> (nce [1] device tensor, c_acc [1] device tensor); leaves everything backward needs in place.
+        plan: a ContrastivePlan to inject, or None when draw_device() already filled the index arrays."""
         cfg, st = self.cfg, self.stack
-        self._set_plan(plan)
+        if plan is not None:
+            self._set_plan(plan)
         x0 = st.x[0]
         self.emb_a.forward(audio, x0[:self.rows_a])
         self.emb_v.forward(_fold_frames(imgs, cfg.frames), x0[self.rows_a:])
@@ -359,8 +438,10 @@ class MaePass:
         self.blk_dec = [BlockParams(arena, f"decoder_blocks.{i}", "") for i in range(cfg.dec_depth)]
         self.fin_a, self.fin_v = [Norm(arena, "ast_base.norm_a")], [Norm(arena, "vit_base.norm")]   # :495,492
         self.dec_norm = [Norm(arena, "decoder_norm")]
-        self.emb_a = PatchEmbedder(arena, dev, self.rows_a, True, cfg)
-        self.emb_v = PatchEmbedder(arena, dev, self.rows_v, False, cfg)
+        rows_e = self.rows_a + self.rows_v
+        self.row_src_all, self.row_tok_all = _z((rows_e,), I32, dev), _z((rows_e,), I32, dev)
+        self.emb_a = PatchEmbedder(arena, dev, self.rows_a, True, cfg, self.row_src_all[:self.rows_a], self.row_tok_all[:self.rows_a])
+        self.emb_v = PatchEmbedder(arena, dev, self.rows_v, False, cfg, self.row_src_all[self.rows_a:], self.row_tok_all[self.rows_a:])
         self.dec_embed = Linear(arena, "decoder_embed.weight", "decoder_embed.bias")
         self.pred_a = Linear(arena, "decoder_pred_a.weight", "decoder_pred_a.bias")
         self.pred_v = Linear(arena, "decoder_pred_v.weight", "decoder_pred_v.bias")
@@ -398,8 +479,21 @@ class MaePass:
         self.p_v = _z((ops.pad_rows(self.nv_rows), P * cfg.in_chans), F32, dev)
         self.dp_a = _z((ops.pad_rows(self.na_rows), P), BF16, dev)
         self.dp_v = _z((ops.pad_rows(self.nv_rows), P * cfg.in_chans), BF16, dev)
-        self.mask_a = _z((B, La), F32, dev)
-        self.mask_v = _z((B, T * Lv), F32, dev)
+        self.mask_all = _z((B * La + B * T * Lv,), F32, dev)       # [mask_a | mask_v], filled by the plan kernel
+        self.mask_a = self.mask_all[:B * La].view(B, La)
+        self.mask_v = self.mask_all[B * La:].view(B, T * Lv)
+        # device-side plan: every descriptor field is static for this pass (75 % unstructured on all sequences)
+        nseq = B + B * T
+        d = np.zeros((nseq, ops.PLAN_FIELDS), dtype=np.int32)
+        for b in range(B):
+            d[b] = [La, ka, b * ka, b, b * self.Ltot, b * self.n_enc, 0, b * La, b * La, 0, 0, 0]
+            for t in range(T):
+                i = b * T + t
+                d[B + i] = [Lv, kv, self.rows_a + i * kv, i, b * self.Ltot + La + t * Lv, b * self.n_enc + ka + t * kv, 0,
+                            B * La + i * Lv, B * La + i * Lv, 0, 0, 0]
+        self.desc_host = d
+        self.desc_dev = torch.from_numpy(d).to(dev)
+        self.ids_dev = _z((B * La + B * T * Lv,), I32, dev)
         self.rl_a, self.rl_v = _z((self.na_rows,), F32, dev), _z((self.nv_rows,), F32, dev)
         self.losses = _z((3,), F32, dev)                       # loss_a, loss_v, loss_mae
         self.nmask_a = float(B * (La - ka))
@@ -426,10 +520,28 @@ class MaePass:
         self.mask_a.copy_((ra >= ka).float(), non_blocking=True)                         # :385-388
         self.mask_v.copy_((rv >= kv).float().reshape(B, T * Lv), non_blocking=True)
 
+    def draw_device(self, seed, nprng=None):
+        """75 % unstructured masks of every audio / video sequence, drawn on the device (one launch)."""
+        ops.mask_plan(self.desc_dev, self.desc_host, seed, self.row_src_all, self.row_tok_all, src_row=self.src_row,
+                      mask_out=self.mask_all, ids_out=self.ids_dev)
+        self.emb_a.rows_updated()
+        self.emb_v.rows_updated()
+
+    def last_plan(self):
+        """Rebuild the MaePlan the device drew (tests / debugging; synchronises)."""
+        cfg, B, T = self.cfg, self.B, self.cfg.frames
+        La, Lv, ka, kv = cfg.audio_tokens, cfg.video_tokens, cfg.keep_a, cfg.keep_v
+        ids = self.ids_dev.cpu().long()
+        sa = ids[:B * La].view(B, La)
+        sv = ids[B * La:].view(B, T, Lv)
+        return MaePlan(sa[:, :ka].contiguous(), torch.argsort(sa, dim=1), sv[..., :kv].contiguous(), torch.argsort(sv, dim=-1))
+
     def forward(self, audio, imgs, plan):
+        """plan: a MaePlan to inject, or None when draw_device() already filled the index arrays."""
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         La, Lv = cfg.audio_tokens, cfg.video_tokens
-        self._set_plan(plan)
+        if plan is not None:
+            self._set_plan(plan)
         self.audio, self.imgs = audio, _fold_frames(imgs, T)
         self.emb_a.forward(audio, self.st_a.x[0])
         self.emb_v.forward(self.imgs, self.st_v.x[0])

@@ -11,8 +11,9 @@ Differences that are deliberate and documented:
   reference-like initial state (weights.py); ``load_state_dict`` accepts reference checkpoints;
 * like the reference, most constructor arguments are accepted and ignored (dims are fixed by the model family,
   :248-261,316-329); a keyword-only ``cfg=`` selects other shapes (T frames, 128 audio tokens, ViT-L);
-* ``mask_plan=`` (keyword-only) injects the token selection; without it the plan is drawn from an internal
-  generator with the reference's distribution (maskplan.py);
+* ``mask_plan=`` (keyword-only) injects the token selection; without it the plan is drawn ON THE DEVICE by the
+  mask-plan kernel (csrc/maskplan.hip, Philox streams keyed by the model's plan seed) with the reference's
+  distribution; ``draw_plans`` is the equivalent host generator (maskplan.py);
 * the forward/backward of a pass is ONE autograd node (hand-scheduled backward); gradients are delivered through
   ``.grad`` views of a flat arena, so ``torch.autograd.grad`` on individual parameters and gradient
   accumulation across several backward calls are not supported (the reference loop does neither).
@@ -55,21 +56,26 @@ class _HotPath(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, audio, imgs, plan_m, plan_c, contrast_w):
+        """plan_*: False = branch off, None = draw on the device, else an explicit MaePlan / ContrastivePlan."""
         ctx.set_materialize_grads(False)
         ctx.model, ctx.contrast_w = model, contrast_w
-        ctx.has_m, ctx.has_c = plan_m is not None, plan_c is not None
+        ctx.has_m, ctx.has_c = plan_m is not False, plan_c is not False
         dev = audio.device
         zero = torch.zeros(1, device=dev)
         B = audio.shape[0]
         out = {}
-        if plan_m is not None:
+        if plan_m is not False:
             eng = model._engine("mae", B)
+            if plan_m is None:
+                eng.draw_device(model._next_seed(), model._np_rng())
             lm, la, lv, ma, mv = eng.forward(audio, imgs, plan_m)
             out.update(loss_mae=lm.clone(), la=la.clone(), lv=lv.clone(), mask_a=ma.clone(), mask_v=mv.clone())
         else:
             out.update(loss_mae=zero.clone(), la=zero.clone(), lv=zero.clone(), mask_a=None, mask_v=None)
-        if plan_c is not None:
+        if plan_c is not False:
             eng = model._engine("contrastive", B)
+            if plan_c is None:
+                eng.draw_device(model._next_seed(), model._np_rng())
             nce, acc = eng.forward(audio, imgs, plan_c)
             out.update(loss_c=nce * contrast_w, c_acc=acc.clone())
         else:
@@ -203,7 +209,29 @@ class CAVMAE_BASE(nn.Module):
             seed = self._plan_seed if self._plan_seed is not None else int(torch.initial_seed() % (2 ** 31))
             self._gen = torch.Generator().manual_seed(seed)
             self._pyrng = _pyrandom.Random(seed)
+            import numpy as np
+            self._nprng = np.random.default_rng(seed)
+            self._seed_base = seed
         return self._gen, self._pyrng
+
+    def _next_seed(self):
+        """64-bit Philox key of the next device-side plan: (base seed, draw counter)."""
+        self._rngs()
+        self._draws = getattr(self, "_draws", 0) + 1
+        return ((self._seed_base & 0xFFFFFFFF) << 32) | (self._draws & 0xFFFFFFFF)
+
+    def _np_rng(self):
+        self._rngs()
+        return self._nprng
+
+    def last_plans(self, batch):
+        """The plans the device drew in the latest forward (rebuilt from the device buffers; synchronises)."""
+        out = {}
+        for which in ("mae", "contrastive"):
+            eng = self._engines.get((which, batch))
+            if eng is not None:
+                out[which] = eng.last_plan()
+        return out
 
     def draw_plans(self, batch, mae=True, contrastive=True):
         gen, pyrng = self._rngs()
@@ -236,14 +264,10 @@ class CAVMAE_BASE(nn.Module):
             plan_m = mask_plan
         elif isinstance(mask_plan, ContrastivePlan):
             plan_c = mask_plan
-        if do_m and plan_m is None:
-            plan_m = self.draw_plans(B, True, False)[0]
-        if do_c and plan_c is None:
-            plan_c = self.draw_plans(B, False, True)[1]
         if not do_m:
-            plan_m = None
+            plan_m = False                                   # False: branch off; None: draw the plan on the device
         if not do_c:
-            plan_c = None
+            plan_c = False
         self._sync_shadows()
         anchor = self._params["vit_base.norm.weight"]
         if torch.is_grad_enabled():

@@ -199,6 +199,38 @@ def im2col_video(v, row_img, row_tok, out, rows):
     _lib.call("avs_im2col_video", v, row_img, row_tok, out, rows, C, H, W, _stream())
 
 
+PLAN_FIELDS = 12      # int32 per sequence descriptor of avs_mask_plan
+
+
+def mask_plan(seqs_dev, seqs_host, seed, row_src, row_tok, tmask_lo=None, tmask_hi=None, fmask=None, src_row=None, mask_out=None,
+              ids_out=None):
+    """Draw the random masks of every sequence in `seqs` on the device.  seqs_host (numpy int32 [nseq, 12]) is the host copy
+    of seqs_dev used to validate every offset before the launch."""
+    _chk(seqs_dev, I32, "plan.seqs", 2); _chk(row_src, I32, "plan.row_src"); _chk(row_tok, I32, "plan.row_tok")
+    _chk(src_row, I32, "plan.src_row"); _chk(mask_out, F32, "plan.mask"); _chk(ids_out, I32, "plan.ids")
+    for t in (tmask_lo, tmask_hi, fmask):
+        _chk(t, I32, "plan.bitmask")
+    nseq = seqs_host.shape[0]
+    assert seqs_dev.shape == (nseq, PLAN_FIELDS) and seqs_host.shape[1] == PLAN_FIELDS
+    L, keep, row_off, dec_off, t_p, ids_off, mask_off = (seqs_host[:, i] for i in (0, 1, 2, 4, 6, 7, 8))
+    assert (L > 0).all() and (L <= 1024).all() and (keep >= 0).all() and (keep <= L).all()
+    assert (row_off >= 0).all() and int((row_off + keep).max()) <= min(row_src.numel(), row_tok.numel())
+    if (dec_off >= 0).any():
+        sel = dec_off >= 0
+        assert src_row is not None and mask_out is not None
+        assert int((dec_off[sel] + L[sel]).max()) <= src_row.numel() and int((mask_off[sel] + L[sel]).max()) <= mask_out.numel()
+        assert (mask_off[sel] >= 0).all()
+    if (ids_off >= 0).any():
+        sel = ids_off >= 0
+        assert ids_out is not None and int((ids_off[sel] + L[sel]).max()) <= ids_out.numel()
+    if (t_p > 0).any():
+        assert all(t is not None and t.numel() >= nseq for t in (tmask_lo, tmask_hi, fmask))
+        sel = t_p > 0
+        assert (t_p[sel] <= 64).all() and (L[sel] % t_p[sel] == 0).all() and (L[sel] // t_p[sel] <= 32).all()
+    _lib.call("avs_mask_plan", seqs_dev, nseq, tmask_lo, tmask_hi, fmask, int(seed) & 0xFFFFFFFFFFFFFFFF, row_src, row_tok, src_row,
+              mask_out, ids_out, _stream())
+
+
 def cast_scale(x, y, n, alpha):
     _chk(x, F32, "cast.x"); _chk(y, BF16, "cast.y")
     assert x.numel() >= n and y.numel() >= n and n % 4 == 0

@@ -22,8 +22,7 @@ from .utils import AverageMeter
 def train_step(model, a_input, v_input, lr, plans=None):
     """One reference step on one batch.  Returns the device scalars the reference logs (no host sync here):
     (loss_pass2, loss_mae_a, loss_mae_v, loss_c, c_acc)."""
-    B = a_input.shape[0]
-    pm, pc = plans if plans is not None else model.draw_plans(B)
+    pm, pc = plans if plans is not None else (None, None)     # None: masks are drawn on the device
     out = model(a_input, v_input, mae_loss_weight=0, contrast_loss_weight=1, mask_plan=pc)        # :132
     loss_c, c_acc = out[4], out[7]
     out[0].backward()                                                                             # :138

@@ -74,6 +74,14 @@ int avs_im2col_audio(const float* a, const int* row_b, const int* row_tok, avs_b
                      int t_patches, avs_stream_t stream);
 int avs_im2col_video(const float* v, const int* row_img, const int* row_tok, avs_bf16* out, int rows, int C, int H, int W,
                      avs_stream_t stream);
+/* random masking on the device (random_masking_unstructured / _structured + the gather index build,
+ * cav_mae_base.py:365-439): one workgroup per sequence; seqs = nseq x 12 int32 {L, keep, row_off, src_id, dec_off, enc_base,
+ * t_patches, ids_off, mask_off, 0, 0, 0}; L <= 1024.  tmask_lo/hi, fmask (per sequence bit masks of the time columns /
+ * frequency rows forced to be removed) are read only where t_patches > 0.  src_row / mask_out / ids_out may be NULL when no
+ * sequence uses them. */
+int avs_mask_plan(const int* seqs, int nseq, const unsigned* tmask_lo, const unsigned* tmask_hi, const unsigned* fmask,
+                  unsigned long long seed, int* row_src, int* row_tok, int* src_row, float* mask_out, int* ids_out,
+                  avs_stream_t stream);
 int avs_cast_scale_bf16(const float* x, avs_bf16* y, long long n, float alpha, avs_stream_t stream);
 int avs_scatter_add_rows(const avs_bf16* src, const int* idx, float* dst, int rows, int D, float scale, avs_stream_t stream);
 int avs_colsum_bf16(const avs_bf16* x, float* out, int rows, int C, avs_stream_t stream);

@@ -372,3 +372,56 @@ def test_adam_matches_torch():
         o.adam(p, gs, m, v, pb, n, 2e-4, step)
         assert torch.allclose(p, ref_p.data, rtol=1e-5, atol=1e-7), step
     assert torch.equal(pb, bf(p))
+
+
+def test_mask_plan_kernel_properties():
+    """Every sequence: ids are a permutation; the first `keep` go to the row arrays; un-shuffle sources / masks agree with
+    the permutation; structured sequences never keep a forced-out token while enough free tokens exist; keeps are uniform."""
+    import numpy as np
+    o = ops()
+    nseq, L, keep, t_p = 300, 512, 307, 64
+    d = np.zeros((nseq, o.PLAN_FIELDS), dtype=np.int32)
+    dec = nseq * L
+    for s in range(nseq):
+        structured = s % 2 == 0
+        d[s] = [L, keep, s * keep, 1000 + s, s * L, s * 77, t_p if structured else 0, s * L, s * L, 0, 0, 0]
+    rng = np.random.default_rng(0)
+    tl = rng.integers(0, 2 ** 31, nseq).astype(np.int32) & 0x0F0F0F0F
+    th = rng.integers(0, 2 ** 31, nseq).astype(np.int32) & 0x00FF00FF
+    fm = (rng.integers(0, 4, nseq) * 5).astype(np.int32) & 0xFF
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    row_src = torch.full((nseq * keep,), -7, dtype=torch.int32, device=DEV)
+    row_tok = torch.full((nseq * keep,), -7, dtype=torch.int32, device=DEV)
+    src_row = torch.full((dec,), -7, dtype=torch.int32, device=DEV)
+    mask = torch.full((dec,), -7.0, device=DEV)
+    ids = torch.full((dec,), -7, dtype=torch.int32, device=DEV)
+    o.mask_plan(dev(d), d, 0x1234ABCD5678, row_src, row_tok, dev(tl), dev(th), dev(fm), src_row, mask, ids)
+    ids_c, tok_c, src_c, mask_c = ids.cpu().view(nseq, L), row_tok.cpu().view(nseq, keep), src_row.cpu().view(nseq, L), mask.cpu().view(nseq, L)
+    assert torch.equal(ids_c.sort(dim=1).values, torch.arange(L, dtype=torch.int32).expand(nseq, L))
+    assert torch.equal(tok_c, ids_c[:, :keep])
+    assert torch.equal(row_src.cpu().view(nseq, keep), (1000 + torch.arange(nseq, dtype=torch.int32))[:, None].expand(nseq, keep))
+    for s in range(0, nseq, 37):
+        kept = ids_c[s, :keep].long()
+        assert torch.equal(src_c[s, kept], (s * 77 + torch.arange(keep)).int())
+        assert (mask_c[s, kept] == 0).all() and mask_c[s].sum().item() == L - keep
+        assert (src_c[s][mask_c[s] == 1] == -1).all()
+    # structured: forced-out tokens are kept only when the free ones run out
+    for s in range(0, nseq, 2):
+        tbits = (int(tl[s]) & 0xFFFFFFFF) | ((int(th[s]) & 0xFFFFFFFF) << 32)
+        forced = torch.tensor([((tbits >> (i % t_p)) & 1) | ((int(fm[s]) >> (i // t_p)) & 1) for i in range(L)], dtype=torch.bool)
+        nfree = int((~forced).sum())
+        kept = ids_c[s, :keep].long()
+        assert int(forced[kept].sum()) == max(0, keep - nfree)
+    # unstructured keeps are uniform over positions
+    freq = torch.zeros(L)
+    for s in range(1, nseq, 2):
+        freq[ids_c[s, :keep].long()] += 1
+    p = keep / L
+    z = (freq - (nseq // 2) * p) / math.sqrt((nseq // 2) * p * (1 - p))
+    assert z.abs().max() < 5.0
+    # different seed -> different plan; same seed -> same plan
+    ids2 = torch.empty_like(ids)
+    o.mask_plan(dev(d), d, 0x1234ABCD5678, row_src, row_tok, dev(tl), dev(th), dev(fm), src_row, mask, ids2)
+    assert torch.equal(ids2, ids)
+    o.mask_plan(dev(d), d, 0x1234ABCD5679, row_src, row_tok, dev(tl), dev(th), dev(fm), src_row, mask, ids2)
+    assert not torch.equal(ids2, ids)

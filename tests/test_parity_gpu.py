@@ -142,3 +142,32 @@ def test_forward_requires_gpu_and_library():
     a, v = synth_inputs(cfg, 2, 1)
     with pytest.raises(_lib.AvsiamHipError):
         m(a, v)
+
+
+@pytest.mark.parametrize("which,B,T,La", [("mae", 3, 2, 128), ("contrastive", 6, 1, 512)])
+def test_device_drawn_plan_matches_oracle(which, B, T, La):
+    """Default path: the mask plan is drawn on the device (csrc/maskplan.hip).  Read the plan back, feed it to the
+    oracle, and require the same parity as with injected plans - this pins the kernel's index outputs (row gather,
+    un-shuffle sources, loss masks) against what the plan says."""
+    cfg = AVSiamConfig(audio_tokens=La, frames=T)
+    a, v = synth_inputs(cfg, B, 5)
+    mae = which == "mae"
+    from avsiam_amd.models import CAVMAE_BASE
+    m = CAVMAE_BASE(cfg=cfg, init_seed=77, init_mode="random", verbose=False, plan_seed=123).cuda()
+    out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1)
+    out[0].backward()
+    plan = m.last_plans(B)[which]
+    ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 77)
+    for i in (0, 1, 2, 3, 4):
+        assert abs(out[i].item() - ref[i].item()) <= 2e-2 * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+    if mae:
+        assert torch.equal(out[5].cpu(), ref[5]) and torch.equal(out[6].cpu(), ref[6])
+    _compare_grads(m, rgrads)
+    # a second forward draws a different plan (the Philox key advances)
+    m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1)
+    plan2 = m.last_plans(B)[which]
+    if mae:
+        assert not torch.equal(plan.ids_keep_a, plan2.ids_keep_a)
+    else:
+        assert any(not torch.equal(x, y) for x, y in zip(plan.a_keep, plan2.a_keep) if x.numel() == y.numel() and x.numel() < 512) or \
+            not torch.equal(plan.a_group, plan2.a_group)
