@@ -96,6 +96,7 @@ struct AttnArgs {
     const int* tile_start;                      // first packed row of the tile's sequence
     const int* tile_len;                        // length of that sequence
     const int* tile_q0;                         // first row (within the sequence) of this 128-row tile
+    int ntiles;
     bf16_t* out; long long ldo;                 // fwd: attention output [rows, D]
     float* lse; int rows_total;                 // [H][rows_total] natural-log sum-exp of the scaled scores
     const bf16_t* dout;                         // bwd: dO [rows, D] (ldo)
@@ -112,9 +113,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     char* sK = smem;
     char* sV = smem + 64 * HD * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int head = blockIdx.y;
-    const int seq0 = a.tile_start[blockIdx.x], L = a.tile_len[blockIdx.x];
-    const int qw = a.tile_q0[blockIdx.x] + 32 * wave;          // first query of this wave
+    // 1-D grid, XCD-aware: logical id = head * ntiles + tile, so the query/key tiles of one (sequence, head) - which all
+    // stream the same K/V (or Q/dO) rows - run on one XCD and re-read them from its L2 instead of from HBM.
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = lid / a.ntiles, tix = lid - head * a.ntiles;
+    const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int qw = a.tile_q0[tix] + 32 * wave;          // first query of this wave
     const bool active = qw < L;
     const int q = min(qw + (lane & 31), L - 1);
     const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
@@ -223,9 +227,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     char* sK = smem;
     char* sV = smem + 64 * HD * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int head = blockIdx.y;
-    const int seq0 = a.tile_start[blockIdx.x], L = a.tile_len[blockIdx.x];
-    const int qw = a.tile_q0[blockIdx.x] + 32 * wave;
+    // 1-D grid, XCD-aware: logical id = head * ntiles + tile, so the query/key tiles of one (sequence, head) - which all
+    // stream the same K/V (or Q/dO) rows - run on one XCD and re-read them from its L2 instead of from HBM.
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = lid / a.ntiles, tix = lid - head * a.ntiles;
+    const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int qw = a.tile_q0[tix] + 32 * wave;
     const bool active = qw < L;
     const int q = min(qw + (lane & 31), L - 1);
     const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
@@ -324,9 +331,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     float* sLse = reinterpret_cast<float*>(smem + 2 * 64 * HD * 2);
     float* sDel = sLse + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int head = blockIdx.y;
-    const int seq0 = a.tile_start[blockIdx.x], L = a.tile_len[blockIdx.x];
-    const int kw = a.tile_q0[blockIdx.x] + 32 * wave;          // first key of this wave
+    // 1-D grid, XCD-aware: logical id = head * ntiles + tile, so the query/key tiles of one (sequence, head) - which all
+    // stream the same K/V (or Q/dO) rows - run on one XCD and re-read them from its L2 instead of from HBM.
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = lid / a.ntiles, tix = lid - head * a.ntiles;
+    const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int kw = a.tile_q0[tix] + 32 * wave;          // first key of this wave
     const bool active = kw < L;
     const int key = min(kw + (lane & 31), L - 1);
     const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
@@ -445,8 +455,8 @@ extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_fwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && lse && (ldo % 4) == 0, "attn_fwd: null output");
-    AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd)};
-    dim3 grid(ntiles, H);
+    AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd)};
+    dim3 grid(ntiles * H);
     if (hd == 64) attn_fwd_kernel<64><<<grid, 256, 0, stream>>>(a);
     else attn_fwd_kernel<32><<<grid, 256, 0, stream>>>(a);
     AVS_LAUNCH_CHECK("attn_fwd");
@@ -459,9 +469,9 @@ extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
-    AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
+    AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
                dout, delta, dqkv, 1.0f / sqrtf((float)hd)};
-    dim3 grid(ntiles, H);
+    dim3 grid(ntiles * H);
     if (hd == 64) attn_bwd_dq_kernel<64><<<grid, 256, 0, stream>>>(a);
     else attn_bwd_dq_kernel<32><<<grid, 256, 0, stream>>>(a);
     AVS_LAUNCH_CHECK("attn_bwd_dq");

@@ -85,4 +85,15 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return fmaf(x * 0.39894228040143268f, pdf, cdf);
 }
 
+// Workgroups b and b+8 share an XCD (round-robin dispatch; speed only, never correctness).  Map the dispatch index to a
+// logical index so that each XCD gets a CONTIGUOUS run of logical work items: neighbouring items (GEMM tiles of one
+// A panel, query tiles of one attention sequence, output tiles of one wgrad split) then hit the same 4-MiB L2.
+// Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run of tiles so that
+    // neighbouring tiles (same A panel) hit the same L2.  Bijective for any nwg.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -31,12 +31,6 @@ struct GemmNtArgs {
     float alpha; int act;                    // 0 none | 1 gelu (out = pre-activation, out2 = gelu) | 2 gelu-backward (aux = pre-activation)
 };
 
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run of tiles so that
-    // neighbouring tiles (same A panel) hit the same L2.  Bijective for any nwg.
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
 
 // Epilogue, staged through LDS (free once the main loop is done).  The accumulators hold 16-row x 4-column patches
 // per lane; written as they stand, one store instruction would touch 16 rows x 32 B, and the per-CU store path is

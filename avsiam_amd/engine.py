@@ -379,7 +379,12 @@ class ContrastivePass:
         B, W, D = self.B, self.world, cfg.embed_dim
         if W > 1:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.all_reps.view(W * 2 * B, D), self.reps)   # c2: one [2,B,D] message per rank
+            if dist.get_backend() == "gloo":                  # test path (2 ranks sharing one GPU): gloo has no device all-gather-into-tensor
+                host = [torch.empty(2 * B, D) for _ in range(W)]
+                dist.all_gather(host, self.reps.cpu())
+                self.all_reps.copy_(torch.stack(host))
+            else:
+                dist.all_gather_into_tensor(self.all_reps.view(W * 2 * B, D), self.reps)   # c2: one [2,B,D] message per rank (RCCL)
             self.A.copy_(self.all_reps[:, :B].reshape(W * B, D))
             self.V.copy_(self.all_reps[:, B:].reshape(W * B, D))
         else:

@@ -286,7 +286,13 @@ class CAVMAE_BASE(nn.Module):
         mean is folded into adam_step's grad_scale."""
         if self._world > 1:
             import torch.distributed as dist
-            dist.all_reduce(self.arena.live_slice(self.arena.ensure_grads(), which))
+            g = self.arena.live_slice(self.arena.ensure_grads(), which)
+            if g.is_cuda and dist.get_backend() == "gloo":    # test path: stage through the host
+                h = g.cpu()
+                dist.all_reduce(h)
+                g.copy_(h)
+            else:
+                dist.all_reduce(g)
 
     def adam_step(self, which, lr, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=5e-7):
         """torch.optim.Adam(lr, weight_decay=5e-7, betas=(0.95, 0.999)) of the reference loop (:64-66) on the pass's

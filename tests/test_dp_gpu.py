@@ -1,0 +1,73 @@
+"""The data-parallel path on the REAL kernels: 2 processes share the single GPU of the test box (gloo for the two
+collectives - RCCL refuses two ranks on one device), each runs the contrastive pass of its own batch, and the results are
+compared with what the unmodified reference produced with 2 gloo ranks (tests/golden/c_w2_b3_r{0,1}.npz): the global
+[6,6] logits, the loss, and every live tensor's LOCAL gradient (before the mean all-reduce) - i.e. the build's
+"own slice x W, no backward collective" must equal GatherLayer's all-reduce + slice (gather_layer.py:35-37).
+Then the flat all-reduce + 1/W must make both ranks hold identical averaged gradients."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from avsiam_amd.config import AVSiamConfig
+from avsiam_amd.weights import synth_inputs
+from tests.helpers import golden_grads, golden_plan, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from avsiam_amd.models import CAVMAE_BASE
+        from avsiam_amd.param_spec import P1
+        d = load_golden(f"c_w2_b3_r{rank}")
+        cfg = AVSiamConfig()
+        B = int(d["batch"])
+        a, v = synth_inputs(cfg, B, int(d["input_seed"]))
+        m = CAVMAE_BASE(cfg=cfg, init_seed=int(d["weight_seed"]), init_mode="random", verbose=False).cuda()
+        m.set_distributed(world, rank)
+        out = m(a.cuda(), v.cuda(), mae_loss_weight=0, contrast_loss_weight=1, mask_plan=golden_plan(d))
+        out[0].backward()
+        got = np.array([out[i].item() for i in (0, 4)])
+        np.testing.assert_allclose(got, d["out_scalars"][[0, 4]], rtol=2e-2)
+        eng = m._engine("contrastive", B)
+        np.testing.assert_allclose(eng.total.cpu().numpy(), d["logits"], atol=0.25)
+        names, none, gsum, gl2, gsamp = golden_grads(d)
+        for i, n in enumerate(names):
+            g = m._params[n].grad
+            assert g is not None, n
+            l2 = float(g.double().norm())
+            assert abs(l2 - gl2[i]) <= 0.08 * gl2[i] + 1e-7, (n, l2, gl2[i])
+        # c1: one all-reduce over the live range, then 1/W -> both ranks hold the same mean gradient
+        m.allreduce_grads(P1)
+        lo, hi = m.arena.range[P1]
+        mean = (m.arena.g[lo:hi] / world).cpu()
+        other = [torch.empty_like(mean) for _ in range(world)]
+        dist.all_gather(other, mean)
+        assert torch.equal(other[0], other[1])
+        assert float(mean.abs().sum()) > 0
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_reference_w2_golden():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29761, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

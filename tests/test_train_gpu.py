@@ -1,0 +1,78 @@
+"""The reference training step (traintest_cavmae_base.py:131-152) end to end on the GPU: contrastive pass -> Adam#1 ->
+MAE pass (sees the updated weights) -> Adam#2, against the oracle driven by torch.optim.Adam with the reference's
+hyper-parameters; plus a short run of the train() loop and of validate()."""
+import argparse
+import random
+
+import pytest
+import torch
+
+from avsiam_amd.config import AVSiamConfig
+from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
+from avsiam_amd.weights import synth_inputs, synth_state
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_step_matches_oracle_adam():
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.traintest_cavmae_base import train_step
+    from oracle import ref_cpu
+    cfg = AVSiamConfig(audio_tokens=128)
+    B, lr = 4, 2e-4
+    a, v = synth_inputs(cfg, B, 3)
+    gen = torch.Generator().manual_seed(9)
+    pm, pc = make_mae_plan(cfg, B, gen), make_contrastive_plan(cfg, B, gen, random.Random(9))
+    m = CAVMAE_BASE(cfg=cfg, init_seed=21, init_mode="random", verbose=False).cuda()
+    m.publish_grads = False
+    before = {k: p.detach().cpu().clone() for k, p in m._params.items()}
+    out = train_step(m, a.cuda(), v.cuda(), lr, plans=(pm, pc))
+    torch.cuda.synchronize()
+    # oracle: same sequence with torch Adam (two optimizers over the same parameters, traintest:64-66)
+    torch.set_num_threads(16)
+    P = {k: t.clone().requires_grad_(True) for k, t in synth_state(cfg, 21, "random", include_dead=False).items()}
+    params = list(P.values())
+    o1 = torch.optim.Adam(params, lr, weight_decay=5e-7, betas=(0.95, 0.999))
+    o2 = torch.optim.Adam(params, lr, weight_decay=5e-7, betas=(0.95, 0.999))
+    r1 = ref_cpu.forward(P, cfg, a, v, pc, mae_loss_weight=0, contrast_loss_weight=1)
+    o1.zero_grad(); r1[0].backward(); o1.step()
+    r2 = ref_cpu.forward(P, cfg, a, v, pm, mae_loss_weight=1, contrast_loss_weight=0)
+    o2.zero_grad(); r2[0].backward(); o2.step()
+    assert abs(out[3].item() - r1[4].item()) <= 2e-2 * abs(r1[4].item())            # loss_c
+    assert abs(out[0].item() - r2[0].item()) <= 2e-2 * abs(r2[0].item())            # MAE loss AFTER the contrastive update
+    # parameter updates: first Adam step moves every element by ~lr*sign(g); compare update directions on big tensors
+    checked = 0
+    for k in ("vit_base.blocks.0.attn.qkv.weight", "vit_base.blocks.11.mlp.fc2.weight", "ast_base.blocks.5.mlp.fc1.weight",
+              "decoder_blocks.3.attn.proj.weight", "mm_layer_1.mlp.fc1.weight", "decoder_pred_v.weight", "vit_base.norm_a.weight",
+              "vit_base.patch_embed.proj.weight"):
+        d_hip = (m._params[k].detach().cpu() - before[k]).double().reshape(-1)
+        d_ref = (P[k].detach() - before[k]).double().reshape(-1)
+        assert d_ref.norm() > 0, k
+        cos = float(torch.dot(d_hip, d_ref) / (d_hip.norm() * d_ref.norm()))
+        assert cos > 0.9, (k, cos)
+        assert abs(float(d_hip.norm() / d_ref.norm()) - 1) < 0.1, k
+        checked += 1
+    assert checked == 8
+    # parameters no pass touches are not updated (Adam skips grad=None parameters)
+    for k in ("vit_base.head.weight", "ast_base.pos_embed", "vit_base.blocks.0.norm1.weight"):
+        assert torch.equal(m._params[k].detach().cpu(), before[k]), k
+
+
+def test_train_loop_and_validate(tmp_path):
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.traintest_cavmae_base import SyntheticAVLoader, train, validate
+    cfg = AVSiamConfig(audio_tokens=128)
+    m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=1)
+    args = argparse.Namespace(n_epochs=1, batch_size=4, lr=1e-3, lrscheduler_start=10, lrscheduler_step=5, lrscheduler_decay=0.5,
+                              n_print_steps=1, exp_dir=str(tmp_path), save_model=True, rank=0, gpu=0, world_size=1, steps_per_epoch=6)
+    val = SyntheticAVLoader(cfg, 4, 1, "cuda", seed=5)
+    train(m, None, [val, None], [None, None], None, args, None)
+    sd = torch.load(tmp_path / "models" / "audio_model.1.pth")
+    assert len(sd) == 963 and all(k.startswith("module.") for k in sd)
+    ev = validate(m, val)
+    assert all(map(lambda x: x == x, ev)) and ev[0] > 0            # finite losses
+    # the saved checkpoint loads back through the reference's consumer path (strip 'module.')
+    m2 = CAVMAE_BASE(cfg=cfg, verbose=False)
+    missing = m2.load_state_dict({k[len("module."):]: v for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert torch.equal(m2._params["decoder_embed.weight"].cpu(), m._params["decoder_embed.weight"].cpu())
