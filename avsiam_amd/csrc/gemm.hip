@@ -518,7 +518,19 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256 && (N1 / 256) * (N2 / 256) >= 24);
     const int T = big ? 256 : 128;
     const int tiles = (N1 / T) * (N2 / T);
-    if (splits <= 0) splits = ceil_div(big ? 256 : 512, tiles);      // ~1 (256^2) / ~2 (128^2) workgroups per CU
+    if (splits <= 0) {
+        // one resident round: 256^2 tiles hold 128 KiB of LDS (1 workgroup per CU), 128^2 tiles 64 KiB (2 per CU).  A grid
+        // slightly LARGER than the resident slots would add a second, almost empty round that doubles the critical path,
+        // so round the split count DOWN (e.g. 27 tiles -> 9 splits = 243 workgroups on 256 CUs).
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+        }
+        const int slots = big ? ncu : 2 * ncu;
+        splits = slots / tiles;
+        if (splits < 1) splits = 1;
+    }
     if (splits > nstages) splits = nstages;
     const int per = ceil_div(nstages, splits);
     splits = ceil_div(nstages, per);
