@@ -475,6 +475,12 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
         }
         attr_done = true;
     }
+    auto launch_small = [&](const GemmNtArgs& x) {
+        const int nwg = ceil_div(x.M, BM) * (x.N / BN);
+        if (act == 0) gemm_nt_kernel<0, 2, 4><<<nwg, 256, 65536, stream>>>(x);
+        else if (act == 1) gemm_nt_kernel<1, 2, 4><<<nwg, 256, 65536, stream>>>(x);
+        else gemm_nt_kernel<2, 2, 4><<<nwg, 256, 65536, stream>>>(x);
+    };
     if (big) {
         // persistent: one 128-KiB-LDS workgroup per CU walks the tiles (grid = min(tiles, CUs))
         static int ncu = 0;
@@ -482,15 +488,38 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
         }
-        const int grid = g_persistent ? (big_tiles < ncu ? big_tiles : ncu) : big_tiles;
-        if (act == 0) gemm_nt_kernel<0, 4, 8><<<grid, 512, 131072, stream>>>(a);
-        else if (act == 1) gemm_nt_kernel<1, 4, 8><<<grid, 512, 131072, stream>>>(a);
-        else gemm_nt_kernel<2, 4, 8><<<grid, 512, 131072, stream>>>(a);
+        // Whole rounds only: with T tiles on C CUs the last of ceil(T/C) rounds may be nearly empty (1122 tiles -> 4.4
+        // rounds cost 5).  Give the 256^2 kernel the row panels that fill floor(T/C) rounds and the remaining rows to the
+        // 128^2 kernel, whose four-times-smaller tiles (two workgroups per CU) fill the chip again.
+        const int nt_n = N / 256, nt_m = ceil_div(M, 256);
+        int big_rows = nt_m;                                                     // row panels given to the 256^2 kernel
+        if (g_persistent && g_force_tile == 0 && big_tiles > ncu) {
+            const int full = (big_tiles / ncu) * ncu;                            // tiles in whole rounds
+            const int rows_full = full / nt_n;
+            const int rem_rows = M - rows_full * 256;
+            if (rows_full >= 1 && rows_full < nt_m && (big_tiles % ncu) * 4 < ncu * 3 && rem_rows > 0) big_rows = rows_full;
+        }
+        GemmNtArgs b = a;
+        b.M = big_rows < nt_m ? big_rows * 256 : M;
+        const int tiles_b = ceil_div(b.M, 256) * nt_n;
+        const int grid = g_persistent ? (tiles_b < ncu ? tiles_b : ncu) : tiles_b;
+        if (act == 0) gemm_nt_kernel<0, 4, 8><<<grid, 512, 131072, stream>>>(b);
+        else if (act == 1) gemm_nt_kernel<1, 4, 8><<<grid, 512, 131072, stream>>>(b);
+        else gemm_nt_kernel<2, 4, 8><<<grid, 512, 131072, stream>>>(b);
+        if (b.M < M) {
+            GemmNtArgs r = a;                                                    // remaining rows [b.M, M)
+            const size_t o = (size_t)b.M;
+            r.M = M - b.M;
+            r.A = a.A + o * a.lda;
+            if (a.res && !a.res_idx) r.res = a.res + o * a.ldr;
+            if (a.res_idx) r.res_idx = a.res_idx + o;
+            if (a.aux) r.aux = a.aux + o * a.ldaux;
+            r.out = a.out_f32 ? (void*)((float*)a.out + o * a.ldo) : (void*)((bf16_t*)a.out + o * a.ldo);
+            if (a.out2) r.out2 = a.out2 + o * a.ldo2;
+            launch_small(r);
+        }
     } else {
-        const int nwg = ceil_div(M, BM) * (N / BN);
-        if (act == 0) gemm_nt_kernel<0, 2, 4><<<nwg, 256, 65536, stream>>>(a);
-        else if (act == 1) gemm_nt_kernel<1, 2, 4><<<nwg, 256, 65536, stream>>>(a);
-        else gemm_nt_kernel<2, 2, 4><<<nwg, 256, 65536, stream>>>(a);
+        launch_small(a);
     }
     AVS_LAUNCH_CHECK("gemm_nt");
     return 0;

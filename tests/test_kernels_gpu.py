@@ -86,7 +86,7 @@ def test_layernorm(D, rows):
     assert rel_err(dcol, 1 + dx2.double().sum(0)) < 1e-5           # fused column sum (bias gradient), accumulated
 
 
-@pytest.mark.parametrize("M,N,K", [(333, 256, 768), (1000, 768, 3072), (4099, 2304, 768), (128, 512, 256)])
+@pytest.mark.parametrize("M,N,K", [(333, 256, 768), (1000, 768, 3072), (4099, 2304, 768), (128, 512, 256), (25700, 768, 768)])
 def test_gemm_nt_epilogues(M, N, K):
     o = ops()
     A = bf(torch.randn(M, K, device=DEV))
