@@ -159,6 +159,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         }
         // running max is kept in RAW score units (sl2 > 0 keeps the order); only the last, partial key tile needs masking
         if (k0 + 64 > L) {
+            // block-uniform branch; the empty asm keeps hipcc from if-converting the body into per-element selects that
+            // every (full) tile would execute
+            asm volatile("; tail key tile: mask" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -271,8 +274,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             tile_load<HD>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
         }
         if (!active) continue;
-        auto key_block = [&](int kb, auto tail_c) {
-            constexpr bool TAIL = decltype(tail_c)::value;
+        const bool tail_tile = k0 + 64 > L;                 // block-uniform
+        auto key_block = [&](int kb) {
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -281,11 +284,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, kk, lane), qf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, kb * 32, kk, lane), dof[kk], dp, 0, 0, 0);
             }
+            if (tail_tile) {
+                // real branch (the empty asm blocks if-conversion): only the last, partial key tile pays for masking
+                asm volatile("; tail key tile: mask" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -INFINITY;     // -> p = exp2(-inf) = 0
+            }
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pr = fast_exp2(fmaf(s[r], sl2, -lse2));
-                if (TAIL && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) pr = 0.f;
+                const float pr = fast_exp2(fmaf(s[r], sl2, -lse2));
                 ds[r] = pr * (dp[r] - delta);
             }
 #pragma unroll
@@ -296,13 +305,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                     dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sK, kb * 32 + 16 * st, d, lane), dsf, dq[d], 0, 0, 0);
             }
         };
-        if (k0 + 64 <= L) {                                  // full tile: no masking code at all (block-uniform branch)
-            key_block(0, std::false_type{});
-            key_block(1, std::false_type{});
-        } else {
-            key_block(0, std::true_type{});
-            key_block(1, std::true_type{});
-        }
+        key_block(0);
+        key_block(1);
     }
     if (!active) return;
     const int qq = qw + (lane & 31);
@@ -374,8 +378,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             if (tid < 64) { rl = lsebase[min(q0 + 64 + tid, L - 1)]; rd = delbase[min(q0 + 64 + tid, L - 1)]; }
         }
         if (!active) continue;
-        auto q_block = [&](int qb, auto tail_c) {
-            constexpr bool TAIL = decltype(tail_c)::value;
+        const bool tail_tile = q0 + 64 > L;                 // block-uniform
+        auto q_block = [&](int qb) {
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -383,6 +387,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             for (int kk = 0; kk < NKK; ++kk) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, qb * 32, kk, lane), kf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sDO, qb * 32, kk, lane), vf[kk], dp, 0, 0, 0);
+            }
+            if (tail_tile) {
+                // real branch (the empty asm blocks if-conversion): only the last, partial query tile pays for masking
+                asm volatile("; tail query tile: mask" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (q0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -INFINITY;     // -> p = exp2(-inf) = 0
             }
             float p[16], ds[16];
 #pragma unroll
@@ -394,8 +405,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * t + j;
-                    float pr = fast_exp2(fmaf(s[r], sl2, -ls[j]));
-                    if (TAIL && (q0 + rb + j) >= L) pr = 0.f;
+                    const float pr = fast_exp2(fmaf(s[r], sl2, -ls[j]));
                     p[r] = pr;
                     ds[r] = pr * (dp[r] - dl[j]);
                 }
@@ -411,13 +421,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
                 }
             }
         };
-        if (q0 + 64 <= L) {                                  // full query tile: no masking code (block-uniform branch)
-            q_block(0, std::false_type{});
-            q_block(1, std::false_type{});
-        } else {
-            q_block(0, std::true_type{});
-            q_block(1, std::true_type{});
-        }
+        q_block(0);
+        q_block(1);
     }
     if (!active) return;
     const int kq = kw + (lane & 31);
