@@ -40,8 +40,9 @@ __global__ void mae_loss_fwd_kernel(const float* __restrict__ pred, const float*
     if (threadIdx.x == 0) row_loss[r] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)P * mask[r];
 }
 
-// deterministic single-block sum: out[0] = scale * sum(x)
-__global__ void sum_scale_kernel(const float* __restrict__ x, int n, float scale, float* out) {
+// deterministic single-block sum: out[0] = scale * sum(x); optionally total[0] = (total_init ? 0 : total[0]) + out[0]
+// (loss_mae = loss_mae_a + loss_mae_v, cav_mae_base.py:707)
+__global__ void sum_scale_kernel(const float* __restrict__ x, int n, float scale, float* out, float* total, int total_init) {
     __shared__ float red[16];
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
@@ -52,6 +53,7 @@ __global__ void sum_scale_kernel(const float* __restrict__ x, int n, float scale
         float t = 0.f;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
         out[0] = t * scale;
+        if (total) total[0] = (total_init ? 0.f : total[0]) + t * scale;
     }
 }
 
@@ -177,8 +179,9 @@ __global__ void infonce_stats_kernel(const float* __restrict__ total, int N, flo
     }
 }
 
-// out[0] = nce = (mean(lse_col - diag) + mean(lse_row - diag)) / 2 ;  out[1] = c_acc = hits / (2N)
-__global__ void infonce_reduce_kernel(const float* __restrict__ stats, int N, float* out) {
+// out[0] = nce = (mean(lse_col - diag) + mean(lse_row - diag)) / 2 ;  out[1] = c_acc = hits / (2N) ;
+// out[2] = weight * nce (loss_c = contrast_loss_weight * loss_c, cav_mae_base.py:735)
+__global__ void infonce_reduce_kernel(const float* __restrict__ stats, int N, float weight, float* out) {
     __shared__ float red[4][2];
     float s = 0.f, h = 0.f;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
@@ -193,6 +196,7 @@ __global__ void infonce_reduce_kernel(const float* __restrict__ stats, int N, fl
         h = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
         out[0] = s / (2.0f * N);
         out[1] = h / (2.0f * N);
+        out[2] = weight * (s / (2.0f * N));
     }
 }
 
@@ -210,13 +214,14 @@ __global__ void infonce_dlogits_kernel(const float* __restrict__ total, const fl
 
 // ===================================================================================================
 extern "C" int avs_mae_loss_fwd(const float* pred, const float* inp, const float* mask, float* row_loss, float* loss,
-                                int rows, int audio, int L, int C, int H, int W, float nmask, hipStream_t stream) {
+                                float* total, int total_init, int rows, int audio, int L, int C, int H, int W, float nmask,
+                                hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && pred && inp && mask && row_loss && loss && nmask > 0, "mae_loss_fwd: bad args");
     const int G = audio ? H / 16 : W / 16;
     const int P = 256 * (audio ? 1 : C);
     mae_loss_fwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, row_loss, audio, L, C, H, W, G, P);
     AVS_LAUNCH_CHECK("mae_loss_fwd");
-    sum_scale_kernel<<<1, 1024, 0, stream>>>(row_loss, rows, 1.0f / nmask, loss);
+    sum_scale_kernel<<<1, 1024, 0, stream>>>(row_loss, rows, 1.0f / nmask, loss, total, total_init);
     AVS_LAUNCH_CHECK("mae_loss_sum");
     return 0;
 }
@@ -254,12 +259,12 @@ extern "C" int avs_gemm_f32_small(const float* A, long long sam, long long sak, 
     return 0;
 }
 
-// total [N,N] -> stats [N,4], out {nce, c_acc}
-extern "C" int avs_infonce_fwd(const float* total, float* stats, float* out, int N, hipStream_t stream) {
+// total [N,N] -> stats [N,4], out {nce, c_acc, weight * nce}
+extern "C" int avs_infonce_fwd(const float* total, float* stats, float* out, int N, float weight, hipStream_t stream) {
     AVS_CHECK_ARG(N > 0 && total && stats && out, "infonce_fwd: bad args");
     infonce_stats_kernel<<<N, 256, 0, stream>>>(total, N, stats);
     AVS_LAUNCH_CHECK("infonce_stats");
-    infonce_reduce_kernel<<<1, 256, 0, stream>>>(stats, N, out);
+    infonce_reduce_kernel<<<1, 256, 0, stream>>>(stats, N, weight, out);
     AVS_LAUNCH_CHECK("infonce_reduce");
     return 0;
 }

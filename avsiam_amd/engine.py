@@ -279,7 +279,7 @@ class ContrastivePass:
         self.An, self.Vn = _z((N, D), F32, dev), _z((N, D), F32, dev)
         self.na, self.nv = _z((N,), F32, dev), _z((N,), F32, dev)
         self.total, self.dtotal = _z((N, N), F32, dev), _z((N, N), F32, dev)
-        self.nstats, self.nout = _z((N, 4), F32, dev), _z((2,), F32, dev)
+        self.nstats, self.nout = _z((N, 4), F32, dev), _z((3,), F32, dev)
         self.dAn, self.dVn = _z((N, D), F32, dev), _z((N, D), F32, dev)
         self.dA, self.dV = _z((N, D), F32, dev), _z((N, D), F32, dev)
         self.dreps = _z((2 * batch, D), F32, dev)
@@ -363,8 +363,8 @@ class ContrastivePass:
             v_keep[int(perm_v[sl])] = [ids[base + t * Lv: base + t * Lv + self.keep_v[g]].clone() for t in range(T)]
         return ContrastivePlan(a_group, v_group, a_keep, v_keep)
 
-    def forward(self, audio, imgs, plan):
-        """-> (nce [1] device tensor, c_acc [1] device tensor); leaves everything backward needs in place.
+    def forward(self, audio, imgs, plan, weight=1.0):
+        """-> (weight * nce [1] device tensor, c_acc [1] device tensor); leaves everything backward needs in place.
         plan: a ContrastivePlan to inject, or None when draw_device() already filled the index arrays."""
         cfg, st = self.cfg, self.stack
         if plan is not None:
@@ -394,8 +394,8 @@ class ContrastivePass:
         ops.l2norm_fwd(self.A, self.An, self.na)
         ops.l2norm_fwd(self.V, self.Vn, self.nv)
         ops.gemm_f32_small(self.An, self.Vn, self.total, N, N, D, (D, 1), (1, D), 1.0 / cfg.temperature)
-        ops.infonce_fwd(self.total, self.nstats, self.nout)
-        return self.nout[0:1], self.nout[1:2]
+        ops.infonce_fwd(self.total, self.nstats, self.nout, weight)
+        return self.nout[2:3], self.nout[1:2]
 
     def backward(self, gout, weight):
         """gout: [1] fp32 device tensor (d loss / d loss_c_weighted); weight = contrast_loss_weight."""
@@ -567,9 +567,10 @@ class MaePass:
         _ln_fwd(self.st_dec.out, self.dec_norm, self.dn, self.dn_stat[0], self.dn_stat[1], rows_d, LN_EPS_BLOCK, out_map=self.dn_map)
         ops.gemm_nt(self.dn[:self.v_off], self.pred_a.w, self.p_a, self.na_rows, bias=self.pred_a.b)       # :634
         ops.gemm_nt(self.dn[self.v_off:], self.pred_v.w, self.p_v, self.nv_rows, bias=self.pred_v.b)       # :635
-        ops.mae_loss_fwd(self.p_a, audio, self.mask_a.view(-1), self.rl_a, self.losses[0:1], True, La, self.nmask_a)
-        ops.mae_loss_fwd(self.p_v, self.imgs, self.mask_v.view(-1), self.rl_v, self.losses[1:2], False, Lv, self.nmask_v)
-        torch.add(self.losses[0:1], self.losses[1:2], out=self.losses[2:3])                                 # :707
+        ops.mae_loss_fwd(self.p_a, audio, self.mask_a.view(-1), self.rl_a, self.losses[0:1], True, La, self.nmask_a,
+                         total=self.losses[2:3], total_init=True)
+        ops.mae_loss_fwd(self.p_v, self.imgs, self.mask_v.view(-1), self.rl_v, self.losses[1:2], False, Lv, self.nmask_v,
+                         total=self.losses[2:3], total_init=False)                                          # loss_mae = a + v (:707)
         return self.losses[2:3], self.losses[0:1], self.losses[1:2], self.mask_a, self.mask_v
 
     def backward(self, gout):

@@ -76,8 +76,8 @@ class _HotPath(torch.autograd.Function):
             eng = model._engine("contrastive", B)
             if plan_c is None:
                 eng.draw_device(model._next_seed(), model._np_rng())
-            nce, acc = eng.forward(audio, imgs, plan_c)
-            out.update(loss_c=nce * contrast_w, c_acc=acc.clone())
+            lc, acc = eng.forward(audio, imgs, plan_c, contrast_w)        # lc = contrast_loss_weight * nce (:735), from the kernel
+            out.update(loss_c=lc.clone(), c_acc=acc.clone())
         else:
             out.update(loss_c=zero.clone(), c_acc=zero.clone())
         ctx.batch = B

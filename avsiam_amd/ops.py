@@ -282,8 +282,9 @@ def segment_mean_bwd(dreps, seg_start, dy, nseg, scale=1.0):
     _lib.call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], float(scale), _stream())
 
 
-def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask):
+def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, total_init=True):
     _chk(pred, F32, "mae.pred", 2); _chk(inp, F32, "mae.inp"); _chk(mask, F32, "mae.mask"); _chk(row_loss, F32, "mae.row_loss"); _chk(loss, F32, "mae.loss")
+    _chk(total, F32, "mae.total")
     rows = mask.numel()
     if audio:
         C, H, W = 1, inp.shape[1], inp.shape[2]          # [B, time, mel]
@@ -292,7 +293,8 @@ def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask):
         C, H, W = inp.shape[-3:]
         assert rows == inp.numel() // (C * H * W) * L and pred.shape[1] == 256 * C and (H // 16) * (W // 16) == L
     assert pred.shape[0] >= rows and row_loss.numel() >= rows
-    _lib.call("avs_mae_loss_fwd", pred, inp, mask, row_loss, loss, rows, int(audio), L, C, H, W, float(nmask), _stream())
+    _lib.call("avs_mae_loss_fwd", pred, inp, mask, row_loss, loss, total, int(bool(total_init)), rows, int(audio), L, C, H, W,
+              float(nmask), _stream())
 
 
 def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask):
@@ -328,11 +330,12 @@ def gemm_f32_small(A, B, C, M, N, K, sa, sb, alpha=1.0):
     _lib.call("avs_gemm_f32_small", A, sa[0], sa[1], B, sb[0], sb[1], C, C.stride(0), M, N, K, float(alpha), _stream())
 
 
-def infonce_fwd(total, stats, out):
+def infonce_fwd(total, stats, out, weight=1.0):
+    """out = {nce, c_acc, weight * nce}"""
     _chk(total, F32, "nce.total", 2); _chk(stats, F32, "nce.stats", 2); _chk(out, F32, "nce.out")
     N = total.shape[0]
-    assert total.shape[1] == N and stats.shape == (N, 4) and out.numel() >= 2
-    _lib.call("avs_infonce_fwd", total, stats, out, N, _stream())
+    assert total.shape[1] == N and stats.shape == (N, 4) and out.numel() >= 3
+    _lib.call("avs_infonce_fwd", total, stats, out, N, float(weight), _stream())
 
 
 def infonce_dlogits(total, stats, gout, weight, dtotal):

@@ -99,8 +99,9 @@ int avs_segment_mean_bwd(const float* dreps, const int* seg_start, float* dy, in
                          avs_stream_t stream);
 
 /* ---- masked-MSE with patchify on the fly (patchify + forward_mae_loss, cav_mae_base.py:343-351,663-683) */
-int avs_mae_loss_fwd(const float* pred, const float* inp, const float* mask, float* row_loss, float* loss, int rows,
-                     int audio, int L, int C, int H, int W, float nmask, avs_stream_t stream);
+/* loss[0] = masked mean; total (may be NULL): total[0] = (total_init ? 0 : total[0]) + loss[0]  (loss_mae = a + v, :707) */
+int avs_mae_loss_fwd(const float* pred, const float* inp, const float* mask, float* row_loss, float* loss, float* total,
+                     int total_init, int rows, int audio, int L, int C, int H, int W, float nmask, avs_stream_t stream);
 int avs_mae_loss_bwd(const float* pred, const float* inp, const float* mask, const float* gout, avs_bf16* dpred, int rows,
                      int audio, int L, int C, int H, int W, float nmask, avs_stream_t stream);
 
@@ -110,7 +111,8 @@ int avs_l2norm_bwd(const float* dxn, const float* xn, const float* norm, float* 
                    avs_stream_t stream);
 int avs_gemm_f32_small(const float* A, long long sam, long long sak, const float* B, long long sbk, long long sbn, float* C,
                        long long scm, int M, int N, int K, float alpha, avs_stream_t stream);
-int avs_infonce_fwd(const float* total, float* stats, float* out, int N, avs_stream_t stream);
+/* out = {nce, c_acc, weight * nce} */
+int avs_infonce_fwd(const float* total, float* stats, float* out, int N, float weight, avs_stream_t stream);
 int avs_infonce_dlogits(const float* total, const float* stats, const float* gout, float weight, float* dtotal, int N,
                         avs_stream_t stream);
 

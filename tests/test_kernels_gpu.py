@@ -315,7 +315,9 @@ def test_mae_loss(audio):
     mask = (torch.rand(B * L, device=DEV) > 0.25).float()
     row_loss = torch.empty(B * L, device=DEV); loss = torch.empty(1, device=DEV)
     nmask = float(mask.sum().item())
-    o.mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask)
+    tot = torch.full((1,), 5.0, device=DEV)
+    o.mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=tot, total_init=False)
+    assert abs(tot.item() - 5.0 - loss.item()) < 1e-5
     pr = pred.cpu().reshape(B, L, P).requires_grad_(True)
     ref = ref_cpu.mae_loss(cfg, inp.cpu(), pr, mask.cpu().reshape(B, L), 'a' if audio else 'v')
     assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
@@ -337,8 +339,9 @@ def test_infonce(N):
     o.l2norm_fwd(a, an, na); o.l2norm_fwd(v, vn, nv)
     total = torch.empty(N, N, device=DEV)
     o.gemm_f32_small(an, vn, total, N, N, D, (D, 1), (1, D), 1 / 0.05)
-    stats = torch.empty(N, 4, device=DEV); out = torch.empty(2, device=DEV)
-    o.infonce_fwd(total, stats, out)
+    stats = torch.empty(N, 4, device=DEV); out = torch.empty(3, device=DEV)
+    o.infonce_fwd(total, stats, out, 0.01)
+    assert abs(out[2].item() - 0.01 * out[0].item()) < 1e-7
     ar, vr = a.cpu().double().requires_grad_(True), v.cpu().double().requires_grad_(True)
     nce, acc, tot = ref_cpu.contrastive(ar, vr)
     assert rel_err(total.cpu(), tot.detach()) < 1e-5
