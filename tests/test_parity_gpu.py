@@ -171,3 +171,24 @@ def test_device_drawn_plan_matches_oracle(which, B, T, La):
     else:
         assert any(not torch.equal(x, y) for x, y in zip(plan.a_keep, plan2.a_keep) if x.numel() == y.numel() and x.numel() < 512) or \
             not torch.equal(plan.a_group, plan2.a_group)
+
+
+@pytest.mark.parametrize("which", ["mae", "contrastive"])
+def test_vit_large_matches_oracle(which):
+    """BASELINE.json configs[3] family: ViT-L/16 (D=1024, 24 layers, 16 heads), here at a small shape (2 frames, 128 audio
+    tokens, batch 2).  No reference source exists for it: the oracle is the pin."""
+    from avsiam_amd.config import vit_large
+    import random
+    cfg = vit_large(audio_tokens=128, frames=2)
+    B = 2
+    a, v = synth_inputs(cfg, B, 17)
+    gen = torch.Generator().manual_seed(3)
+    mae = which == "mae"
+    plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(3))
+    m = _model(cfg, 99)
+    out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
+    out[0].backward()
+    ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 99)
+    for i in (0, 1, 2, 3, 4):
+        assert abs(out[i].item() - ref[i].item()) <= 2e-2 * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+    _compare_grads(m, rgrads, cos_min=0.985)
