@@ -61,6 +61,7 @@ class ParamArena:
                 toff += (math.prod(s.shape) + ALIGN - 1) // ALIGN * ALIGN
         self.t_total = toff
         self.p = torch.zeros(self.total, dtype=torch.float32)
+        self._tr_tables = {}
         self.g = None
         self.pb = None
         self.wt = None
@@ -74,6 +75,7 @@ class ParamArena:
 
     def to(self, device):
         self.p = self.p.to(device)
+        self._tr_tables = {}
         if self.p.is_cuda:
             self.g = torch.zeros(self.live_end, dtype=torch.float32, device=device)
             self.pb = torch.zeros(self.live_end, dtype=torch.bfloat16, device=device)
@@ -121,15 +123,35 @@ class ParamArena:
         return self.wt[o:o + n].view(n // s.shape[0], s.shape[0])
 
     # ----- shadows / optimizer -------------------------------------------------------------------
+    def _transpose_table(self, which):
+        """Descriptor table (built once per device placement) for the batched transpose of every [N,K] -> [K,N] copy
+        in the live range of pass `which`."""
+        key = which
+        if key not in self._tr_tables:
+            lo, hi = (self.range[P1][0], self.live_end) if which is None else self.range[which]
+            rows, tmap, t0 = [], [], 0
+            for i, name in enumerate(n for n in self.t_offset if lo <= self.offset[n] < hi):
+                src, dst = self.wb(name), self.wtb(name)
+                R, C = src.shape
+                assert dst.shape == (C, R) and src.is_contiguous() and dst.is_contiguous()
+                tpr, ntl = (C + 63) // 64, ((C + 63) // 64) * ((R + 63) // 64)
+                rows.append([src.data_ptr(), dst.data_ptr(), R, C, t0, tpr])
+                tmap += [i] * ntl
+                t0 += ntl
+            dev = self.p.device
+            self._tr_tables[key] = (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(tmap, dtype=torch.int32, device=dev), t0)
+        return self._tr_tables[key]
+
     def refresh_shadows(self, which=None, cast=True):
-        """fp32 master -> bf16 shadow (+ transposed copies) for the live range of pass `which` (None: all)."""
+        """fp32 master -> bf16 shadow (+ transposed copies, ONE batched launch) for the live range of pass `which`
+        (None: all)."""
         from . import ops
         lo, hi = (self.range[P1][0], self.live_end) if which is None else self.range[which]
         if cast:
             ops.cast_bf16(self.p[lo:hi], self.pb[lo:hi], hi - lo)
-        for name in self.t_offset:
-            if lo <= self.offset[name] < hi:
-                ops.transpose_bf16(self.wb(name), self.wtb(name))
+        desc, tmap, ntiles = self._transpose_table(which)
+        if ntiles:
+            ops.transpose_batched(desc, tmap, ntiles)
 
     def zero_grad_range(self, which):
         lo, hi = self.range[which]

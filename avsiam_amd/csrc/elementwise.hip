@@ -187,6 +187,27 @@ __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __r
     }
 }
 
+// Batched form: one launch transposes every weight of a pass.  desc[m] = {src, dst, R, C, first_tile, tiles_per_row}
+// (int64 x 6); tile_map[b] = matrix of workgroup b.
+__global__ void transpose_batched_kernel(const long long* __restrict__ desc, const int* __restrict__ tile_map) {
+    __shared__ bf16_t tile[64][66];
+    const long long* d = desc + (size_t)tile_map[blockIdx.x] * 6;
+    const bf16_t* in = reinterpret_cast<const bf16_t*>(d[0]);
+    bf16_t* out = reinterpret_cast<bf16_t*>(d[1]);
+    const int R = (int)d[2], C = (int)d[3];
+    const int local = blockIdx.x - (int)d[4], tpr = (int)d[5];
+    const int c0 = (local % tpr) * 64, r0 = (local / tpr) * 64;
+    for (int i = threadIdx.y; i < 64; i += blockDim.y) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < C) ? in[(size_t)r * C + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 64; i += blockDim.y) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < C && r < R) out[(size_t)c * R + r] = tile[threadIdx.x][i];
+    }
+}
+
 __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
     const size_t n4 = n / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -316,6 +337,13 @@ extern "C" int avs_transpose_bf16(const bf16_t* in, bf16_t* out, int R, int C, h
     AVS_CHECK_ARG(R > 0 && C > 0 && in && out, "transpose: bad args");
     transpose_bf16_kernel<<<dim3(ceil_div(C, 64), ceil_div(R, 64)), dim3(64, 4), 0, stream>>>(in, out, R, C);
     AVS_LAUNCH_CHECK("transpose");
+    return 0;
+}
+
+extern "C" int avs_transpose_batched(const long long* desc, const int* tile_map, int ntiles, hipStream_t stream) {
+    AVS_CHECK_ARG(desc && tile_map && ntiles > 0, "transpose_batched: bad args");
+    transpose_batched_kernel<<<ntiles, dim3(64, 4), 0, stream>>>(desc, tile_map);
+    AVS_LAUNCH_CHECK("transpose_batched");
     return 0;
 }
 

@@ -351,6 +351,13 @@ def transpose_bf16(x, out):
     _lib.call("avs_transpose_bf16", x, out, x.shape[0], x.shape[1], _stream())
 
 
+def transpose_batched(desc, tile_map, ntiles):
+    """desc: int64 [nmat, 6] on the device, built (and bounds-checked) by ParamArena from its own views."""
+    _chk(desc, torch.int64, "trb.desc", 2); _chk(tile_map, I32, "trb.map")
+    assert desc.shape[1] == 6 and tile_map.numel() == ntiles
+    _lib.call("avs_transpose_batched", desc, tile_map, ntiles, _stream())
+
+
 def cast_bf16(x, y, n):
     _chk(x, F32, "castb.x"); _chk(y, BF16, "castb.y")
     assert x.numel() >= n and y.numel() >= n

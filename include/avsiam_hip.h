@@ -119,6 +119,9 @@ int avs_infonce_dlogits(const float* total, const float* stats, const float* gou
 /* ---- weights: bf16 shadow copies and the fused Adam step (torch.optim.Adam as built at
  * src/traintest_cavmae_base.py:64-66) */
 int avs_transpose_bf16(const avs_bf16* in, avs_bf16* out, int R, int C, avs_stream_t stream);
+/* one launch for many matrices: desc = nmat x {src, dst, R, C, first_tile, tiles_per_row} (int64), tile_map[b] = matrix of
+ * workgroup b, ntiles = sum of ceil(R/64)*ceil(C/64) */
+int avs_transpose_batched(const long long* desc, const int* tile_map, int ntiles, avs_stream_t stream);
 int avs_cast_bf16(const float* x, avs_bf16* y, long long n, avs_stream_t stream);
 int avs_adam(float* p, const float* g, float* m, float* v, avs_bf16* p_bf16, long long n, float lr, float beta1,
              float beta2, float eps, float weight_decay, int step, float grad_scale, avs_stream_t stream);
