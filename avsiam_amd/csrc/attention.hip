@@ -60,31 +60,31 @@ __device__ __forceinline__ bf16x8 acc_frag(const float* v) {
 // Staging a [64][HD] tile is split (issue early / write late): tile_load puts the next tile's global loads in flight
 // before the current tile's MFMA work, tile_store writes them into the LDS image after the barrier that retires the
 // previous tile's reads - the HBM/L2 latency hides under the compute instead of being paid per tile.
-template <int HD>
+template <int HD, int NTH>
 struct TileRegs {
     static constexpr int NCH = HD / 8;
-    static constexpr int PER = 64 * NCH / 256;
+    static constexpr int PER = 64 * NCH / NTH;
     uint4 v[PER];
 };
 
-template <int HD>
-__device__ __forceinline__ void tile_load(TileRegs<HD>& t, const bf16_t* src, long long ld, int row0, int last_row, int tid) {
+template <int HD, int NTH>
+__device__ __forceinline__ void tile_load(TileRegs<HD, NTH>& t, const bf16_t* src, long long ld, int row0, int last_row, int tid) {
     constexpr int NCH = HD / 8;
 #pragma unroll
-    for (int i = 0; i < TileRegs<HD>::PER; ++i) {
-        const int c = i * 256 + tid;
+    for (int i = 0; i < TileRegs<HD, NTH>::PER; ++i) {
+        const int c = i * NTH + tid;
         const int row = c / NCH, ch = c % NCH;
         const int gr = min(row0 + row, last_row);
         t.v[i] = *reinterpret_cast<const uint4*>(src + (size_t)gr * ld + ch * 8);
     }
 }
 
-template <int HD>
-__device__ __forceinline__ void tile_store(const TileRegs<HD>& t, char* tile, int tid) {
+template <int HD, int NTH>
+__device__ __forceinline__ void tile_store(const TileRegs<HD, NTH>& t, char* tile, int tid) {
     constexpr int NCH = HD / 8;
 #pragma unroll
-    for (int i = 0; i < TileRegs<HD>::PER; ++i) {
-        const int c = i * 256 + tid;
+    for (int i = 0; i < TileRegs<HD, NTH>::PER; ++i) {
+        const int c = i * NTH + tid;
         *reinterpret_cast<uint4*>(tile + Img<HD>::off(c / NCH, c % NCH)) = t.v[i];
     }
 }
@@ -95,7 +95,7 @@ struct AttnArgs {
     const bf16_t* qkv; long long ld; int D;     // [rows, 3*D]: q | k | v, head h at columns h*HD
     const int* tile_start;                      // first packed row of the tile's sequence
     const int* tile_len;                        // length of that sequence
-    const int* tile_q0;                         // first row (within the sequence) of this 128-row tile
+    const int* tile_q0;                         // first row (within the sequence) of this (32 * waves)-row tile
     int ntiles;
     bf16_t* out; long long ldo;                 // fwd: attention output [rows, D]
     float* lse; int rows_total;                 // [H][rows_total] natural-log sum-exp of the scaled scores
@@ -106,8 +106,9 @@ struct AttnArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int NTH = 64 * NW;
     constexpr int NKK = HD / 16, NDB = HD / 32;
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2];
     char* sK = smem;
@@ -135,17 +136,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    TileRegs<HD> rk, rv;
-    tile_load<HD>(rk, base + a.D, a.ld, 0, L - 1, tid);
-    tile_load<HD>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
+    TileRegs<HD, NTH> rk, rv;
+    tile_load<HD, NTH>(rk, base + a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
     for (int k0 = 0; k0 < L; k0 += 64) {
         __syncthreads();
-        tile_store<HD>(rk, sK, tid);
-        tile_store<HD>(rv, sV, tid);
+        tile_store<HD, NTH>(rk, sK, tid);
+        tile_store<HD, NTH>(rv, sV, tid);
         __syncthreads();
         if (k0 + 64 < L) {
-            tile_load<HD>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
-            tile_load<HD>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
         }
         if (!active) continue;
         f32x16 s[2];
@@ -223,8 +224,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // dQ (query-major).  Also produces delta = rowsum(dO * O), reused by the dK/dV kernel.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
+    constexpr int NTH = 64 * NW;
     constexpr int NKK = HD / 16, NDB = HD / 32;
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2];
     char* sK = smem;
@@ -261,17 +263,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
-    TileRegs<HD> rk, rv;
-    tile_load<HD>(rk, base + a.D, a.ld, 0, L - 1, tid);
-    tile_load<HD>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
+    TileRegs<HD, NTH> rk, rv;
+    tile_load<HD, NTH>(rk, base + a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
     for (int k0 = 0; k0 < L; k0 += 64) {
         __syncthreads();
-        tile_store<HD>(rk, sK, tid);
-        tile_store<HD>(rv, sV, tid);
+        tile_store<HD, NTH>(rk, sK, tid);
+        tile_store<HD, NTH>(rv, sV, tid);
         __syncthreads();
         if (k0 + 64 < L) {
-            tile_load<HD>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
-            tile_load<HD>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
         }
         if (!active) continue;
         const bool tail_tile = k0 + 64 > L;                 // block-uniform
@@ -326,8 +328,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // dK, dV (key-major): each wave owns 32 keys (the lane) and walks the query rows of the sequence.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
+    constexpr int NTH = 64 * NW;
     constexpr int NKK = HD / 16, NDB = HD / 32;
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 2 * 64 * 4];
     char* sQ = smem;
@@ -361,20 +364,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const bf16_t* dobase = a.dout + (size_t)seq0 * a.ldo + head * HD;
     const float* lsebase = a.lse + (size_t)head * a.rows_total + seq0;
     const float* delbase = a.delta + (size_t)head * a.rows_total + seq0;
-    TileRegs<HD> rq, rdo;
+    TileRegs<HD, NTH> rq, rdo;
     float rl = 0.f, rd = 0.f;
-    tile_load<HD>(rq, base, a.ld, 0, L - 1, tid);
-    tile_load<HD>(rdo, dobase, a.ldo, 0, L - 1, tid);
+    tile_load<HD, NTH>(rq, base, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH>(rdo, dobase, a.ldo, 0, L - 1, tid);
     if (tid < 64) { rl = lsebase[min(tid, L - 1)]; rd = delbase[min(tid, L - 1)]; }
     for (int q0 = 0; q0 < L; q0 += 64) {
         __syncthreads();
-        tile_store<HD>(rq, sQ, tid);
-        tile_store<HD>(rdo, sDO, tid);
+        tile_store<HD, NTH>(rq, sQ, tid);
+        tile_store<HD, NTH>(rdo, sDO, tid);
         if (tid < 64) { sLse[tid] = rl * 1.4426950408889634f; sDel[tid] = rd; }
         __syncthreads();
         if (q0 + 64 < L) {
-            tile_load<HD>(rq, base, a.ld, q0 + 64, L - 1, tid);
-            tile_load<HD>(rdo, dobase, a.ldo, q0 + 64, L - 1, tid);
+            tile_load<HD, NTH>(rq, base, a.ld, q0 + 64, L - 1, tid);
+            tile_load<HD, NTH>(rdo, dobase, a.ldo, q0 + 64, L - 1, tid);
             if (tid < 64) { rl = lsebase[min(q0 + 64 + tid, L - 1)]; rd = delbase[min(q0 + 64 + tid, L - 1)]; }
         }
         if (!active) continue;
@@ -455,33 +458,50 @@ static int check_common(const char* name, const void* qkv, long long ld, int D, 
 }
 
 extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
-                            const int* tile_q0, int ntiles, bf16_t* out, long long ldo, float* lse, int rows_total,
+                            const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
                             hipStream_t stream) {
+    AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_fwd: tile_rows must be 64 or 128");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_fwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && lse && (ldo % 4) == 0, "attn_fwd: null output");
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd)};
     dim3 grid(ntiles * H);
-    if (hd == 64) attn_fwd_kernel<64><<<grid, 256, 0, stream>>>(a);
-    else attn_fwd_kernel<32><<<grid, 256, 0, stream>>>(a);
+    if (tile_rows == 128) {
+        if (hd == 64) attn_fwd_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
+        else attn_fwd_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
+    } else {
+        if (hd == 64) attn_fwd_kernel<64, 2><<<grid, 128, 0, stream>>>(a);
+        else attn_fwd_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
+    }
     AVS_LAUNCH_CHECK("attn_fwd");
     return 0;
 }
 
 extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
-                            const int* tile_q0, int ntiles, const bf16_t* out, const bf16_t* dout, long long ldo,
+                            const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
                             const float* lse, float* delta, int rows_total, bf16_t* dqkv, hipStream_t stream) {
+    AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_bwd: tile_rows must be 64 or 128");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
                dout, delta, dqkv, 1.0f / sqrtf((float)hd)};
     dim3 grid(ntiles * H);
-    if (hd == 64) attn_bwd_dq_kernel<64><<<grid, 256, 0, stream>>>(a);
-    else attn_bwd_dq_kernel<32><<<grid, 256, 0, stream>>>(a);
+    if (tile_rows == 128) {
+        if (hd == 64) attn_bwd_dq_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
+        else attn_bwd_dq_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
+    } else {
+        if (hd == 64) attn_bwd_dq_kernel<64, 2><<<grid, 128, 0, stream>>>(a);
+        else attn_bwd_dq_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
+    }
     AVS_LAUNCH_CHECK("attn_bwd_dq");
-    if (hd == 64) attn_bwd_dkv_kernel<64><<<grid, 256, 0, stream>>>(a);
-    else attn_bwd_dkv_kernel<32><<<grid, 256, 0, stream>>>(a);
+    if (tile_rows == 128) {
+        if (hd == 64) attn_bwd_dkv_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
+        else attn_bwd_dkv_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
+    } else {
+        if (hd == 64) attn_bwd_dkv_kernel<64, 2><<<grid, 128, 0, stream>>>(a);
+        else attn_bwd_dkv_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
+    }
     AVS_LAUNCH_CHECK("attn_bwd_dkv");
     return 0;
 }

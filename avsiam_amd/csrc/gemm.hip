@@ -27,7 +27,6 @@ struct GemmNtArgs {
     const bf16_t* aux; long long ldaux;
     void* out; long long ldo; int out_f32;
     bf16_t* out2; long long ldo2;
-    int debug;                               // tuning aid (AVSIAM_GEMM_DEBUG): bit0 = skip the epilogue's global stores (timing only)
     float alpha; int act;                    // 0 none | 1 gelu (out = pre-activation, out2 = gelu) | 2 gelu-backward (aux = pre-activation)
 };
 
@@ -41,12 +40,6 @@ struct GemmNtArgs {
 //   bf16 output: row = i*8 + lane/8,  8 columns (lane%8)*8         -> dwordx4 stores, 128-B row segments
 // Residual reads (fp32) and the GELU' operand read (bf16) use the same ownership, i.e. are 16 B per lane as well.
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-
-template <typename T>
-__device__ __forceinline__ void st_out(T* p, T v, int nt) {
-    if (nt) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
 
 __device__ __forceinline__ void epi_apply4(const GemmNtArgs& a, int ACT, float (&v)[4], const float4& bias4, uint2 p,
                                            const float* resp) {
@@ -99,12 +92,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     const int rr = i * 4 + rq;
                     const float4 t = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
                     const int m = mw0 + mi * 16 + rr;
-                    if (m >= a.M || (a.debug & 1)) continue;
+                    if (m >= a.M) continue;
                     float v[4] = {t.x, t.y, t.z, t.w};
                     uint2 ax = make_uint2(0, 0);
                     if (ACT == 2) ax = *reinterpret_cast<const uint2*>(a.aux + (size_t)m * a.ldaux + n);
                     epi_apply4(a, ACT, v, bias4, ax, a.res ? &rs[mj][i].x : nullptr);
-                    st_out(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n), f32x4{v[0], v[1], v[2], v[3]}, a.debug & 2);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
                     if (ACT == 1) {
                         uint2 o;
                         o.x = pack_bf2(gelu_erf(v[0]), gelu_erf(v[1]));
@@ -143,7 +136,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 const float4 t0 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
                 const float4 t1 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc + 4);
                 const int m = mw0 + mi * 16 + rr;
-                if (m >= a.M || (a.debug & 1)) continue;
+                if (m >= a.M) continue;
                 float v0[4] = {t0.x, t0.y, t0.z, t0.w}, v1[4] = {t1.x, t1.y, t1.z, t1.w};
                 const long long rrow = a.res ? (a.res_idx ? (long long)a.res_idx[m] : (long long)m) : 0;
                 uint4 ax = make_uint4(0, 0, 0, 0);
@@ -154,12 +147,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 uint4 o;
                 o.x = pack_bf2(v0[0], v0[1]); o.y = pack_bf2(v0[2], v0[3]);
                 o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
-                st_out(reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n), u32x4{o.x, o.y, o.z, o.w}, a.debug & 2);
+                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = u32x4{o.x, o.y, o.z, o.w};
                 if (ACT == 1) {
                     uint4 g;
                     g.x = pack_bf2(gelu_erf(v0[0]), gelu_erf(v0[1])); g.y = pack_bf2(gelu_erf(v0[2]), gelu_erf(v0[3]));
                     g.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); g.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
-                    st_out(reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n), u32x4{g.x, g.y, g.z, g.w}, a.debug & 2);
+                    *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = u32x4{g.x, g.y, g.z, g.w};
                 }
             }
         }
@@ -452,9 +445,7 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (!out2 || (ldo2 % 8) == 0) && (!aux || (ldaux % 8) == 0),
                   "gemm_nt: leading dimensions must keep 16-byte alignment");
     AVS_CHECK_ARG(act >= 0 && act <= 2 && (act != 1 || out2) && (act != 2 || aux), "gemm_nt: bad activation arguments");
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("AVSIAM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
-    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, dbg, alpha, act};
+    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;

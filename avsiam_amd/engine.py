@@ -16,8 +16,6 @@ MI355X-first restructuring of ``CAVMAE_BASE.forward`` (/root/reference/src/model
 
 The mask plan (which tokens each sample keeps) is an explicit input - see maskplan.py.
 """
-import math
-
 import numpy as np
 import torch
 
@@ -25,7 +23,6 @@ from . import ops
 from .arena import ParamArena
 from .config import AVSiamConfig
 from .maskplan import ContrastivePlan, MaePlan, group_sizes, group_ratio, len_keep
-from .param_spec import P1, P2
 
 BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
 LN_EPS_BLOCK, LN_EPS_FINAL = 1e-5, 1e-6       # nn.LayerNorm default in Block; timm ViT final norm

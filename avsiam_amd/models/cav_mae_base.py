@@ -28,7 +28,7 @@ from .. import _lib
 from ..arena import ParamArena
 from ..config import AVSiamConfig
 from ..maskplan import ContrastivePlan, MaePlan, make_contrastive_plan, make_mae_plan
-from ..param_spec import P1, P2, alias_of, build_spec
+from ..param_spec import P1, P2, build_spec
 from ..weights import synth_state
 
 
@@ -44,11 +44,6 @@ def _attach(root, dotted, param):
             mod.add_module(p, _Holder())
         mod = mod._modules[p]
     mod.register_parameter(parts[-1], param)
-
-
-class _PassState:
-    def __init__(self):
-        self.zeroed = False
 
 
 class _HotPath(torch.autograd.Function):

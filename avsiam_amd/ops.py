@@ -146,13 +146,17 @@ def gemm_tn(A, B, C, M, splits=0):
 
 # ---------------------------------------------------------------------------------------------------
 class AttnTiles:
-    """(sequence start, length, q0) per 128-row tile for a packed batch of sequences."""
+    """(sequence start, length, q0) per tile of `tile_rows` (128 or 64) rows for a packed batch of sequences."""
 
-    def __init__(self, seq_lens, device, start_row=0):
+    def __init__(self, seq_lens, device, start_row=0, tile_rows=None):
         starts, lens, q0s = [], [], []
         row = start_row
+        if tile_rows is None:      # 128-row (4-wave) workgroups measured faster than 64-row ones at every length (tools/bench_attn.py)
+            tile_rows = 128
+        assert tile_rows in (64, 128)
+        self.tile_rows = tile_rows
         for L in seq_lens:
-            for q0 in range(0, L, 128):
+            for q0 in range(0, L, tile_rows):
                 starts.append(row); lens.append(L); q0s.append(q0)
             row += L
         self.rows = row - start_row
@@ -170,8 +174,8 @@ def attn_fwd(qkv, tiles, H, out, lse):
     assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64)
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row
     assert lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    _launch("attn_fwd", 4.0 * tiles.sum_sq * D, "avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, out, out.stride(0),
-              lse, lse.shape[1], _stream())
+    _launch("attn_fwd", 4.0 * tiles.sum_sq * D, "avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, out.stride(0),
+            lse, lse.shape[1], _stream())
 
 
 def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
@@ -180,8 +184,8 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
     D = qkv.shape[1] // 3
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    _launch("attn_bwd", 10.0 * tiles.sum_sq * D, "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, out, dout,
-              out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
+    _launch("attn_bwd", 10.0 * tiles.sum_sq * D, "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
+            out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
 
 
 # ---------------------------------------------------------------------------------------------------

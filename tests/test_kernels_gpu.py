@@ -147,15 +147,16 @@ def _attn_ref(qkv, lens, H):
     return torch.cat(outs)
 
 
+@pytest.mark.parametrize("tile_rows", [128, 64])
 @pytest.mark.parametrize("H,hd,lens", [(12, 64, [39, 128, 177, 512, 1, 65]), (16, 32, [708, 33, 200]), (2, 64, [300])])
-def test_attention_fwd_bwd(H, hd, lens):
+def test_attention_fwd_bwd(H, hd, lens, tile_rows):
     o = ops()
     D = H * hd
     rows = sum(lens)
     rp = o.pad_rows(rows)
     qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
     qkv[:rows] = bf(torch.randn(rows, 3 * D, device=DEV))
-    tiles = o.AttnTiles(lens, DEV)
+    tiles = o.AttnTiles(lens, DEV, tile_rows=tile_rows)
     out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
     lse = torch.zeros(H, rp, device=DEV)
     o.attn_fwd(qkv, tiles, H, out, lse)
