@@ -64,7 +64,7 @@ template <int HD, int NTH>
 struct TileRegs {
     static constexpr int NCH = HD / 8;
     static constexpr int PER = 64 * NCH / NTH;
-    uint4 v[PER];
+    f32x4 v[PER];
 };
 
 template <int HD, int NTH>
@@ -75,7 +75,7 @@ __device__ __forceinline__ void tile_load(TileRegs<HD, NTH>& t, const bf16_t* sr
         const int c = i * NTH + tid;
         const int row = c / NCH, ch = c % NCH;
         const int gr = min(row0 + row, last_row);
-        t.v[i] = *reinterpret_cast<const uint4*>(src + (size_t)gr * ld + ch * 8);
+        t.v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gr * ld + ch * 8);
     }
 }
 
@@ -85,7 +85,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<HD, NTH>& t, char* til
 #pragma unroll
     for (int i = 0; i < TileRegs<HD, NTH>::PER; ++i) {
         const int c = i * NTH + tid;
-        *reinterpret_cast<uint4*>(tile + Img<HD>::off(c / NCH, c % NCH)) = t.v[i];
+        *reinterpret_cast<f32x4*>(tile + Img<HD>::off(c / NCH, c % NCH)) = t.v[i];
     }
 }
 
