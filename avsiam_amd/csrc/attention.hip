@@ -16,6 +16,12 @@
 //     tile's rows;
 //   * backward recomputes P from the saved log-sum-exp (no N x N tensor), in two kernels: dQ (query-major, same
 //     shape as forward) and dK/dV (key-major), so no atomics and bitwise-reproducible gradients.
+//   * the softmax is VALU-bound at these head dims (per score: v_exp 8 issue cycles + 4 per plain VALU op, against
+//     32 MFMA cycles per 32x32x16 tile), so the per-score arithmetic is pushed into the MFMA's C operand: q arrives
+//     PRE-MULTIPLIED by hd^-0.5 * log2(e) (epilogue of the qkv GEMM, one bf16 rounding as before), the score
+//     accumulators start from -running_max (forward) / -lse (backward) and the dP accumulators from -delta, so the
+//     matrix core delivers exp2's argument and (dP - delta) directly.  Forward keeps a stale running max and only
+//     rescales when a tile exceeds it by 2^8 (exact: the final division and the saved lse use the same max).
 // Head dims 64 (encoder, 12 heads) and 32 (decoder, 16 heads).
 #include "common.h"
 #include <type_traits>
@@ -90,6 +96,7 @@ __device__ __forceinline__ void tile_store(const TileRegs<HD, NTH>& t, char* til
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float LN2 = 0.6931471805599453f;
 
 struct AttnArgs {
     const bf16_t* qkv; long long ld; int D;     // [rows, 3*D]: q | k | v, head h at columns h*HD
@@ -102,8 +109,16 @@ struct AttnArgs {
     const bf16_t* dout;                         // bwd: dO [rows, D] (ldo)
     float* delta;                               // bwd: rowsum(dO * O) [H][rows_total]
     bf16_t* dqkv;                               // bwd: [rows, 3*D] (ld)
-    float scale;                                // hd^-0.5
+    float scale;                                // hd^-0.5 (q columns of qkv hold q * scale * log2(e))
 };
+
+__device__ __forceinline__ f32x16 splat16(float v) {
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = v;
+    asm volatile("" : "+v"(t));                 // keep the 16 registers: they are an MFMA C operand, not a scalar to re-broadcast
+    return t;
+}
 
 // ---------------------------------------------------------------------------------------------------
 template <int HD, int NW>
@@ -123,7 +138,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const bool active = qw < L;
     const int q = min(qw + (lane & 31), L - 1);
     const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
-    const float sl2 = a.scale * 1.4426950408889634f;
 
     bf16x8 qf[NKK];
 #pragma unroll
@@ -134,7 +148,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    // scores are in log2 units (q is pre-scaled).  m_run is the reference point the accumulators start from; it trails
+    // the true running max by at most LAZY, so p = exp2(s - m_run) <= 2^LAZY and nothing is rescaled on most tiles.
+    constexpr float LAZY = 8.0f;
+    float m_run = 0.f, l_run = 0.f;
+    f32x16 negm = splat16(0.f);
 
     TileRegs<HD, NTH> rk, rv;
     tile_load<HD, NTH>(rk, base + a.D, a.ld, 0, L - 1, tid);
@@ -152,13 +170,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, 0, lane), qf[0], negm, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk)
+            for (int kk = 1; kk < NKK; ++kk)
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
         }
-        // running max is kept in RAW score units (sl2 > 0 keeps the order); only the last, partial key tile needs masking
         if (k0 + 64 > L) {
             // block-uniform branch; the empty asm keeps hipcc from if-converting the body into per-element selects that
             // every (full) tile would execute
@@ -169,30 +185,41 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r)
                     if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[kb][r] = -INFINITY;
         }
-        float mloc = -INFINITY;
+        float t = -INFINITY;                                   // tile max relative to m_run
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kb][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = fast_exp2((m_run - m_new) * sl2);
-        m_run = m_new;
-        const float nm = -m_new * sl2;
+            for (int r = 0; r < 16; ++r) t = fmaxf(t, s[kb][r]);
+        t = fmaxf(t, __shfl_xor(t, 32, 64));
+        if (k0 == 0 || __any(t > LAZY)) {
+            // wave-uniform and rare after the first tile: move the reference point to the new max
+            asm volatile("; softmax: new reference max" ::: "memory");
+            const float d = k0 == 0 ? t : fmaxf(t, 0.f);
+            if (k0 != 0) {
+                const float alpha = fast_exp2(-d);
+                l_run *= alpha;
+#pragma unroll
+                for (int dd = 0; dd < NDB; ++dd)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+            }
+            m_run += d;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= d;
+            negm = splat16(-m_run);
+        }
         float psum = 0.f;
         float p[2][16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[kb][r] = fast_exp2(fmaf(s[kb][r], sl2, nm));
+                p[kb][r] = fast_exp2(s[kb][r]);
                 psum += p[kb][r];
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        l_run += psum;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
                 w.y = pack_bf2(o[d][4 * t + 2] * inv, o[d][4 * t + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + d * 32 + 8 * t + 4 * hh) = w;
             }
-        if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run * sl2 + log2f(l_tot)) * 0.6931471805599453f;
+        if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
 }
 
@@ -241,7 +268,6 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     const bool active = qw < L;
     const int q = min(qw + (lane & 31), L - 1);
     const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
-    const float sl2 = a.scale * 1.4426950408889634f;
 
     bf16x8 qf[NKK], dof[NKK];
     float dpart = 0.f;
@@ -256,6 +282,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     const float delta = dpart + __shfl_xor(dpart, 32, 64);
     const float lse2 = a.lse[(size_t)head * a.rows_total + seq0 + q] * 1.4426950408889634f;
     if (active && hh == 0 && qw + (lane & 31) < L) a.delta[(size_t)head * a.rows_total + seq0 + q] = delta;
+    // the query is on the lane, so -lse and -delta are per-lane constants: as the accumulators' initial values they make
+    // the MFMAs deliver log2(p) and (dP - delta) with no VALU work
+    const f32x16 nlse = splat16(-lse2), ndel = splat16(-delta);
 
     f32x16 dq[NDB];
 #pragma unroll
@@ -278,11 +307,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
         if (!active) continue;
         const bool tail_tile = k0 + 64 > L;                 // block-uniform
         auto key_block = [&](int kb) {
-            f32x16 s, dp;
+            f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, 0, lane), qf[0], nlse, 0, 0, 0);
+            f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, kb * 32, 0, lane), dof[0], ndel, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
+            for (int kk = 1; kk < NKK; ++kk) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, kk, lane), qf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, kb * 32, kk, lane), dof[kk], dp, 0, 0, 0);
             }
@@ -296,8 +324,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pr = fast_exp2(fmaf(s[r], sl2, -lse2));
-                ds[r] = pr * (dp[r] - delta);
+                ds[r] = fast_exp2(s[r]) * dp[r];
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -347,7 +374,6 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     const bool active = kw < L;
     const int key = min(kw + (lane & 31), L - 1);
     const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
-    const float sl2 = a.scale * 1.4426950408889634f;
 
     bf16x8 kf[NKK], vf[NKK];
 #pragma unroll
@@ -373,7 +399,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
         __syncthreads();
         tile_store<HD, NTH>(rq, sQ, tid);
         tile_store<HD, NTH>(rdo, sDO, tid);
-        if (tid < 64) { sLse[tid] = rl * 1.4426950408889634f; sDel[tid] = rd; }
+        if (tid < 64) { sLse[tid] = -rl * 1.4426950408889634f; sDel[tid] = -rd; }    // negated: MFMA C operands
         __syncthreads();
         if (q0 + 64 < L) {
             tile_load<HD, NTH>(rq, base, a.ld, q0 + 64, L - 1, tid);
@@ -383,9 +409,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (!active) continue;
         const bool tail_tile = q0 + 64 > L;                 // block-uniform
         auto q_block = [&](int qb) {
+            // the query is on the accumulator ROWS here: -lse / -delta of the 16 rows this lane holds come straight from LDS
+            // into the C operands
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int t = 0; t < 4; ++t) {
+                const int rb = qb * 32 + 8 * t + 4 * hh;                 // rows rb..rb+3 of the staged tile
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + rb);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + rb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[4 * t + j] = l4[j]; dp[4 * t + j] = d4[j]; }
+            }
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, qb * 32, kk, lane), kf[kk], s, 0, 0, 0);
@@ -400,18 +434,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
             }
             float p[16], ds[16];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int rb = qb * 32 + 8 * t + 4 * hh;                 // rows rb..rb+3 of the staged tile
-                const float4 l4 = *reinterpret_cast<const float4*>(sLse + rb);
-                const float4 d4 = *reinterpret_cast<const float4*>(sDel + rb);
-                const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * t + j;
-                    const float pr = fast_exp2(fmaf(s[r], sl2, -ls[j]));
-                    p[r] = pr;
-                    ds[r] = pr * (dp[r] - dl[j]);
-                }
+            for (int r = 0; r < 16; ++r) {
+                p[r] = fast_exp2(s[r]);
+                ds[r] = p[r] * dp[r];
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -437,8 +462,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 uint2 w;
-                w.x = pack_bf2(dk[d][4 * t + 0] * a.scale, dk[d][4 * t + 1] * a.scale);
-                w.y = pack_bf2(dk[d][4 * t + 2] * a.scale, dk[d][4 * t + 3] * a.scale);
+                // dK = dS^T . (q * scale) and the staged q is q * scale * log2(e)
+                w.x = pack_bf2(dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2);
+                w.y = pack_bf2(dk[d][4 * t + 2] * LN2, dk[d][4 * t + 3] * LN2);
                 *reinterpret_cast<uint2*>(krow + d * 32 + 8 * t + 4 * hh) = w;
                 w.x = pack_bf2(dv[d][4 * t + 0], dv[d][4 * t + 1]);
                 w.y = pack_bf2(dv[d][4 * t + 2], dv[d][4 * t + 3]);

@@ -28,6 +28,7 @@ struct GemmNtArgs {
     void* out; long long ldo; int out_f32;
     bf16_t* out2; long long ldo2;
     float alpha; int act;                    // 0 none | 1 gelu (out = pre-activation, out2 = gelu) | 2 gelu-backward (aux = pre-activation)
+    int scale_cols; float col_scale;         // columns [0, scale_cols) are multiplied by col_scale as well (scale_cols % 64 == 0)
 };
 
 
@@ -41,7 +42,7 @@ struct GemmNtArgs {
 // Residual reads (fp32) and the GELU' operand read (bf16) use the same ownership, i.e. are 16 B per lane as well.
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-__device__ __forceinline__ void epi_apply4(const GemmNtArgs& a, int ACT, float (&v)[4], const float4& bias4, uint2 p,
+__device__ __forceinline__ void epi_apply4(float alpha, int ACT, float (&v)[4], const float4& bias4, uint2 p,
                                            const float* resp) {
     v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
     if (ACT == 2) {
@@ -54,13 +55,14 @@ __device__ __forceinline__ void epi_apply4(const GemmNtArgs& a, int ACT, float (
         const float4 r = *reinterpret_cast<const float4*>(resp);
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
     }
-    v[0] *= a.alpha; v[1] *= a.alpha; v[2] *= a.alpha; v[3] *= a.alpha;
+    v[0] *= alpha; v[1] *= alpha; v[2] *= alpha; v[3] *= alpha;
 }
 
 template <int ACT, int MI>
 __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], char* smem, int wave, int lane, int mw0, int nw0) {
     const int fr = lane & 15, fq = lane >> 4;
     float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    const float alpha = nw0 < a.scale_cols ? a.alpha * a.col_scale : a.alpha;      // wave-uniform (a wave owns 64 columns)
     if (a.out_f32) {
         const int cc = (lane & 15) * 4, rq = lane >> 4;
         const int n = nw0 + cc;
@@ -96,7 +98,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     float v[4] = {t.x, t.y, t.z, t.w};
                     uint2 ax = make_uint2(0, 0);
                     if (ACT == 2) ax = *reinterpret_cast<const uint2*>(a.aux + (size_t)m * a.ldaux + n);
-                    epi_apply4(a, ACT, v, bias4, ax, a.res ? &rs[mj][i].x : nullptr);
+                    epi_apply4(alpha, ACT, v, bias4, ax, a.res ? &rs[mj][i].x : nullptr);
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
                     if (ACT == 1) {
                         uint2 o;
@@ -142,8 +144,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 uint4 ax = make_uint4(0, 0, 0, 0);
                 if (ACT == 2) ax = axs[mi % GRP][i];
                 const float* resp = a.res ? a.res + rrow * a.ldr + n : nullptr;
-                epi_apply4(a, ACT, v0, bias_lo, make_uint2(ax.x, ax.y), resp);
-                epi_apply4(a, ACT, v1, bias_hi, make_uint2(ax.z, ax.w), resp ? resp + 4 : nullptr);
+                epi_apply4(alpha, ACT, v0, bias_lo, make_uint2(ax.x, ax.y), resp);
+                epi_apply4(alpha, ACT, v1, bias_hi, make_uint2(ax.z, ax.w), resp ? resp + 4 : nullptr);
                 uint4 o;
                 o.x = pack_bf2(v0[0], v0[1]); o.y = pack_bf2(v0[2], v0[3]);
                 o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
@@ -439,13 +441,14 @@ extern "C" int avs_gemm_set_tile(int tile) {
 extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
                                 const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
                                 long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
-                                float alpha, int act, hipStream_t stream) {
+                                float alpha, int act, int scale_cols, float col_scale, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % BN) == 0 && (K % BK) == 0, "gemm_nt: need N%%128==0, K%%64==0 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out, "gemm_nt: null operand");
     AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (!out2 || (ldo2 % 8) == 0) && (!aux || (ldaux % 8) == 0),
                   "gemm_nt: leading dimensions must keep 16-byte alignment");
     AVS_CHECK_ARG(act >= 0 && act <= 2 && (act != 1 || out2) && (act != 2 || aux), "gemm_nt: bad activation arguments");
-    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act};
+    AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
+    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;

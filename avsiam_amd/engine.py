@@ -87,6 +87,7 @@ class Stack:
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
         self.tiles = ops.AttnTiles(seq_lens, dev)
+        self.q_scale = ops.attn_q_scale(D // H)          # q leaves the qkv GEMM ready for the attention kernels
         self.x = [_z((rp, D), F32, dev) for _ in range(nblocks + 1)]     # x[i] = input of block i; x[-1] = output
         self.xmid = [_z((rp, D), F32, dev) for _ in range(nblocks)]
         self.ln1 = [_z((rp, D), BF16, dev) for _ in range(nblocks)]
@@ -116,7 +117,7 @@ class Stack:
         for i, bp in enumerate(blocks):
             x, st = self.x[i], self.stats[i]
             _ln_fwd(x, bp.n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
-            ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b)
+            ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale)
             ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i])
             ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x)
             _ln_fwd(self.xmid[i], bp.n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)

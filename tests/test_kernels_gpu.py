@@ -105,6 +105,14 @@ def test_gemm_nt_epilogues(M, N, K):
     res2 = torch.randn(M, N, device=DEV)
     o.gemm_nt(A, W, outf, M, bias=bias, res=res2)
     assert rel_err(outf, ref + bias.double() + res2.double()) < 1e-5
+    # column-ranged scale (q part of the qkv projection)
+    sc = (N // 128) * 64
+    o.gemm_nt(A, W, outf, M, bias=bias, scale_cols=sc, col_scale=0.25)
+    want = ref + bias.double()
+    want[:, :sc] *= 0.25
+    assert rel_err(outf, want) < 1e-5
+    o.gemm_nt(A, W, out, M, bias=bias, scale_cols=sc, col_scale=0.25)
+    assert rel_err(out, want) < 4e-3
     # gelu dual output
     pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
     act = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
@@ -155,12 +163,16 @@ def test_attention_fwd_bwd(H, hd, lens, tile_rows):
     rows = sum(lens)
     rp = o.pad_rows(rows)
     qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
-    qkv[:rows] = bf(torch.randn(rows, 3 * D, device=DEV))
+    x = torch.randn(rows, 3 * D, device=DEV)
+    x[:, :D] *= o.attn_q_scale(hd)              # the kernels take q pre-multiplied by hd^-0.5 * log2(e) (qkv GEMM epilogue)
+    qkv[:rows] = bf(x)
     tiles = o.AttnTiles(lens, DEV, tile_rows=tile_rows)
     out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
     lse = torch.zeros(H, rp, device=DEV)
     o.attn_fwd(qkv, tiles, H, out, lse)
-    qr = qkv[:rows].double().requires_grad_(True)
+    qr = qkv[:rows].double()
+    qr[:, :D] /= o.attn_q_scale(hd)             # the q the reference formula sees; dqkv is the gradient w.r.t. this q
+    qr.requires_grad_(True)
     ref = _attn_ref(qr, lens, H)
     assert rel_err(out[:rows], ref) < 6e-3
     dout = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
@@ -185,15 +197,23 @@ def test_attention_spiked_scores():
     x = torch.randn(L, 3 * D, device=DEV)
     x[150, D:2 * D] *= 8.0          # one late key dominates
     x[10, :D] *= 6.0
+    x[60:70, :D] *= -4.0            # rows whose first key tile is far BELOW the later maximum and far above others
+    x[:, :D] *= o.attn_q_scale(hd)
     qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
     qkv[:L] = bf(x)
     tiles = o.AttnTiles([L], DEV)
     out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
     lse = torch.zeros(H, rp, device=DEV)
     o.attn_fwd(qkv, tiles, H, out, lse)
-    ref = _attn_ref(qkv[:L].double(), [L], H)
+    qr = qkv[:L].double()
+    qr[:, :D] /= o.attn_q_scale(hd)
+    ref = _attn_ref(qr, [L], H)
     assert torch.isfinite(out.float()).all()
     assert rel_err(out[:L], ref) < 8e-3
+    # the saved log-sum-exp is exact whatever reference max the kernel happened to keep
+    q, k = qr[:, :D].reshape(L, H, hd), qr[:, D:2 * D].reshape(L, H, hd)
+    lse_ref = torch.logsumexp(torch.einsum("qhd,khd->hqk", q, k) * hd ** -0.5, dim=-1)
+    assert (lse[:, :L].double() - lse_ref).abs().max().item() < 2e-2
 
 
 def test_im2col_and_patch_embed_matches_conv():
