@@ -10,7 +10,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "avsiam_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libavsiam_hip.so")
+# AVSIAM_HIP_LIB: load another build of the same ABI (A/B kernel measurements on one box; see tools/ab_lib.sh)
+LIB_PATH = os.environ.get("AVSIAM_HIP_LIB") or os.path.join(_HERE, "csrc", "libavsiam_hip.so")
 
 _lib = None
 _protos = None

@@ -29,6 +29,7 @@ struct GemmNtArgs {
     bf16_t* out2; long long ldo2;
     float alpha; int act;                    // 0 none | 1 gelu (out = pre-activation, out2 = gelu) | 2 gelu-backward (aux = pre-activation)
     int scale_cols; float col_scale;         // columns [0, scale_cols) are multiplied by col_scale as well (scale_cols % 64 == 0)
+    float* colsum;                           // bf16 output only: colsum[n] += sum_m out[m][n] (bias gradient of the layer that produced A)
 };
 
 
@@ -43,7 +44,7 @@ struct GemmNtArgs {
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 __device__ __forceinline__ void epi_apply4(float alpha, int ACT, float (&v)[4], const float4& bias4, uint2 p,
-                                           const float* resp) {
+                                           bool has_res, f32x4 r) {
     v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
     if (ACT == 2) {
         v[0] *= gelu_erf_grad(__uint_as_float(p.x << 16));
@@ -51,42 +52,72 @@ __device__ __forceinline__ void epi_apply4(float alpha, int ACT, float (&v)[4], 
         v[2] *= gelu_erf_grad(__uint_as_float(p.y << 16));
         v[3] *= gelu_erf_grad(__uint_as_float(p.y & 0xffff0000u));
     }
-    if (resp) {
-        const float4 r = *reinterpret_cast<const float4*>(resp);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-    }
+    if (has_res) { v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
     v[0] *= alpha; v[1] *= alpha; v[2] *= alpha; v[3] *= alpha;
 }
 
+// Operands the epilogue reads from HBM (fp32 residual rows / bf16 GELU' pre-activations) are loaded in groups that are
+// double-buffered in registers: a load in the epilogue is synchronous (its latency is paid by the one workgroup of the
+// CU), so group g+1 is in flight while group g is transposed and stored, and group 0 is issued by the caller BEFORE the
+// barrier / next-tile prefetch that precede the epilogue.
+template <int MI>
+struct EpiPrefetch {
+    static constexpr int RG = 1;                 // residual: 16 rows per group      (4 float4 per 16 rows -> 16 VGPRs / group)
+    static constexpr int AG = 4;                 // GELU' aux: 4 x 16 rows per group, single-buffered (32 VGPRs; a second
+                                                 // buffer spills next to the 128 accumulator registers and costs more than it hides)
+    f32x4 rs[2][RG][4];                          // [buffer][16-row block][row quad]   (ext vectors: HIP's float4/uint4
+    u32x4 ax[AG][2];                             //  structs in arrays end up in scratch)
+};
+
+template <int MI>
+__device__ __forceinline__ void epi_load_res(const GemmNtArgs& a, f32x4 (&rs)[EpiPrefetch<MI>::RG][4], int grp, int lane, int mw0, int nw0) {
+    const int n = nw0 + (lane & 15) * 4, rq = lane >> 4;
+#pragma unroll
+    for (int mj = 0; mj < EpiPrefetch<MI>::RG; ++mj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(mw0 + (grp * EpiPrefetch<MI>::RG + mj) * 16 + i * 4 + rq, a.M - 1);
+            const long long rrow = a.res_idx ? (long long)a.res_idx[m] : (long long)m;
+            rs[mj][i] = *reinterpret_cast<const f32x4*>(a.res + rrow * a.ldr + n);
+        }
+}
+
+template <int MI>
+__device__ __forceinline__ void epi_load_aux(const GemmNtArgs& a, u32x4 (&ax)[EpiPrefetch<MI>::AG][2], int grp, int lane, int mw0, int nw0) {
+    const int n = nw0 + (lane & 7) * 8, rq = lane >> 3;
+#pragma unroll
+    for (int mj = 0; mj < EpiPrefetch<MI>::AG; ++mj)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = min(mw0 + (grp * EpiPrefetch<MI>::AG + mj) * 16 + i * 8 + rq, a.M - 1);
+            ax[mj][i] = *reinterpret_cast<const u32x4*>(a.aux + (size_t)m * a.ldaux + n);
+        }
+}
+
+// group 0 of whatever this epilogue will read; called before the barrier that ends the main loop
 template <int ACT, int MI>
-__device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], char* smem, int wave, int lane, int mw0, int nw0) {
+__device__ __forceinline__ void nt_epilogue_prefetch(const GemmNtArgs& a, EpiPrefetch<MI>& pf, int lane, int mw0, int nw0) {
+    if (ACT == 0 && a.out_f32 && a.res) epi_load_res<MI>(a, pf.rs[0], 0, lane, mw0, nw0);
+}
+
+template <int ACT, int MI>
+__device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], EpiPrefetch<MI>& pf, char* smem, int wave, int lane,
+                                            int mw0, int nw0) {
     const int fr = lane & 15, fq = lane >> 4;
     float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
     const float alpha = nw0 < a.scale_cols ? a.alpha * a.col_scale : a.alpha;      // wave-uniform (a wave owns 64 columns)
-    if (a.out_f32) {
+    if (ACT == 0 && a.out_f32) {                                                   // fp32 output exists without activation only
         const int cc = (lane & 15) * 4, rq = lane >> 4;
         const int n = nw0 + cc;
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + n);
-        // The residual rows are read into registers half a sub-tile ahead of their use (one latency per half instead of
-        // one per row: a load in the epilogue is synchronous, a store is not).
-        constexpr int HALF = 2;                              // sub-tile rows are pre-read 2 x 16 at a time (32 VGPRs)
+        constexpr int RG = EpiPrefetch<MI>::RG, NG = MI / RG;
 #pragma unroll
-        for (int hf = 0; hf < MI / HALF; ++hf) {
-            float4 rs[HALF][4];
-            if (a.res) {
+        for (int g = 0; g < NG; ++g) {
+            if (a.res && g + 1 < NG) epi_load_res<MI>(a, pf.rs[(g + 1) & 1], g + 1, lane, mw0, nw0);
 #pragma unroll
-                for (int mj = 0; mj < HALF; ++mj)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int m = min(mw0 + (hf * HALF + mj) * 16 + i * 4 + rq, a.M - 1);
-                        const long long rrow = a.res_idx ? (long long)a.res_idx[m] : (long long)m;
-                        rs[mj][i] = *reinterpret_cast<const float4*>(a.res + rrow * a.ldr + n);
-                    }
-            }
-#pragma unroll
-            for (int mj = 0; mj < HALF; ++mj) {
-                const int mi = hf * HALF + mj;
+            for (int mj = 0; mj < RG; ++mj) {
+                const int mi = g * RG + mj;
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
 #pragma unroll
@@ -96,16 +127,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     const int m = mw0 + mi * 16 + rr;
                     if (m >= a.M) continue;
                     float v[4] = {t.x, t.y, t.z, t.w};
-                    uint2 ax = make_uint2(0, 0);
-                    if (ACT == 2) ax = *reinterpret_cast<const uint2*>(a.aux + (size_t)m * a.ldaux + n);
-                    epi_apply4(alpha, ACT, v, bias4, ax, a.res ? &rs[mj][i].x : nullptr);
+                    epi_apply4(alpha, 0, v, bias4, make_uint2(0, 0), a.res != nullptr, pf.rs[g & 1][mj][i]);
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
-                    if (ACT == 1) {
-                        uint2 o;
-                        o.x = pack_bf2(gelu_erf(v[0]), gelu_erf(v[1]));
-                        o.y = pack_bf2(gelu_erf(v[2]), gelu_erf(v[3]));
-                        *reinterpret_cast<uint2*>(a.out2 + (size_t)m * a.ldo2 + n) = o;
-                    }
                 }
             }
         }
@@ -117,45 +140,65 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
             bias_lo = *reinterpret_cast<const float4*>(a.bias + n);
             bias_hi = *reinterpret_cast<const float4*>(a.bias + n + 4);
         }
-        constexpr int GRP = 4;                               // GELU' operands are pre-read 4 x 16 rows at a time (32 VGPRs)
-        uint4 axs[GRP][2];
+        constexpr int AG = EpiPrefetch<MI>::AG, NG = MI / AG;
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            if (ACT == 2 && (mi % GRP) == 0) {
+        for (int g = 0; g < NG; ++g) {
+            if (ACT == 2) epi_load_aux<MI>(a, pf.ax, g, lane, mw0, nw0);
 #pragma unroll
-                for (int mj = 0; mj < GRP; ++mj)
+            for (int mj = 0; mj < AG; ++mj) {
+                const int mi = g * AG + mj;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int m = min(mw0 + (mi + mj) * 16 + i * 8 + rq, a.M - 1);
-                        axs[mj][i] = *reinterpret_cast<const uint4*>(a.aux + (size_t)m * a.ldaux + n);
+                for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int rr = i * 8 + rq;
+                    const float4 t0 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
+                    const float4 t1 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc + 4);
+                    const int m = mw0 + mi * 16 + rr;
+                    if (m >= a.M) continue;
+                    float v0[4] = {t0.x, t0.y, t0.z, t0.w}, v1[4] = {t1.x, t1.y, t1.z, t1.w};
+                    const long long rrow = a.res ? (a.res_idx ? (long long)a.res_idx[m] : (long long)m) : 0;
+                    u32x4 ax = {0, 0, 0, 0};
+                    if (ACT == 2) ax = pf.ax[mj][i];
+                    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+                    if (a.res) {
+                        r0 = *reinterpret_cast<const f32x4*>(a.res + rrow * a.ldr + n);
+                        r1 = *reinterpret_cast<const f32x4*>(a.res + rrow * a.ldr + n + 4);
                     }
-            }
+                    epi_apply4(alpha, ACT, v0, bias_lo, make_uint2(ax[0], ax[1]), a.res != nullptr, r0);
+                    epi_apply4(alpha, ACT, v1, bias_hi, make_uint2(ax[2], ax[3]), a.res != nullptr, r1);
+                    if (a.colsum) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rr = i * 8 + rq;
-                const float4 t0 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
-                const float4 t1 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc + 4);
-                const int m = mw0 + mi * 16 + rr;
-                if (m >= a.M) continue;
-                float v0[4] = {t0.x, t0.y, t0.z, t0.w}, v1[4] = {t1.x, t1.y, t1.z, t1.w};
-                const long long rrow = a.res ? (a.res_idx ? (long long)a.res_idx[m] : (long long)m) : 0;
-                uint4 ax = make_uint4(0, 0, 0, 0);
-                if (ACT == 2) ax = axs[mi % GRP][i];
-                const float* resp = a.res ? a.res + rrow * a.ldr + n : nullptr;
-                epi_apply4(alpha, ACT, v0, bias_lo, make_uint2(ax.x, ax.y), resp);
-                epi_apply4(alpha, ACT, v1, bias_hi, make_uint2(ax.z, ax.w), resp ? resp + 4 : nullptr);
-                uint4 o;
-                o.x = pack_bf2(v0[0], v0[1]); o.y = pack_bf2(v0[2], v0[3]);
-                o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
-                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = u32x4{o.x, o.y, o.z, o.w};
-                if (ACT == 1) {
-                    uint4 g;
-                    g.x = pack_bf2(gelu_erf(v0[0]), gelu_erf(v0[1])); g.y = pack_bf2(gelu_erf(v0[2]), gelu_erf(v0[3]));
-                    g.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); g.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
-                    *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = u32x4{g.x, g.y, g.z, g.w};
+                        for (int j = 0; j < 4; ++j) { cs[j] += v0[j]; cs[4 + j] += v1[j]; }
+                    }
+                    uint4 o;
+                    o.x = pack_bf2(v0[0], v0[1]); o.y = pack_bf2(v0[2], v0[3]);
+                    o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = u32x4{o.x, o.y, o.z, o.w};
+                    if (ACT == 1) {
+                        uint4 gq;
+                        gq.x = pack_bf2(gelu_erf(v0[0]), gelu_erf(v0[1])); gq.y = pack_bf2(gelu_erf(v0[2]), gelu_erf(v0[3]));
+                        gq.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); gq.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
+                        *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = u32x4{gq.x, gq.y, gq.z, gq.w};
+                    }
                 }
+            }
+        }
+        if (a.colsum) {
+            // lanes with the same (lane & 7) hold the same 8 columns for different rows: fold the 8 row groups, then one
+            // atomic per column and wave (fp32 atomics, like the weight gradients)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = cs[j];
+                t += __shfl_xor(t, 8, 64);
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                cs[j] = t;
+            }
+            if (rq == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(a.colsum + n + j, cs[j]);
             }
         }
     }
@@ -258,7 +301,9 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
             set_tile(v + gridDim.x);
             stage(0, 0);
         }
-        nt_epilogue<ACT, MI>(a, acc, smem + BUF_BYTES, wave, lane, em, en);
+        EpiPrefetch<MI> pf;
+        nt_epilogue_prefetch<ACT, MI>(a, pf, lane, em, en);
+        nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, lane, em, en);
     }
 }
 
@@ -441,14 +486,16 @@ extern "C" int avs_gemm_set_tile(int tile) {
 extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
                                 const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
                                 long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
-                                float alpha, int act, int scale_cols, float col_scale, hipStream_t stream) {
+                                float alpha, int act, int scale_cols, float col_scale, float* colsum, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % BN) == 0 && (K % BK) == 0, "gemm_nt: need N%%128==0, K%%64==0 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out, "gemm_nt: null operand");
     AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (!out2 || (ldo2 % 8) == 0) && (!aux || (ldaux % 8) == 0),
                   "gemm_nt: leading dimensions must keep 16-byte alignment");
     AVS_CHECK_ARG(act >= 0 && act <= 2 && (act != 1 || out2) && (act != 2 || aux), "gemm_nt: bad activation arguments");
+    AVS_CHECK_ARG(!(out_f32 && act != 0), "gemm_nt: fp32 output is supported with act 0 only");
+    AVS_CHECK_ARG(!(out_f32 && colsum), "gemm_nt: the fused column sum is implemented for bf16 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
-    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale};
+    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;

@@ -135,14 +135,13 @@ class Stack:
         for i in reversed(range(self.nblocks)):
             bp, st = blocks[i], self.stats[i]
             # fc2: d(gelu out) fused with GELU' -> d(fc1 pre-activation)
-            ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2)
+            ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb)     # + fc1 bias gradient
             ops.gemm_tn(dbo, self.act[i], bp.fc2.gw, M)
             if i == self.nblocks - 1 and not last_fc2_bias_done:
                 ops.colsum(dbo, bp.fc2.gb, M)
             # fc1
             ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M)
             ops.gemm_tn(self.dfc1, self.ln2[i], bp.fc1.gw, M)
-            ops.colsum(self.dfc1, bp.fc1.gb, M)
             _ln_bwd(self.dln, self.xmid[i], st[2], st[3], bp.n2, dxm, self.lnws, M, self.row_mod, dres=dxo, dx_bf16=dbm,
                     dcol=bp.proj.gb)
             # proj

@@ -109,8 +109,9 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
 
 
 # ---------------------------------------------------------------------------------------------------
-def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None, alpha=1.0, act=0, scale_cols=0, col_scale=1.0):
-    """out[M,N] = alpha * (A[M,K] @ B[N,K]^T + bias [* gelu'(aux)] + res[res_idx]); columns [0, scale_cols) also * col_scale."""
+def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None, alpha=1.0, act=0, scale_cols=0, col_scale=1.0, colsum=None):
+    """out[M,N] = alpha * (A[M,K] @ B[N,K]^T + bias [* gelu'(aux)] + res[res_idx]); columns [0, scale_cols) also * col_scale;
+    colsum[n] += sum_m out[m, n] (bf16 output only)."""
     _chk(A, BF16, "gemm.A", 2); _chk(B, BF16, "gemm.B", 2); _chk(bias, F32, "gemm.bias"); _chk(res, F32, "gemm.res", 2)
     _chk(res_idx, I32, "gemm.res_idx"); _chk(aux, BF16, "gemm.aux", 2); _chk(out2, BF16, "gemm.out2", 2)
     if out.dtype not in (BF16, F32) or not out.is_cuda or not out.is_contiguous() or out.dim() != 2:
@@ -125,13 +126,16 @@ def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None
             assert res.shape[0] >= M
         else:
             assert res_idx.numel() >= M
+    if colsum is not None:
+        _chk(colsum, F32, "gemm.colsum")
+        assert colsum.numel() == N and out.dtype == BF16
     if act == 1:
         assert out2 is not None and out2.shape[0] >= M and out2.shape[1] == N
     if act == 2:
         assert aux is not None and aux.shape[0] >= M and aux.shape[1] == N
     _launch("gemm_nt_act%d" % act, 2.0 * M * N * K, "avs_gemm_nt_bf16", A, A.stride(0), B, B.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
               res_idx, aux, aux.stride(0) if aux is not None else 0, out, out.stride(0), 1 if out.dtype == F32 else 0, out2,
-              out2.stride(0) if out2 is not None else 0, float(alpha), act, int(scale_cols), float(col_scale), _stream())
+              out2.stride(0) if out2 is not None else 0, float(alpha), act, int(scale_cols), float(col_scale), colsum, _stream())
 
 
 def gemm_tn(A, B, C, M, splits=0):

@@ -46,11 +46,14 @@ int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* m
  * 600,634-635).  nt: out = alpha*(A[M,K].B[N,K]^T + bias [*gelu'(aux)] + res[res_idx? res_idx[m] : m]); act 0 none,
  * 1 gelu (out = pre-activation, out2 = gelu(out) bf16), 2 gelu-backward (aux = saved pre-activation).  N%128==0, K%64==0.
  * Columns [0, scale_cols) (a multiple of 64, 0 = none) are multiplied by col_scale in addition: the qkv projection
- * uses it to hand the attention kernels q already multiplied by hd^-0.5 * log2(e), rounded to bf16 once. */
+ * uses it to hand the attention kernels q already multiplied by hd^-0.5 * log2(e), rounded to bf16 once.
+ * colsum (bf16 output only, may be NULL): colsum[n] += sum over rows of the output - the bias gradient of the layer
+ * whose output gradient this GEMM produces (fc1.bias from the fc2 dgrad), without re-reading the matrix.
+ * fp32 output (out_f32) requires act 0. */
 int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, int M, int N, int K,
                      const float* bias, const float* res, long long ldr, const int* res_idx, const avs_bf16* aux,
                      long long ldaux, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
-                     int act, int scale_cols, float col_scale, avs_stream_t stream);
+                     int act, int scale_cols, float col_scale, float* colsum, avs_stream_t stream);
 /* tile selection of the nt kernel: 0 = automatic (256x256 when that alone fills the chip, else 128x128), 128, 256 */
 int avs_gemm_set_tile(int tile);
 /* 1 (default): 256x256 nt tiles run as persistent workgroups (one per CU); 0: one workgroup per tile (A/B measurements) */

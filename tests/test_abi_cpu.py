@@ -35,7 +35,7 @@ def test_abi_version_and_error_string(lib_path):
     assert lib.avs_abi_version() == 1
     assert isinstance(lib.avs_last_error(), bytes)
     # argument validation happens before any launch, so it is testable without a GPU
-    rc = lib.avs_gemm_nt_bf16(None, 0, None, 0, 10, 100, 64, None, None, 0, None, None, 0, None, 0, 0, None, 0, 1.0, 0, 0, 1.0, None)
+    rc = lib.avs_gemm_nt_bf16(None, 0, None, 0, 10, 100, 64, None, None, 0, None, None, 0, None, 0, 0, None, 0, 1.0, 0, 0, 1.0, None, None)
     assert rc == -2 and b"gemm_nt" in lib.avs_last_error()
     rc = lib.avs_layernorm_fwd(None, None, None, None, None, None, None, None, 0, None, None, 4, 100, 1e-5, None)
     assert rc == -2

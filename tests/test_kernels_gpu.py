@@ -121,10 +121,12 @@ def test_gemm_nt_epilogues(M, N, K):
     assert rel_err(act, F.gelu(ref + bias.double())) < 5e-3
     # gelu backward epilogue
     dpre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
-    o.gemm_nt(A, W, dpre, M, aux=pre, act=2)
+    csum = torch.ones(N, device=DEV)
+    o.gemm_nt(A, W, dpre, M, aux=pre, act=2, colsum=csum)
     p = pre.double().requires_grad_(True)
     F.gelu(p).backward(ref)
     assert rel_err(dpre, p.grad) < 5e-3
+    assert rel_err(csum, 1 + p.grad.sum(0)) < 2e-3               # fused column sum (bias gradient), accumulated
 
 
 @pytest.mark.parametrize("M,N1,N2,splits", [(64, 128, 128, 1), (1000, 256, 768, 0), (4099, 768, 256, 3), (333, 2304, 768, 0)])
