@@ -12,6 +12,7 @@
 // fp32 accumulation on v_mfma_f32_16x16x32_bf16 (nt) / v_mfma_f32_32x32x16_bf16 (tn).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -30,6 +31,7 @@ struct GemmNtArgs {
     float alpha; int act;                    // 0 none | 1 gelu (out = pre-activation, out2 = gelu) | 2 gelu-backward (aux = pre-activation)
     int scale_cols; float col_scale;         // columns [0, scale_cols) are multiplied by col_scale as well (scale_cols % 64 == 0)
     float* colsum;                           // bf16 output only: colsum[n] += sum_m out[m][n] (bias gradient of the layer that produced A)
+    int m_full;                              // rows [0, m_full) in full tiles, [m_full, M) in half-height tiles (m_full == M: none)
 };
 
 
@@ -63,7 +65,7 @@ __device__ __forceinline__ void epi_apply4(float alpha, int ACT, float (&v)[4], 
 template <int MI>
 struct EpiPrefetch {
     static constexpr int RG = 1;                 // residual: 16 rows per group      (4 float4 per 16 rows -> 16 VGPRs / group)
-    static constexpr int AG = 4;                 // GELU' aux: 4 x 16 rows per group, single-buffered (32 VGPRs; a second
+    static constexpr int AG = MI < 4 ? MI : 4;                 // GELU' aux: 4 x 16 rows per group, single-buffered (32 VGPRs; a second
                                                  // buffer spills next to the 128 accumulator registers and costs more than it hides)
     f32x4 rs[2][RG][4];                          // [buffer][16-row block][row quad]   (ext vectors: HIP's float4/uint4
     u32x4 ax[AG][2];                             //  structs in arrays end up in scratch)
@@ -215,13 +217,17 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
     constexpr int TBN = NWN * 64;                 // tile cols (B rows / weights)
     constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int CA = TBM * 8 / NT, CB = TBN * 8 / NT;   // 16-byte chunks staged per thread per K-step
+    constexpr int MIH = MI / 2, CAH = CA / 2;     // HALF-height tiles (TBM/2 rows, same LDS image: the A region is half used)
     extern __shared__ __attribute__((aligned(16))) char smem[];            // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
     const int nt_n = a.N / TBN;
-    const int nt_m = (a.M + TBM - 1) / TBM;
-    const int ntiles = nt_m * nt_n;
+    // Tiles [0, nfull) are TBM x TBN tiles over rows [0, m_full); rows [m_full, M) - what is left after the whole rounds of
+    // full tiles, see the host - are cut into half-height tiles so that the last, partial round still covers the chip.
+    const int nfull = ((a.m_full + TBM - 1) / TBM) * nt_n;
+    const int nhalf = a.m_full < a.M ? ((a.M - a.m_full + TBM / 2 - 1) / (TBM / 2)) * nt_n : 0;
+    const int ntiles = nfull + nhalf;
     const int fr = lane & 15, fq = lane >> 4;
     // fragment read offsets: row = base + (lane&15), chunk = kk*4 + (lane>>4), swizzled with row&7 == lane&7
     const int off_k0 = fr * 128 + (((0 + fq) ^ (lane & 7)) << 4);
@@ -235,12 +241,20 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
     const bf16_t* srcA[CA];
     const bf16_t* srcB[CB];
     int m0 = 0, n0 = 0;
+    bool half = false;                             // kind of the tile srcA/srcB point at (block-uniform)
     auto set_tile = [&](int v) {
-        const int wg = xcd_remap(v, ntiles);
-        m0 = (wg / nt_n) * TBM;
-        n0 = (wg % nt_n) * TBN;
+        half = v >= nfull;
+        if (!half) {
+            const int wg = xcd_remap(v, nfull);
+            m0 = (wg / nt_n) * TBM;
+            n0 = (wg % nt_n) * TBN;
+        } else {
+            const int h = v - nfull;
+            m0 = a.m_full + (h / nt_n) * (TBM / 2);
+            n0 = (h % nt_n) * TBN;
+        }
 #pragma unroll
-        for (int i = 0; i < CA; ++i) {
+        for (int i = 0; i < CA; ++i) {             // a half tile uses chunks [0, CAH): rows 0 .. TBM/2-1
             const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
             srcA[i] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + c * 8;
         }
@@ -255,7 +269,8 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
         char* sb = sa + A_BYTES;
 #pragma unroll
         for (int i = 0; i < CA; ++i)
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + k0), (LDS_AS void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
+            if (i < CAH || !half)
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + k0), (LDS_AS void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < CB; ++i)
             __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + k0), (LDS_AS void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
@@ -265,45 +280,53 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
     if (v >= ntiles) return;
     set_tile(v);
     stage(0, 0);
-    for (; v < ntiles; v += gridDim.x) {
-        f32x4 acc[4][MI];
+    // one tile of 2 x MIT x 16 rows (MIT = MI: full, MI/2: half); srcA/srcB/half describe it on entry and the NEXT tile on exit
+    auto run_tile = [&](auto mit) {
+        constexpr int MIT = decltype(mit)::value;
+        f32x4 acc[4][MIT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MIT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int t = 0; t < nk; ++t) {
-            __syncthreads();                               // K-slab t landed (vmcnt(0)); buffer (t+1)&1 and the epilogue patches are free
+            // K-slab t must have landed: wait for this wave's LDS-DMA explicitly - hipcc's own vmcnt(0) in front of the
+            // barrier is not guaranteed (it is missing from the half-tile instantiation of the GELU kernel)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                               // buffer (t+1)&1 and the epilogue patches are free
             if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
-            const char* sa = smem + (t & 1) * BUF_BYTES + wm * (MI * 16) * 128;
+            const char* sa = smem + (t & 1) * BUF_BYTES + wm * (MIT * 16) * 128;
             const char* sb = smem + (t & 1) * BUF_BYTES + A_BYTES + wn * 64 * 128;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int off = kk ? off_k1 : off_k0;
-                bf16x8 wf[4], xf[MI];
+                bf16x8 wf[4], xf[MIT];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + off);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + off);
+                for (int i = 0; i < MIT; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + off);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MIT; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
             }
         }
-        const int em = m0 + wm * (MI * 16), en = n0 + wn * 64;
+        const int em = m0 + wm * (MIT * 16), en = n0 + wn * 64;
         __syncthreads();                                   // every wave is done reading the K-slab buffers
-        // the last K-slab sat in buffer (nk-1)&1; the epilogue patches go to the OTHER half... both halves are free now,
-        // so prefetch the next tile's first slab into buffer 0 and stage the epilogue through buffer 1.
+        // both LDS buffers are free now: prefetch the next tile's first slab into buffer 0, stage the epilogue through buffer 1
         if (v + (int)gridDim.x < ntiles) {
             set_tile(v + gridDim.x);
             stage(0, 0);
         }
-        EpiPrefetch<MI> pf;
-        nt_epilogue_prefetch<ACT, MI>(a, pf, lane, em, en);
-        nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, lane, em, en);
+        EpiPrefetch<MIT> pf;
+        nt_epilogue_prefetch<ACT, MIT>(a, pf, lane, em, en);
+        nt_epilogue<ACT, MIT>(a, acc, pf, smem + BUF_BYTES, wave, lane, em, en);
+    };
+    for (; v < ntiles; v += gridDim.x) {
+        if (!half) run_tile(std::integral_constant<int, MI>{});
+        else run_tile(std::integral_constant<int, MIH>{});
     }
 }
 
@@ -424,6 +447,7 @@ __global__ __launch_bounds__(128 * NWC) void gemm_tn_kernel(GemmTnArgs a) {
     stage(0, s_begin);
     for (int s = s_begin; s < s_end; ++s) {
         const int t = s - s_begin;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of slab s has landed (explicit: see gemm_nt_kernel)
         __syncthreads();
         if (s + 1 < s_end) stage((t + 1) & 1, s + 1);
         const char* sa = smem + (t & 1) * BUF_BYTES;
@@ -495,7 +519,7 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     AVS_CHECK_ARG(!(out_f32 && act != 0), "gemm_nt: fp32 output is supported with act 0 only");
     AVS_CHECK_ARG(!(out_f32 && colsum), "gemm_nt: the fused column sum is implemented for bf16 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
-    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum};
+    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;
@@ -529,36 +553,20 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
         }
-        // Whole rounds only: with T tiles on C CUs the last of ceil(T/C) rounds may be nearly empty (1122 tiles -> 4.4
-        // rounds cost 5).  Give the 256^2 kernel the row panels that fill floor(T/C) rounds and the remaining rows to the
-        // 128^2 kernel, whose four-times-smaller tiles (two workgroups per CU) fill the chip again.
+        // Whole rounds: with T tiles on C CUs the last of ceil(T/C) rounds may be nearly empty (1122 tiles -> 4.4 rounds
+        // cost 5).  When the last round would be less than half full, the row panels that fill floor(T/C) rounds stay
+        // 256^2 tiles and the remaining rows become 128 x 256 tiles of the SAME launch: twice as many, half as long.
         const int nt_n = N / 256, nt_m = ceil_div(M, 256);
-        int big_rows = nt_m;                                                     // row panels given to the 256^2 kernel
-        if (g_persistent && g_force_tile == 0 && big_tiles > ncu) {
-            const int full = (big_tiles / ncu) * ncu;                            // tiles in whole rounds
-            const int rows_full = full / nt_n;
-            const int rem_rows = M - rows_full * 256;
-            if (rows_full >= 1 && rows_full < nt_m && (big_tiles % ncu) * 4 < ncu * 3 && rem_rows > 0) big_rows = rows_full;
-        }
         GemmNtArgs b = a;
-        b.M = big_rows < nt_m ? big_rows * 256 : M;
-        const int tiles_b = ceil_div(b.M, 256) * nt_n;
+        if (g_persistent && g_force_tile == 0 && big_tiles > ncu) {
+            const int rows_full = ((big_tiles / ncu) * ncu) / nt_n;              // row panels inside whole rounds
+            if (rows_full >= 1 && rows_full < nt_m && (big_tiles % ncu) * 2 <= ncu) b.m_full = rows_full * 256;
+        }
+        const int tiles_b = ceil_div(b.m_full, 256) * nt_n + (b.m_full < M ? ceil_div(M - b.m_full, 128) * nt_n : 0);
         const int grid = g_persistent ? (tiles_b < ncu ? tiles_b : ncu) : tiles_b;
         if (act == 0) gemm_nt_kernel<0, 4, 8><<<grid, 512, 131072, stream>>>(b);
         else if (act == 1) gemm_nt_kernel<1, 4, 8><<<grid, 512, 131072, stream>>>(b);
         else gemm_nt_kernel<2, 4, 8><<<grid, 512, 131072, stream>>>(b);
-        if (b.M < M) {
-            GemmNtArgs r = a;                                                    // remaining rows [b.M, M)
-            const size_t o = (size_t)b.M;
-            r.M = M - b.M;
-            r.A = a.A + o * a.lda;
-            if (a.res && !a.res_idx) r.res = a.res + o * a.ldr;
-            if (a.res_idx) r.res_idx = a.res_idx + o;
-            if (a.aux) r.aux = a.aux + o * a.ldaux;
-            r.out = a.out_f32 ? (void*)((float*)a.out + o * a.ldo) : (void*)((bf16_t*)a.out + o * a.ldo);
-            if (a.out2) r.out2 = a.out2 + o * a.ldo2;
-            launch_small(r);
-        }
     } else {
         launch_small(a);
     }

@@ -29,10 +29,16 @@ def _stream():
 
 class KernelProfiler:
     """HIP-event timing of individual launches on torch's current stream (the stream the kernels run on).
-    Enabled by bench.py over its timed region: `ops.prof = KernelProfiler()`; read with .summary() after a sync."""
+    Enabled by bench.py over its timed region: `ops.prof = KernelProfiler()`; read with .summary() after a sync.
+    `only`: kind prefixes to time (an event pair costs the stream ~5 us, so the default bench run times the dominant
+    kernel only)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.rec = {}
+        self.only = tuple(only) if only else None
+
+    def wants(self, kind):
+        return self.only is None or kind.startswith(self.only)
 
     def add(self, kind, e0, e1, work):
         self.rec.setdefault(kind, []).append((e0, e1, work))
@@ -51,7 +57,7 @@ prof = None
 
 
 def _launch(kind, work, cname, *args):
-    if prof is None:
+    if prof is None or not prof.wants(kind):
         return _lib.call(cname, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--all-kernel-events", action="store_true",
+                    help="HIP-event timing of every kernel family (default: the dominant kernel, gemm_nt, only - each timed "
+                         "launch costs the stream ~5 us)")
     args = ap.parse_args()
 
     from avsiam_amd import _lib, ops
@@ -136,7 +139,7 @@ def main():
         log(f"warm-up step {i} done, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     if not args.no_kernel_events:
-        ops.prof = ops.KernelProfiler()
+        ops.prof = ops.KernelProfiler(None if args.all_kernel_events else ("gemm_nt",))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = train_step(model, a, v, args.lr)
