@@ -36,6 +36,7 @@ def main():
     stacks = [("P1 shared ViT", 95630, 768, 3072, 12), ("P2 audio tower", 8192, 768, 3072, 11), ("P2 video tower", 31360, 768, 3072, 11),
               ("P2 joint", 39552, 768, 3072, 1), ("P2 decoder", 158208, 512, 2048, 8)]
     grand = 0.0
+    grand_w = 0.0
     for name, M, D, Hd, layers in stacks:
         Mp = ops.pad_rows(M, 256)
         rnd = lambda n, dt=BF16: (torch.randn(Mp, n, device=dev) * 0.5).to(dt)  # noqa: E731
@@ -68,8 +69,20 @@ def main():
                   f"   x{layers} = {t * layers * 1e3:6.2f} ms", flush=True)
         print(f"   stack total {tot * 1e3:.2f} ms/step", flush=True)
         grand += tot
+        # weight gradients: C[N1,N2] += dY[M,N1]^T . X[M,N2]
+        totw = 0.0
+        for kname, dy, x, N1, N2 in [("qkv wgrad", x3, xD, 3 * D, D), ("proj wgrad", xD, oD, D, D), ("fc1 wgrad", xH, xD, Hd, D), ("fc2 wgrad", xD, xH, D, Hd)]:
+            C = torch.zeros(N1, N2, device=dev)
+            dy[M:].zero_(); x[M:].zero_()
+            t = timeit(lambda: ops.gemm_tn(dy, x, C, M), args.iters)
+            fl = 2.0 * M * N1 * N2
+            totw += t * layers
+            print(f"   {kname:24s} {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TF/s   floors: mfma {fl / 2.5e15 * 1e6:7.1f} us  hbm {M * 2 * (N1 + N2) / 8e12 * 1e6:7.1f} us"
+                  f"   x{layers} = {t * layers * 1e3:6.2f} ms", flush=True)
+        print(f"   stack wgrad total {totw * 1e3:.2f} ms/step", flush=True)
+        grand_w += totw
         del xD, xH, x3, oD, oH, o3, oH2, fD, rD
-    print(f"all forward+dgrad GEMMs: {grand * 1e3:.2f} ms/step")
+    print(f"all forward+dgrad GEMMs: {grand * 1e3:.2f} ms/step; all wgrad GEMMs: {grand_w * 1e3:.2f} ms/step")
 
 
 if __name__ == "__main__":
