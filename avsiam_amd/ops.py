@@ -30,15 +30,22 @@ def _stream():
 class KernelProfiler:
     """HIP-event timing of individual launches on torch's current stream (the stream the kernels run on).
     Enabled by bench.py over its timed region: `ops.prof = KernelProfiler()`; read with .summary() after a sync.
-    `only`: kind prefixes to time (an event pair costs the stream ~5 us, so the default bench run times the dominant
-    kernel only)."""
+    `only`: kind prefixes to time; `stride`: time every stride-th launch of those kinds.  An event pair costs the stream
+    ~5 us, so the default bench run samples the dominant kernel only: with a stride co-prime to the launches per step
+    every launch position of the step is covered equally often over the timed steps, and the sample mean equals the mean
+    over all launches."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, stride=1):
         self.rec = {}
         self.only = tuple(only) if only else None
+        self.stride = max(1, int(stride))
+        self.seen = 0
 
     def wants(self, kind):
-        return self.only is None or kind.startswith(self.only)
+        if self.only is not None and not kind.startswith(self.only):
+            return False
+        self.seen += 1
+        return (self.seen - 1) % self.stride == 0
 
     def add(self, kind, e0, e1, work):
         self.rec.setdefault(kind, []).append((e0, e1, work))

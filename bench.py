@@ -139,7 +139,9 @@ def main():
         log(f"warm-up step {i} done, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     if not args.no_kernel_events:
-        ops.prof = ops.KernelProfiler(None if args.all_kernel_events else ("gemm_nt",))
+        # default: every 5th gemm_nt launch (378 per step, co-prime to 5: over 5 or 10 steps every launch position is timed
+        # equally often); --all-kernel-events: every launch of every kernel family (costs ~5 ms/step of event overhead)
+        ops.prof = ops.KernelProfiler() if args.all_kernel_events else ops.KernelProfiler(("gemm_nt",), stride=5)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = train_step(model, a, v, args.lr)
@@ -175,7 +177,8 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (forward + dgrad bf16 MFMA GEMMs)", "achieved": ach,
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args),
-                                "launches": n, "avg_launch_us": 1e3 * ms / n, "flops_per_launch": flops / n}
+                                "launches": n, "avg_launch_us": 1e3 * ms / n, "flops_per_launch": flops / n,
+                                "sampling": "all launches" if args.all_kernel_events else "every 5th launch of the timed region"}
             line["kernels"] = {k: {"launches": x["launches"], "total_ms": round(x["total_ms"], 3), "avg_us": round(x["avg_us"], 2),
                                    "rate_T_per_s": round(x["rate"] / 1e12, 3)} for k, x in sorted(s.items())}
         if world == 1 and not args.no_cpu_baseline:
