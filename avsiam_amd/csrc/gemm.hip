@@ -331,6 +331,173 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 8-phase variant of the 256x256 tile (after the guide's "256^2 8-phase template": this schedule is derived for THIS
+// kernel's LDS image and epilogue).  What it changes against gemm_nt_kernel<.,4,8>:
+//   * the two wave groups (G0 = waves 0-3: output rows 0-127, G1 = waves 4-7: rows 128-255) run the same phase sequence
+//     offset by ONE barrier: while one group's MFMA segment runs, the other group issues its fragment reads and LDS-DMAs,
+//     so the matrix pipe of every SIMD always has a wave with operands in registers;
+//   * a K-tile (64 deep) is multiplied in four phases of 16 MFMAs per wave - output quadrants (a0,b0) (a0,b1) (a1,b1)
+//     (a1,b0), a = 64-row half of the wave's 128 rows, b = 32-column half of its 64 columns; both b halves stay in
+//     registers, so a K-tile's LDS reads are a0+b0 | b1 | a1 | none;
+//   * staging granules are 16 KiB (A rows of one group, or the b0 / b1 column halves of all waves); each is re-filled
+//     for K-tile t+2 as soon as its last reader is a barrier past it: phase 1: A1(t+1), 2: B1(t+1), 3: B0(t+2), 4: A0(t+2).
+//     Three granules are in flight across every barrier (counted vmcnt(6), never 0 inside the loop) instead of one
+//     64-KiB slab that has to land completely before the next K-step starts.
+// Hazards (barrier b_i; G0's load segment of phase p of K-tile t lies in (b_{8t+2p-3}, b_{8t+2p-2}), G1's one later):
+//   WAR  a granule is re-filled at least one full barrier interval after the lgkmcnt(0) of its last reader;
+//   RAW  every wave waits for its own share of a granule (counted vmcnt) in the load segment BEFORE the one that reads it.
+// counted wait on the vector-memory queue as a REAL s_waitcnt (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 |
+// vmcnt[5:4] << 14): hipcc's waitcnt pass reads it and retires the loads it covers from its scoreboard - with an asm
+// statement it cannot see, it re-waits (vmcnt(0), every iteration) for epilogue loads whose registers the loop reuses
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
+    constexpr int NT = 512, TBM = 256, TBN = 256, MI = 8;
+    constexpr int A_BYTES = TBM * 128, BUF_BYTES = 2 * A_BYTES, GR = 16384;     // per K-tile buffer: [A 32 KiB | B 32 KiB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wc = wave & 3;                   // wave group (row half) and 64-column slice
+    const int nt_n = a.N / TBN;
+    const int ntiles = ((a.M + TBM - 1) / TBM) * nt_n;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int off_k0 = fr * 128 + (((0 + fq) ^ (lane & 7)) << 4);
+    const int off_k1 = fr * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    const int nk = a.K / BK;
+    const unsigned lds_base = (unsigned)(size_t)(LDS_AS const char*)smem;
+
+    // DMA bookkeeping.  Granule-local chunk p = j*512 + tid (j = 0,1): local row lr = p >> 3, slot p & 7, source chunk
+    // (p & 7) ^ (lr & 7).  A granules: physical row = h*128 + lr; B granules: physical row = (lr>>5)*64 + h*32 + (lr&31).
+    const bf16_t* sA[2][2];                                   // [granule half][j]
+    const bf16_t* sB[2][2];
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int v) {
+        const int wg = xcd_remap(v, ntiles);
+        m0 = (wg / nt_n) * TBM;
+        n0 = (wg % nt_n) * TBN;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = j * NT + tid, lr = p >> 3, c = (p & 7) ^ (lr & 7);
+                sA[h][j] = a.A + (size_t)min(m0 + h * 128 + lr, a.M - 1) * a.lda + c * 8;
+                sB[h][j] = a.B + (size_t)(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31)) * a.ldb + c * 8;
+            }
+    };
+    // LDS destination of this wave's j-th instruction of a granule (wave-uniform; the hardware adds lane*16)
+    auto dma_a = [&](int t, int h) {
+        char* dst = smem + (t & 1) * BUF_BYTES + h * GR;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sA[h][j] + t * BK), (LDS_AS void*)(dst + (j * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    auto dma_b = [&](int t, int h) {
+        char* dst = smem + (t & 1) * BUF_BYTES + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int lr0 = j * 64 + wave * 8;                // first of the 8 local rows this wave-instruction covers
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sB[h][j] + t * BK),
+                                             (LDS_AS void*)(dst + ((lr0 >> 5) * 64 + h * 32 + (lr0 & 31)) * 128), 16, 0, 0);
+        }
+    };
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    int v = blockIdx.x;
+    if (v >= ntiles) return;
+    set_tile(v);
+    dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
+    for (; v < ntiles; v += gridDim.x) {
+        f32x4 acc[4][MI];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // K-tile 0 (8 DMAs per thread, issued before the previous epilogue) must land; after the barrier every wave has
+        // left that epilogue, so buffer 1 (its LDS patches) may take B0(1), A0(1)
+        wait_vm<0>();
+        bar();
+        if (nk > 1) { dma_b(1, 0); dma_a(1, 0); }
+        if (g == 1) bar();                                    // the one-barrier offset between the groups
+        bf16x8 xf[4][2], wb[2][2][2];                         // a half: [mi][kk];  b halves: [bh][ni][kk]
+        for (int t = 0; t < nk; ++t) {
+            // fragment reads go through inline asm: hipcc treats an LDS-DMA in flight as a pending store to LDS and, unable to
+            // tell the granule being re-filled from the one being read (same K-tile buffer), would put s_waitcnt vmcnt(0)
+            // in front of the first ds_read of the K-tile - draining the whole ring.  lgkmcnt is waited for by hand.
+            const unsigned la = lds_base + (t & 1) * BUF_BYTES + (g * 128) * 128;
+            const unsigned lb = lds_base + (t & 1) * BUF_BYTES + A_BYTES + (wc * 64) * 128;
+            const unsigned va0 = la + off_k0, va1 = la + off_k1, vb0 = lb + off_k0, vb1 = lb + off_k1;
+            const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+#define NT8_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF) : "memory")
+#define NT8_RD_A(AH)                                                                                          \
+    NT8_RD(xf[0][0], va0, (AH) * 8192 + 0);    NT8_RD(xf[0][1], va1, (AH) * 8192 + 0);                          \
+    NT8_RD(xf[1][0], va0, (AH) * 8192 + 2048); NT8_RD(xf[1][1], va1, (AH) * 8192 + 2048);                       \
+    NT8_RD(xf[2][0], va0, (AH) * 8192 + 4096); NT8_RD(xf[2][1], va1, (AH) * 8192 + 4096);                       \
+    NT8_RD(xf[3][0], va0, (AH) * 8192 + 6144); NT8_RD(xf[3][1], va1, (AH) * 8192 + 6144)
+#define NT8_RD_B(BH)                                                                                          \
+    NT8_RD(wb[BH][0][0], vb0, (BH) * 4096 + 0);    NT8_RD(wb[BH][0][1], vb1, (BH) * 4096 + 0);                  \
+    NT8_RD(wb[BH][1][0], vb0, (BH) * 4096 + 2048); NT8_RD(wb[BH][1][1], vb1, (BH) * 4096 + 2048)
+            auto mma = [&](int ah, int bh) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this phase's fragment reads (issued before the barrier)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[bh * 2 + ni][ah * 4 + mi] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[bh][ni][kk], xf[mi][kk], acc[bh * 2 + ni][ah * 4 + mi], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // ---- phase 1: (a0, b0); re-fill A1 of the next K-tile; B1(t) must have landed for phase 2
+            NT8_RD_B(0); NT8_RD_A(0);
+            if (n1) { dma_a(t + 1, 1); wait_vm<6>(); } else wait_vm<0>();
+            bar(); mma(0, 0); bar();
+            // ---- phase 2: (a0, b1)
+            NT8_RD_B(1);
+            if (n1) dma_b(t + 1, 1);
+            bar(); mma(0, 1); bar();
+            // ---- phase 3: (a1, b1)
+            NT8_RD_A(1);
+            if (n2) dma_b(t + 2, 0);
+            bar(); mma(1, 1); bar();
+            // ---- phase 4: (a1, b0); A1(t+1) (and everything older) must have landed for the next K-tile's phase 1
+            if (n2) { dma_a(t + 2, 0); wait_vm<6>(); }
+            else if (n1) wait_vm<2>();
+            bar(); mma(1, 0); bar();
+        }
+#undef NT8_RD
+#undef NT8_RD_A
+#undef NT8_RD_B
+        if (g == 0) bar();                                    // pairs with G1's last barrier
+        const int em = m0 + g * 128, en = n0 + wc * 64;
+        __syncthreads();                                      // every wave is done with both buffers, nothing in flight
+        if (v + (int)gridDim.x < ntiles) {
+            set_tile(v + gridDim.x);
+            dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
+        }
+        EpiPrefetch<MI> pf;
+        nt_epilogue_prefetch<ACT, MI>(a, pf, lane, em, en);
+        nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, lane, em, en);
+        // a compiler-visible full drain: the K loop reuses registers the epilogue loaded into, and hipcc would otherwise
+        // re-wait for those loads (vmcnt(0)) at the head of EVERY K-tile.  The next tile's first wait drains the stores anyway.
+        wait_vm<0>();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // wgrad.  Both operands are row-major with the CONTRACTION index (token row m) as the slow dimension, so the
 // MFMA fragments (8 consecutive k per lane) are columns of the staged tiles: they are read with the gfx950
 // transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, lane i receives column i).
@@ -501,6 +668,12 @@ extern "C" int avs_gemm_set_persistent(int on) {
     return 0;
 }
 
+static int g_nt8 = -1;                     // 1: 256^2 GEMMs run the 8-phase kernel (AVSIAM_GEMM_NT8 / avs_gemm_set_nt8)
+extern "C" int avs_gemm_set_nt8(int on) {
+    g_nt8 = on ? 1 : 0;
+    return 0;
+}
+
 extern "C" int avs_gemm_set_tile(int tile) {
     AVS_CHECK_ARG(tile == 0 || tile == 128 || tile == 256, "gemm_set_tile: tile must be 0 (auto), 128 or 256");
     g_force_tile = tile;
@@ -529,6 +702,8 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     if (!attr_done) {
         hipError_t e = hipSuccess;
         const void* big_k[3] = {(const void*)gemm_nt_kernel<0, 4, 8>, (const void*)gemm_nt_kernel<1, 4, 8>, (const void*)gemm_nt_kernel<2, 4, 8>};
+        const void* k8[3] = {(const void*)gemm_nt8_kernel<0>, (const void*)gemm_nt8_kernel<1>, (const void*)gemm_nt8_kernel<2>};
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipFuncSetAttribute(k8[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         const void* small_k[3] = {(const void*)gemm_nt_kernel<0, 2, 4>, (const void*)gemm_nt_kernel<1, 2, 4>, (const void*)gemm_nt_kernel<2, 2, 4>};
         for (int i = 0; i < 3 && e == hipSuccess; ++i) {
             e = hipFuncSetAttribute(big_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -561,6 +736,39 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
         if (g_persistent && g_force_tile == 0 && big_tiles > ncu) {
             const int rows_full = ((big_tiles / ncu) * ncu) / nt_n;              // row panels inside whole rounds
             if (rows_full >= 1 && rows_full < nt_m && (big_tiles % ncu) * 2 <= ncu) b.m_full = rows_full * 256;
+        }
+        if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
+        if (g_nt8 == 1 && K >= 128 && g_persistent && g_force_tile == 0) {
+            // 8-phase kernel on the whole rounds of full tiles; the leftover rows (if any) as half-height tiles of the
+            // two-buffer kernel (m_full = 0: every row is a half tile) on the shifted operands
+            GemmNtArgs f = a;
+            f.M = b.m_full;
+            f.m_full = b.m_full;
+            const int tiles8 = ceil_div(f.M, 256) * nt_n;
+            const int grid8 = tiles8 < ncu ? tiles8 : ncu;
+            if (act == 0) gemm_nt8_kernel<0><<<grid8, 512, 131072, stream>>>(f);
+            else if (act == 1) gemm_nt8_kernel<1><<<grid8, 512, 131072, stream>>>(f);
+            else gemm_nt8_kernel<2><<<grid8, 512, 131072, stream>>>(f);
+            AVS_LAUNCH_CHECK("gemm_nt8");
+            if (b.m_full < M) {
+                GemmNtArgs r = a;
+                const size_t o = (size_t)b.m_full;
+                r.M = M - b.m_full;
+                r.m_full = 0;
+                r.A = a.A + o * a.lda;
+                if (a.res && !a.res_idx) r.res = a.res + o * a.ldr;
+                if (a.res_idx) r.res_idx = a.res_idx + o;
+                if (a.aux) r.aux = a.aux + o * a.ldaux;
+                r.out = a.out_f32 ? (void*)((float*)a.out + o * a.ldo) : (void*)((bf16_t*)a.out + o * a.ldo);
+                if (a.out2) r.out2 = a.out2 + o * a.ldo2;
+                const int tiles_r = ceil_div(r.M, 128) * nt_n;
+                const int grid_r = tiles_r < ncu ? tiles_r : ncu;
+                if (act == 0) gemm_nt_kernel<0, 4, 8><<<grid_r, 512, 131072, stream>>>(r);
+                else if (act == 1) gemm_nt_kernel<1, 4, 8><<<grid_r, 512, 131072, stream>>>(r);
+                else gemm_nt_kernel<2, 4, 8><<<grid_r, 512, 131072, stream>>>(r);
+                AVS_LAUNCH_CHECK("gemm_nt (leftover rows)");
+            }
+            return 0;
         }
         const int tiles_b = ceil_div(b.m_full, 256) * nt_n + (b.m_full < M ? ceil_div(M - b.m_full, 128) * nt_n : 0);
         const int grid = g_persistent ? (tiles_b < ncu ? tiles_b : ncu) : tiles_b;

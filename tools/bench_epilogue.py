@@ -36,8 +36,13 @@ def main():
          "fc1 plain": lambda: ops.gemm_nt(xD, W1, oH, M, bias=bH),
          "fc1 gelu": lambda: ops.gemm_nt(xD, W1, oH, M, bias=bH, out2=oH2, act=1),
          "fc2dg gelu'": lambda: ops.gemm_nt(xD, W2t, oH, M, aux=oH2, act=2)}
-    for _ in range(3):
-        print("  ".join(f"{k}: {timeit(f) * 1e6:.1f}" for k, f in v.items()), flush=True)
+    from avsiam_amd import _lib
+    lib = _lib.load()
+    for rnd in range(3):
+        for nt8 in (0, 1):
+            lib.avs_gemm_set_nt8(nt8)
+            print(("8-phase " if nt8 else "2-buffer") + "  " + "  ".join(f"{k}: {timeit(f) * 1e6:.1f}" for k, f in v.items()), flush=True)
+    lib.avs_gemm_set_nt8(0)
 
 
 if __name__ == "__main__":
