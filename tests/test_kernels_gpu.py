@@ -129,6 +129,45 @@ def test_gemm_nt_epilogues(M, N, K):
     assert rel_err(csum, 1 + p.grad.sum(0)) < 2e-3               # fused column sum (bias gradient), accumulated
 
 
+@pytest.mark.parametrize("M,N,K", [(33000, 768, 256), (70001, 512, 2048), (95630, 768, 768)])
+def test_gemm_nt_8phase_matches_two_buffer_kernel(M, N, K):
+    """The 8-phase kernel accumulates in the same order as the two-buffer kernel, so every epilogue variant must agree
+    BITWISE (several tiles per workgroup, ragged last row tile, leftover rows): a stale or early-read staging granule
+    shows up here as a differing tile."""
+    from avsiam_amd import _lib
+    o = ops()
+    lib = _lib.load()
+    A = bf(torch.randn(M, K, device=DEV))
+    W = bf(torch.randn(N, K, device=DEV) * 0.05)
+    bias = torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV)
+
+    def run():
+        out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        o.gemm_nt(A, W, out, M, bias=bias, scale_cols=(N // 128) * 64, col_scale=0.25)
+        outf = torch.zeros(M, N, device=DEV)
+        o.gemm_nt(A, W, outf, M, bias=bias, res=res)
+        pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        act = torch.zeros_like(pre)
+        o.gemm_nt(A, W, pre, M, bias=bias, out2=act, act=1)
+        dpre = torch.zeros_like(pre)
+        o.gemm_nt(A, W, dpre, M, aux=pre, act=2)
+        return out, outf, pre, act, dpre
+
+    try:
+        lib.avs_gemm_set_nt8(0)
+        want = run()
+        lib.avs_gemm_set_nt8(1)
+        for rep in range(3):
+            got = run()
+            for name, g, w in zip(("bf16", "f32+res", "pre", "gelu", "gelu'"), got, want):
+                assert torch.equal(g, w), (name, rep, float((g.float() - w.float()).abs().max()))
+    finally:
+        lib.avs_gemm_set_nt8(1)
+    ref = A.double() @ W.double().t() + bias.double()
+    assert rel_err(want[1], ref + res.double()) < 1e-5
+
+
 @pytest.mark.parametrize("M,N1,N2,splits", [(64, 128, 128, 1), (1000, 256, 768, 0), (4099, 768, 256, 3), (333, 2304, 768, 0)])
 def test_gemm_tn(M, N1, N2, splits):
     o = ops()
