@@ -659,6 +659,117 @@ __global__ __launch_bounds__(128 * NWC) void gemm_tn_kernel(GemmTnArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 8-phase variant of the 256x256 wgrad tile (same idea as gemm_nt8_kernel).  A stage (64 token rows of A and B) is
+// multiplied in four phases of 16 rows = 8 MFMAs (32x32x16) per wave; the two wave groups (wr = 0 / 1) are offset by one
+// barrier, so a group's 12 transposing fragment reads and 2 LDS-DMAs run under the other group's MFMA segment, and a
+// single fragment set suffices.  The 8-KiB (A) + 8-KiB (B) granule a phase consumes is re-filled two phases later with
+// the rows of the stage two ahead: granules are issued in reading order, six phases before they are read, and the wait
+// in front of every barrier is the constant vmcnt(10) (five younger granules stay in flight).
+template <int DUMMY>
+__global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTnArgs a) {
+    constexpr int T1 = 256, T2 = 256, MI = 4;
+    constexpr int RA = T1 * 2, RB = T2 * 2;                 // LDS row bytes of the staged [64 rows][256] tiles
+    constexpr int A_BYTES = 64 * RA, BUF_BYTES = 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles2 = a.N2 / T2, tiles = (a.N1 / T1) * tiles2;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / tiles, tile = lid % tiles;
+    const int n2_0 = (tile % tiles2) * T2, n1_0 = (tile / tiles2) * T1;
+    const int nstages = (a.M + BK - 1) / BK;
+    const int s_begin = split * a.stages_per_split;
+    const int nst = min(nstages, s_begin + a.stages_per_split) - s_begin;      // stages of this workgroup
+    if (nst <= 0) return;
+
+    // granule (stage t, quarter q) = token rows s*64 + q*16 .. +15: 16 rows x 32 chunks = one 16-B chunk per thread
+    const int grow = tid >> 5, gc = (tid & 31) ^ ((grow & 3) << 2);
+    const bf16_t* srcA = a.A + (size_t)(s_begin * BK + grow) * a.lda + n1_0 + gc * 8;
+    const bf16_t* srcB = a.B + (size_t)(s_begin * BK + grow) * a.ldb + n2_0 + gc * 8;
+    auto dma = [&](int t, int q) {
+        char* dst = smem + (t & 1) * BUF_BYTES + (q * 16) * RA + wave * 1024;
+        const size_t r = (size_t)(t * BK + q * 16);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA + r * a.lda), (LDS_AS void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB + r * a.ldb), (LDS_AS void*)(dst + A_BYTES), 16, 0, 0);
+    };
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int h = lane >> 5, cb = (lane >> 4) & 1, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+    const int trow = 8 * h + q4;
+    const int tcol = 16 * cb + 4 * p4;
+    auto tr_off = [&](int colbase) {                          // offset inside a granule (rows 0..15)
+        const int col = colbase + tcol;
+        const int chunk = (col >> 3) ^ (q4 << 2);
+        return trow * RA + (chunk << 4) + (col & 7) * 2;
+    };
+    int offA[MI], offB[2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) offA[i] = tr_off(wr * (MI * 32) + i * 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) offB[i] = A_BYTES + tr_off(wc * 64 + i * 32);
+
+    // prologue: granules are issued in reading order; six run ahead of the reader
+    dma(0, 0); dma(0, 1); dma(0, 2); dma(0, 3);
+    if (nst > 1) { dma(1, 0); dma(1, 1); wait_vm<10>(); } else wait_vm<0>();
+    bar();
+    if (wr == 1) bar();                                       // the one-barrier offset between the groups
+    TrFrag af[MI], bfr[2];
+    for (int t = 0; t < nst; ++t) {
+        const bool full = t + 2 < nst;                        // every granule this stage wants to issue exists
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char* gr = smem + (t & 1) * BUF_BYTES + (q * 16) * RA;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) lds_tr_issue<RA>(af[i], gr + offA[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lds_tr_issue<RB>(bfr[i], gr + offB[i]);
+            // re-fill the granule read two phases ago with the rows of the stage after next
+            const int ts = q < 2 ? t + 1 : t + 2, qs = (q + 2) & 3;
+            if (ts < nst) dma(ts, qs);
+            // the granule of the NEXT phase (issued six phases ago) must have landed; five younger ones stay in flight
+            if (full) wait_vm<10>(); else wait_vm<0>();
+            bar();
+            tr_wait();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(af[i]), tr_join(bfr[j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            bar();
+        }
+    }
+    if (wr == 0) bar();                                       // pairs with the other group's last barrier
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n2 = n2_0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n1 = n1_0 + wr * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(a.C + (size_t)n1 * a.ldc + n2, acc[i][j][r]);
+            }
+        }
+}
+
 // ===================================================================================================
 static int g_force_tile = -1;          // -1: read AVSIAM_GEMM_TILE once; 0 auto; 128 / 256 force a tile (tuning + tests)
 static int g_persistent = 1;           // 256^2 nt tiles: persistent workgroups (0: one workgroup per tile, for A/B tests)
@@ -790,6 +901,7 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_tn_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         if (e != hipSuccess) {
             avs_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -801,7 +913,10 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     const bool can_big = (N1 % 256) == 0 && (N2 % 256) == 0;
     // 256^2 tiles need a long contraction to amortise their 256 KiB atomic epilogue per split
     // ... and enough output tiles that the splits (each adds a full-tile atomic epilogue) stay few
-    const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256 && (N1 / 256) * (N2 / 256) >= 24);
+    // (8-phase kernel: from 12 tiles - the decoder's 1536x512 / 2048x512 gradients gain 14-18 % on it; 9 tiles and fewer lose)
+    if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
+    const int min_tiles = g_nt8 == 1 ? 12 : 24;
+    const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256 && (N1 / 256) * (N2 / 256) >= min_tiles);
     const int T = big ? 256 : 128;
     const int tiles = (N1 / T) * (N2 / T);
     if (splits <= 0) {
@@ -821,7 +936,8 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     const int per = ceil_div(nstages, splits);
     splits = ceil_div(nstages, per);
     GemmTnArgs a{A, lda, B, ldb, C, ldc, M, N1, N2, per};
-    if (big) gemm_tn_kernel<4, 4><<<tiles * splits, 512, 131072, stream>>>(a);
+    if (big && g_nt8 == 1) gemm_tn8_kernel<0><<<tiles * splits, 512, 131072, stream>>>(a);
+    else if (big) gemm_tn_kernel<4, 4><<<tiles * splits, 512, 131072, stream>>>(a);
     else gemm_tn_kernel<2, 2><<<tiles * splits, 256, 65536, stream>>>(a);
     AVS_LAUNCH_CHECK("gemm_tn");
     return 0;
