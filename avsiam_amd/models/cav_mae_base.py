@@ -157,6 +157,14 @@ class CAVMAE_BASE(nn.Module):
         self._shadow_dirty = True
         return out
 
+    def load_vit_pretrained(self, vit_state_dict, seed=0):
+        """Initialise from a timm ViT-B/16 checkpoint (the reference hard-codes jx_vit_base_patch16_224_in21k,
+        cav_mae_base.py:236-240) - see weights.state_from_vit for the derivation of the audio / per-modality copies."""
+        from ..weights import state_from_vit
+        self.arena.load_state(state_from_vit(vit_state_dict, self.cfg, seed))
+        self._shadow_dirty = True
+        self._opt_state.clear()
+
     def mark_weights_changed(self):
         """Call after modifying parameters outside adam_step() (e.g. an external optimizer)."""
         self._shadow_dirty = True

@@ -94,6 +94,37 @@ def _tie_init(st, cfg):
             st[k] = st["vit_base." + k[len("my_"):]].clone()
 
 
+def state_from_vit(vit_sd, cfg: AVSiamConfig, seed: int = 0):
+    """Initial state of CAVMAE_BASE from a timm ViT checkpoint (``jx_vit_base_patch16_224_in21k``: keys ``cls_token``,
+    ``pos_embed``, ``patch_embed.proj.*``, ``blocks.N.*``, ``norm.*``, ``head.*``), the way the reference constructor
+    derives it (/root/reference/src/models/cav_mae_base.py:236-307): the checkpoint goes into ``vit_base`` (non-strict:
+    :240), every block's ``norm1/norm2`` is copied to ``norm1_a/_v`` / ``norm2_a/_v`` (:262-267), ``norm`` to ``norm_a``
+    (:299), the audio patch embedding is the RGB mean of the visual kernel (:291-294), ``pos_embed_a`` the nearest
+    interpolation of the visual table to the audio token count (:298), ``ast_base`` a deep copy of ``vit_base`` (:303),
+    ``mm_layer_1/2`` copies of the last block (:306-307).  Everything the checkpoint does not cover (decoder, mask token,
+    modality embeddings) keeps the synthetic initial state of ``synth_state(cfg, seed)``.
+    Returns {name: fp32 tensor} over the unique tensors of the schema; unknown / mis-shaped checkpoint keys raise."""
+    st = synth_state(cfg, seed, mode="init")
+    for k, val in vit_sd.items():
+        name = "vit_base." + k
+        if name not in st:
+            if k.startswith(("pre_logits", "fc_norm", "head_dist")):     # timm variants carry these; the reference drops them (strict=False)
+                continue
+            raise KeyError(f"checkpoint key '{k}' has no counterpart in the CAVMAE_BASE schema")
+        if tuple(val.shape) != tuple(st[name].shape):
+            raise ValueError(f"checkpoint key '{k}': shape {tuple(val.shape)} != {tuple(st[name].shape)}")
+        st[name] = val.detach().to(torch.float32).clone()
+    for i in range(cfg.depth):
+        for n in ("norm1", "norm2"):
+            for suf in ("_a", "_v"):
+                for wb in ("weight", "bias"):
+                    st[f"vit_base.blocks.{i}.{n}{suf}.{wb}"] = st[f"vit_base.blocks.{i}.{n}.{wb}"].clone()
+    for wb in ("weight", "bias"):
+        st[f"vit_base.norm_a.{wb}"] = st[f"vit_base.norm.{wb}"].clone()
+    _tie_init(st, cfg)
+    return st
+
+
 def synth_inputs(cfg: AVSiamConfig, batch: int, seed: int = 87, constant: float = None):
     """AudioSet-shaped synthetic pair: a ~ N(0,1) [B, target_length, 128] (fbank after normalisation,
     /root/reference/src/dataloader.py:505-506), v ~ N(0,1) [B,(T,)3,224,224] (:152-155).

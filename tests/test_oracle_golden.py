@@ -69,3 +69,47 @@ def test_schema_matches_reference(golden_dir):
     # live sets: 86,426,880 (contrastive pass) and 212,123,392 (MAE pass)
     assert sum(int(np.prod(s.shape)) for s in spec.values() if s.live & 1) == 86426880
     assert sum(int(np.prod(s.shape)) for s in spec.values() if s.live & 2) == 212123392
+
+
+def test_pretrained_vit_init_reproduces_constructor_identities():
+    """a timm ViT-B/16 checkpoint loaded the way the reference constructor does it
+    (/root/reference/src/models/cav_mae_base.py:236-307) - checked on a random timm-shaped state dict."""
+    import torch.nn.functional as F
+    from avsiam_amd.config import AVSiamConfig
+    from avsiam_amd.models import CAVMAE_BASE
+    cfg = AVSiamConfig()
+    g = torch.Generator().manual_seed(3)
+    D, depth = cfg.embed_dim, cfg.depth
+    vit = {"cls_token": torch.randn(1, 1, D, generator=g), "pos_embed": torch.randn(1, 197, D, generator=g),
+           "patch_embed.proj.weight": torch.randn(D, 3, 16, 16, generator=g), "patch_embed.proj.bias": torch.randn(D, generator=g),
+           "norm.weight": torch.randn(D, generator=g), "norm.bias": torch.randn(D, generator=g),
+           "head.weight": torch.randn(21843, D, generator=g), "head.bias": torch.randn(21843, generator=g)}
+    for i in range(depth):
+        b = f"blocks.{i}."
+        for n, shp in (("norm1.weight", (D,)), ("norm1.bias", (D,)), ("attn.qkv.weight", (3 * D, D)), ("attn.qkv.bias", (3 * D,)),
+                       ("attn.proj.weight", (D, D)), ("attn.proj.bias", (D,)), ("norm2.weight", (D,)), ("norm2.bias", (D,)),
+                       ("mlp.fc1.weight", (4 * D, D)), ("mlp.fc1.bias", (4 * D,)), ("mlp.fc2.weight", (D, 4 * D)), ("mlp.fc2.bias", (D,))):
+            vit[b + n] = torch.randn(*shp, generator=g)
+    m = CAVMAE_BASE(cfg=cfg, verbose=False)
+    m.load_vit_pretrained(vit)
+    sd = m.state_dict()
+    assert len(sd) == 963
+    for k, v in vit.items():                                        # the checkpoint itself, under both block names
+        assert torch.equal(sd["vit_base." + k], v), k
+        if k.startswith("blocks."):
+            assert torch.equal(sd["my_" + k], v), k                 # my_blocks aliases vit_base.blocks (:248,278)
+    for i in (0, depth - 1):
+        for n in ("norm1", "norm2"):
+            for suf in ("_a", "_v"):
+                assert torch.equal(sd[f"vit_base.blocks.{i}.{n}{suf}.weight"], vit[f"blocks.{i}.{n}.weight"])      # :262-267
+    assert torch.equal(sd["vit_base.norm_a.bias"], vit["norm.bias"])                                               # :299
+    assert torch.equal(sd["vit_base.patch_embed_a.proj.weight"], vit["patch_embed.proj.weight"].mean(dim=1, keepdim=True))   # :291-294
+    want_pos = F.interpolate(vit["pos_embed"][:, 1:].permute(0, 2, 1), size=[cfg.audio_tokens]).permute(0, 2, 1)
+    assert torch.equal(sd["vit_base.pos_embed_a"], want_pos)                                                        # :298
+    for k in sd:
+        if k.startswith("ast_base."):                                                                               # deepcopy (:303)
+            assert torch.equal(sd[k], sd["vit_base." + k[len("ast_base."):]]), k
+        if k.startswith("mm_layer_1."):                                                                             # :306-307
+            assert torch.equal(sd[k], sd[f"vit_base.blocks.{depth - 1}." + k[len("mm_layer_1."):]]), k
+    with pytest.raises(ValueError):
+        m.load_vit_pretrained({"pos_embed": torch.zeros(1, 577, D)})
