@@ -58,8 +58,9 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
 int avs_gemm_set_tile(int tile);
 /* 1 (default): 256x256 nt tiles run as persistent workgroups (one per CU); 0: one workgroup per tile (A/B measurements) */
 int avs_gemm_set_persistent(int on);
-/* 1: 256x256 nt GEMMs run the 8-phase kernel (two wave groups offset by a barrier, 16-KiB staging granules, counted
- * vmcnt); 0 (default): the two-buffer kernel.  Also AVSIAM_GEMM_NT8=1. */
+/* 1 (default): 256x256 tiles of BOTH GEMMs (nt and tn) run the 8-phase kernels (two wave groups offset by a barrier,
+ * 16-KiB staging granules, counted vmcnt); 0: the two-buffer kernels (A/B measurements, the bitwise cross-check of
+ * tests/test_kernels_gpu.py).  Environment: AVSIAM_GEMM_NT8=0|1. */
 int avs_gemm_set_nt8(int on);
 /* tn (weight gradient): C[N1,N2] += A[M,N1]^T . B[M,N2], fp32 atomics; A and B must be allocated and ZERO up to the
  * next multiple of 64 rows; N1%128==0, N2%128==0; splits<=0 picks a split of the contraction that fills the chip. */
