@@ -94,8 +94,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const int drow = out_map ? out_map[row] : row;
         const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
         const float4* gp = reinterpret_cast<const float4*>(mod ? g1 : g0);
-        float4 xh[NV], gy[NV];
+        float4 xh[NV], gy[NV], rsd[NV];
         float s1 = 0.f, s2 = 0.f;
+        // the residual-gradient row is loaded together with x and dy (not after the two reductions, where its latency
+        // would be exposed once per row)
+        const float4* drr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * D) : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) rsd[i] = drr ? drr[i * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float4 xv = xr[i * 64 + lane];
@@ -124,16 +129,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         const float m1 = wave_sum(s1) * (1.0f / D);
         const float m2 = wave_sum(s2) * (1.0f / D);
         float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * D);
-        const float4* drr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * D) : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             float4 o;
-            o.x = rs * (gy[i].x - m1 - xh[i].x * m2); o.y = rs * (gy[i].y - m1 - xh[i].y * m2);
-            o.z = rs * (gy[i].z - m1 - xh[i].z * m2); o.w = rs * (gy[i].w - m1 - xh[i].w * m2);
-            if (drr) {
-                const float4 r = drr[i * 64 + lane];
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            }
+            o.x = rs * (gy[i].x - m1 - xh[i].x * m2) + rsd[i].x; o.y = rs * (gy[i].y - m1 - xh[i].y * m2) + rsd[i].y;
+            o.z = rs * (gy[i].z - m1 - xh[i].z * m2) + rsd[i].z; o.w = rs * (gy[i].w - m1 - xh[i].w * m2) + rsd[i].w;
             dxr[i * 64 + lane] = o;
             dc[i].x += o.x; dc[i].y += o.y; dc[i].z += o.z; dc[i].w += o.w;      // column sum of dx (bias grad of the producer Linear)
             if (dx_bf16) {
