@@ -283,8 +283,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     const float lse2 = a.lse[(size_t)head * a.rows_total + seq0 + q] * 1.4426950408889634f;
     if (active && hh == 0 && qw + (lane & 31) < L) a.delta[(size_t)head * a.rows_total + seq0 + q] = delta;
     // the query is on the lane, so -lse and -delta are per-lane constants: as the accumulators' initial values they make
-    // the MFMAs deliver log2(p) and (dP - delta) with no VALU work
-    const f32x16 nlse = splat16(-lse2), ndel = splat16(-delta);
+    // the MFMAs deliver log2(p) and (dP - delta) with no VALU work.  Only for hd 32 (VALU-bound, registers to spare): at
+    // hd 64 the two 16-register tuples cost an occupancy step (174 vs 142 VGPRs) that outweighs two VALU ops per score.
+    constexpr bool C_INIT = HD == 32;
+    f32x16 nlse, ndel;
+    if (C_INIT) { nlse = splat16(-lse2); ndel = splat16(-delta); }
 
     f32x16 dq[NDB];
 #pragma unroll
@@ -307,8 +310,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
         if (!active) continue;
         const bool tail_tile = k0 + 64 > L;                 // block-uniform
         auto key_block = [&](int kb) {
-            f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, 0, lane), qf[0], nlse, 0, 0, 0);
-            f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, kb * 32, 0, lane), dof[0], ndel, 0, 0, 0);
+            f32x16 s, dp;
+            if (C_INIT) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, 0, lane), qf[0], nlse, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, kb * 32, 0, lane), dof[0], ndel, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, 0, lane), qf[0], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sV, kb * 32, 0, lane), dof[0], dp, 0, 0, 0);
+            }
 #pragma unroll
             for (int kk = 1; kk < NKK; ++kk) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, kk, lane), qf[kk], s, 0, 0, 0);
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                ds[r] = fast_exp2(s[r]) * dp[r];
+                ds[r] = C_INIT ? fast_exp2(s[r]) * dp[r] : fast_exp2(s[r] - lse2) * (dp[r] - delta);
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
