@@ -26,7 +26,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(avs_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const\s+char\s*\*|long\s+long|int)\s+(avs_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         kinds = []
         if args and args != "void":
@@ -44,7 +44,7 @@ def parse_header(path=HEADER):
                     kinds.append("int")
                 else:
                     raise ValueError(f"unparsed argument '{a}' of {name}")
-        protos[name] = ("str" if "char" in ret else "int", kinds)
+        protos[name] = ("str" if "char" in ret else "ll" if "long" in ret else "int", kinds)
     return protos
 
 
@@ -62,7 +62,7 @@ def load():
     _protos = parse_header()
     for name, (ret, kinds) in _protos.items():
         fn = getattr(lib, name)
-        fn.restype = ctypes.c_char_p if ret == "str" else ctypes.c_int
+        fn.restype = ctypes.c_char_p if ret == "str" else ctypes.c_longlong if ret == "ll" else ctypes.c_int
         fn.argtypes = [_CT[k] for k in kinds]
     _lib = lib
     return lib

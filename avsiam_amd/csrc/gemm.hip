@@ -779,6 +779,9 @@ extern "C" int avs_gemm_set_persistent(int on) {
     return 0;
 }
 
+static long long g_nt_dispatches = 0;      // kernel dispatches issued by avs_gemm_nt_bf16 so far (a call is one or two)
+extern "C" long long avs_gemm_nt_dispatches(void) { return g_nt_dispatches; }
+
 static int g_nt8 = -1;                     // 1: 256^2 GEMMs run the 8-phase kernel (AVSIAM_GEMM_NT8 / avs_gemm_set_nt8)
 extern "C" int avs_gemm_set_nt8(int on) {
     g_nt8 = on ? 1 : 0;
@@ -861,6 +864,7 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
             else if (act == 1) gemm_nt8_kernel<1><<<grid8, 512, 131072, stream>>>(f);
             else gemm_nt8_kernel<2><<<grid8, 512, 131072, stream>>>(f);
             AVS_LAUNCH_CHECK("gemm_nt8");
+            ++g_nt_dispatches;
             if (b.m_full < M) {
                 GemmNtArgs r = a;
                 const size_t o = (size_t)b.m_full;
@@ -878,6 +882,7 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
                 else if (act == 1) gemm_nt_kernel<1, 4, 8><<<grid_r, 512, 131072, stream>>>(r);
                 else gemm_nt_kernel<2, 4, 8><<<grid_r, 512, 131072, stream>>>(r);
                 AVS_LAUNCH_CHECK("gemm_nt (leftover rows)");
+                ++g_nt_dispatches;
             }
             return 0;
         }
@@ -890,6 +895,7 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
         launch_small(a);
     }
     AVS_LAUNCH_CHECK("gemm_nt");
+    ++g_nt_dispatches;
     return 0;
 }
 

@@ -174,10 +174,12 @@ def main():
             flops = sum(s[k]["work"] for k in mm)
             ms = sum(s[k]["total_ms"] for k in mm)
             n = sum(s[k]["launches"] for k in mm)
+            nd = sum(s[k]["dispatches"] for k in mm)
             ach = flops / (ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt8_kernel / gemm_nt_kernel (forward + dgrad bf16 MFMA GEMMs, one avs_gemm_nt_bf16 call = one launch)", "achieved": ach,
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args),
                                 "launches": n, "avg_launch_us": 1e3 * ms / n, "flops_per_launch": flops / n,
+                                "dispatches": nd, "avg_dispatch_us": 1e3 * ms / nd,
                                 "sampling": "all launches" if args.all_kernel_events else "every 5th launch of the timed region"}
             line["kernels"] = {k: {"launches": x["launches"], "total_ms": round(x["total_ms"], 3), "avg_us": round(x["avg_us"], 2),
                                    "rate_T_per_s": round(x["rate"] / 1e12, 3)} for k, x in sorted(s.items())}

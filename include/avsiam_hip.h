@@ -54,6 +54,10 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
                      const float* bias, const float* res, long long ldr, const int* res_idx, const avs_bf16* aux,
                      long long ldaux, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
                      int act, int scale_cols, float col_scale, float* colsum, avs_stream_t stream);
+/* number of kernel dispatches avs_gemm_nt_bf16 has issued so far (a call is one dispatch, or two when the rows left over
+ * after the whole rounds of 256x256 tiles go to the half-height-tile kernel): lets bench.py quote a per-DISPATCH average
+ * that is directly comparable with rocprofv3's per-kernel statistics */
+long long avs_gemm_nt_dispatches(void);
 /* tile selection of the nt kernel: 0 = automatic (256x256 when that alone fills the chip, else 128x128), 128, 256 */
 int avs_gemm_set_tile(int tile);
 /* 1 (default): 256x256 nt tiles run as persistent workgroups (one per CU); 0: one workgroup per tile (A/B measurements) */
