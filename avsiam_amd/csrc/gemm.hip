@@ -74,14 +74,28 @@ struct EpiPrefetch {
 template <int MI>
 __device__ __forceinline__ void epi_load_res(const GemmNtArgs& a, f32x4 (&rs)[EpiPrefetch<MI>::RG][4], int grp, int lane, int mw0, int nw0) {
     const int n = nw0 + (lane & 15) * 4, rq = lane >> 4;
+    // the row gather (res_idx) is decided ONCE, outside the loads: a per-element "index or row" select makes hipcc branch
+    // around every index load and wait vmcnt(0) in front of every residual load - serialising them behind each other
+    // and behind the LDS-DMAs of the next tile that are in flight during the epilogue
+    if (a.res_idx) {
+        int rrow[EpiPrefetch<MI>::RG][4];
 #pragma unroll
-    for (int mj = 0; mj < EpiPrefetch<MI>::RG; ++mj)
+        for (int mj = 0; mj < EpiPrefetch<MI>::RG; ++mj)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = min(mw0 + (grp * EpiPrefetch<MI>::RG + mj) * 16 + i * 4 + rq, a.M - 1);
-            const long long rrow = a.res_idx ? (long long)a.res_idx[m] : (long long)m;
-            rs[mj][i] = *reinterpret_cast<const f32x4*>(a.res + rrow * a.ldr + n);
-        }
+            for (int i = 0; i < 4; ++i) rrow[mj][i] = a.res_idx[min(mw0 + (grp * EpiPrefetch<MI>::RG + mj) * 16 + i * 4 + rq, a.M - 1)];
+#pragma unroll
+        for (int mj = 0; mj < EpiPrefetch<MI>::RG; ++mj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[mj][i] = *reinterpret_cast<const f32x4*>(a.res + (long long)rrow[mj][i] * a.ldr + n);
+    } else {
+#pragma unroll
+        for (int mj = 0; mj < EpiPrefetch<MI>::RG; ++mj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = min(mw0 + (grp * EpiPrefetch<MI>::RG + mj) * 16 + i * 4 + rq, a.M - 1);
+                rs[mj][i] = *reinterpret_cast<const f32x4*>(a.res + (long long)m * a.ldr + n);
+            }
+    }
 }
 
 template <int MI>
@@ -316,13 +330,20 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
         const int em = m0 + wm * (MIT * 16), en = n0 + wn * 64;
         __syncthreads();                                   // every wave is done reading the K-slab buffers
         // both LDS buffers are free now: prefetch the next tile's first slab into buffer 0, stage the epilogue through buffer 1
-        if (v + (int)gridDim.x < ntiles) {
+        // (epilogues that load - fp32 residual, GELU' operand - run with no LDS-DMA in flight, see gemm_nt8_kernel)
+        const bool has_next = v + (int)gridDim.x < ntiles;
+        const bool loads_in_epilogue = (ACT == 0 && a.out_f32 && a.res) || ACT == 2;
+        if (has_next && !loads_in_epilogue) {
             set_tile(v + gridDim.x);
             stage(0, 0);
         }
         EpiPrefetch<MIT> pf;
         nt_epilogue_prefetch<ACT, MIT>(a, pf, lane, em, en);
         nt_epilogue<ACT, MIT>(a, acc, pf, smem + BUF_BYTES, wave, lane, em, en);
+        if (has_next && loads_in_epilogue) {
+            set_tile(v + gridDim.x);
+            stage(0, 0);
+        }
     };
     for (; v < ntiles; v += gridDim.x) {
         if (!half) run_tile(std::integral_constant<int, MI>{});
@@ -484,16 +505,32 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
         if (g == 0) bar();                                    // pairs with G1's last barrier
         const int em = m0 + g * 128, en = n0 + wc * 64;
         __syncthreads();                                      // every wave is done with both buffers, nothing in flight
-        if (v + (int)gridDim.x < ntiles) {
+        const bool has_next = v + (int)gridDim.x < ntiles;
+        // Epilogues that LOAD (fp32 residual rows, GELU' operands) run with no LDS-DMA in flight: beside a pending DMA hipcc
+        // waits vmcnt(0) for every ordinary load it uses and in front of every store that follows, which serialises the
+        // epilogue's memory operations; the next tile's first K-tile is then requested after the epilogue instead.
+        const bool loads_in_epilogue = (ACT == 0 && a.out_f32 && a.res) || ACT == 2;
+        if (has_next && !loads_in_epilogue) {
             set_tile(v + gridDim.x);
             dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
         }
+        // the epilogue's lane-derived constants are recomputed per tile from an opaque copy of the lane id: hoisted out of the
+        // tile loop they would be spilled (the K loop owns the register file) and every reload is a vmcnt(0) in the epilogue
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
         EpiPrefetch<MI> pf;
-        nt_epilogue_prefetch<ACT, MI>(a, pf, lane, em, en);
-        nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, lane, em, en);
+        nt_epilogue_prefetch<ACT, MI>(a, pf, elane, em, en);
+        nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
         // a compiler-visible full drain: the K loop reuses registers the epilogue loaded into, and hipcc would otherwise
         // re-wait for those loads (vmcnt(0)) at the head of EVERY K-tile.  The next tile's first wait drains the stores anyway.
         wait_vm<0>();
+        // the eight DMA source pointers are recomputed here so that they are DEAD during the epilogue: alive, they pushed
+        // the fp32-residual epilogue over the register file, and every spill reload there is a vector-memory op hipcc
+        // waits for with vmcnt(0) - draining the residual loads and the next tile's DMAs each time
+        if (has_next) {
+            set_tile(v + gridDim.x);
+            if (loads_in_epilogue) { dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1); }
+        }
     }
 }
 
