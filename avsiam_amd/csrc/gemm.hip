@@ -116,17 +116,27 @@ __device__ __forceinline__ void nt_epilogue_prefetch(const GemmNtArgs& a, EpiPre
     if (ACT == 0 && a.out_f32 && a.res) epi_load_res<MI>(a, pf.rs[0], 0, lane, mw0, nw0);
 }
 
+// called by the kernels BEFORE they put the next tile's LDS-DMAs in flight: the one global load of the bias path is then
+// waited for on its own (beside a pending DMA hipcc's wait for it is vmcnt(0), i.e. it would wait for the DMAs as well)
+__device__ __forceinline__ void nt_epilogue_stage_bias(const GemmNtArgs& a, char* smem, int wave, int lane, int nw0) {
+    float* sbias = reinterpret_cast<float*>(smem) + (blockDim.x >> 6) * (16 * 68) + wave * 64;       // behind the waves' transpose patches
+    sbias[lane] = a.bias ? a.bias[nw0 + lane] : 0.f;
+}
+
 template <int ACT, int MI>
 __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], EpiPrefetch<MI>& pf, char* smem, int wave, int lane,
                                             int mw0, int nw0) {
     const int fr = lane & 15, fq = lane >> 4;
     float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
     const float alpha = nw0 < a.scale_cols ? a.alpha * a.col_scale : a.alpha;      // wave-uniform (a wave owns 64 columns)
+    // The wave's 64 bias values go through LDS (one coalesced load per tile, re-read per row group with ds_read): kept in
+    // registers they do not fit next to 128 accumulators, and hipcc then RE-LOADS them from global memory in front of
+    // every row group - each reload a vmcnt(0) that also waits for the stores just issued, i.e. a fully serialised
+    // store -> load -> store chain over the whole epilogue.
+    const float* sbias = reinterpret_cast<const float*>(smem) + (blockDim.x >> 6) * (16 * 68) + wave * 64;     // staged by nt_epilogue_stage_bias
     if (ACT == 0 && a.out_f32) {                                                   // fp32 output exists without activation only
         const int cc = (lane & 15) * 4, rq = lane >> 4;
         const int n = nw0 + cc;
-        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + n);
         constexpr int RG = EpiPrefetch<MI>::RG, NG = MI / RG;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -143,6 +153,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     const int m = mw0 + mi * 16 + rr;
                     if (m >= a.M) continue;
                     float v[4] = {t.x, t.y, t.z, t.w};
+                    const float4 bias4 = *reinterpret_cast<const float4*>(sbias + cc);
                     epi_apply4(alpha, 0, v, bias4, make_uint2(0, 0), a.res != nullptr, pf.rs[g & 1][mj][i]);
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
                 }
@@ -151,11 +162,6 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
     } else {
         const int cc = (lane & 7) * 8, rq = lane >> 3;
         const int n = nw0 + cc;
-        float4 bias_lo = make_float4(0.f, 0.f, 0.f, 0.f), bias_hi = bias_lo;
-        if (a.bias) {
-            bias_lo = *reinterpret_cast<const float4*>(a.bias + n);
-            bias_hi = *reinterpret_cast<const float4*>(a.bias + n + 4);
-        }
         constexpr int AG = EpiPrefetch<MI>::AG, NG = MI / AG;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
 #pragma unroll
@@ -174,16 +180,14 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     const int m = mw0 + mi * 16 + rr;
                     if (m >= a.M) continue;
                     float v0[4] = {t0.x, t0.y, t0.z, t0.w}, v1[4] = {t1.x, t1.y, t1.z, t1.w};
-                    const long long rrow = a.res ? (a.res_idx ? (long long)a.res_idx[m] : (long long)m) : 0;
+                    // (no residual here: it exists for fp32 output only - an optional per-row load in this loop would put a
+                    //  vmcnt(0) at its join point in front of every row group's stores, taken or not)
                     u32x4 ax = {0, 0, 0, 0};
                     if (ACT == 2) ax = pf.ax[mj][i];
-                    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-                    if (a.res) {
-                        r0 = *reinterpret_cast<const f32x4*>(a.res + rrow * a.ldr + n);
-                        r1 = *reinterpret_cast<const f32x4*>(a.res + rrow * a.ldr + n + 4);
-                    }
-                    epi_apply4(alpha, ACT, v0, bias_lo, make_uint2(ax[0], ax[1]), a.res != nullptr, r0);
-                    epi_apply4(alpha, ACT, v1, bias_hi, make_uint2(ax[2], ax[3]), a.res != nullptr, r1);
+                    const f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+                    const float4 bias_lo = *reinterpret_cast<const float4*>(sbias + cc), bias_hi = *reinterpret_cast<const float4*>(sbias + cc + 4);
+                    epi_apply4(alpha, ACT, v0, bias_lo, make_uint2(ax[0], ax[1]), false, r0);
+                    epi_apply4(alpha, ACT, v1, bias_hi, make_uint2(ax[2], ax[3]), false, r1);
                     if (a.colsum) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { cs[j] += v0[j]; cs[4 + j] += v1[j]; }
@@ -330,17 +334,13 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
         const int em = m0 + wm * (MIT * 16), en = n0 + wn * 64;
         __syncthreads();                                   // every wave is done reading the K-slab buffers
         // both LDS buffers are free now: prefetch the next tile's first slab into buffer 0, stage the epilogue through buffer 1
-        // (epilogues that load - fp32 residual, GELU' operand - run with no LDS-DMA in flight, see gemm_nt8_kernel)
+        nt_epilogue_stage_bias(a, smem + BUF_BYTES, wave, lane, en);
+        // (the epilogue runs with no LDS-DMA in flight, see gemm_nt8_kernel: the next tile's first slab is requested after it)
         const bool has_next = v + (int)gridDim.x < ntiles;
-        const bool loads_in_epilogue = (ACT == 0 && a.out_f32 && a.res) || ACT == 2;
-        if (has_next && !loads_in_epilogue) {
-            set_tile(v + gridDim.x);
-            stage(0, 0);
-        }
         EpiPrefetch<MIT> pf;
         nt_epilogue_prefetch<ACT, MIT>(a, pf, lane, em, en);
         nt_epilogue<ACT, MIT>(a, acc, pf, smem + BUF_BYTES, wave, lane, em, en);
-        if (has_next && loads_in_epilogue) {
+        if (has_next) {
             set_tile(v + gridDim.x);
             stage(0, 0);
         }
@@ -505,15 +505,12 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
         if (g == 0) bar();                                    // pairs with G1's last barrier
         const int em = m0 + g * 128, en = n0 + wc * 64;
         __syncthreads();                                      // every wave is done with both buffers, nothing in flight
+        nt_epilogue_stage_bias(a, smem + BUF_BYTES, wave, lane, en);
         const bool has_next = v + (int)gridDim.x < ntiles;
-        // Epilogues that LOAD (fp32 residual rows, GELU' operands) run with no LDS-DMA in flight: beside a pending DMA hipcc
-        // waits vmcnt(0) for every ordinary load it uses and in front of every store that follows, which serialises the
-        // epilogue's memory operations; the next tile's first K-tile is then requested after the epilogue instead.
-        const bool loads_in_epilogue = (ACT == 0 && a.out_f32 && a.res) || ACT == 2;
-        if (has_next && !loads_in_epilogue) {
-            set_tile(v + gridDim.x);
-            dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
-        }
+        // The epilogue runs with NO LDS-DMA in flight; the next tile's first K-tile is requested after it.  Beside a pending
+        // DMA hipcc waits vmcnt(0) for every ordinary load it uses (bias, fp32 residual rows, GELU' operands) and - because
+        // a DMA is a pending LDS write it cannot disambiguate - in front of every group of LDS patch reads, so every row
+        // group's stores would wait for the previous group's stores: a fully serialised epilogue.
         // the epilogue's lane-derived constants are recomputed per tile from an opaque copy of the lane id: hoisted out of the
         // tile loop they would be spilled (the K loop owns the register file) and every reload is a vmcnt(0) in the epilogue
         int elane = lane;
@@ -524,12 +521,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
         // a compiler-visible full drain: the K loop reuses registers the epilogue loaded into, and hipcc would otherwise
         // re-wait for those loads (vmcnt(0)) at the head of EVERY K-tile.  The next tile's first wait drains the stores anyway.
         wait_vm<0>();
-        // the eight DMA source pointers are recomputed here so that they are DEAD during the epilogue: alive, they pushed
-        // the fp32-residual epilogue over the register file, and every spill reload there is a vector-memory op hipcc
-        // waits for with vmcnt(0) - draining the residual loads and the next tile's DMAs each time
+        // (the eight DMA source pointers are also only computed here: alive during the epilogue they pushed its fp32-residual
+        //  path over the register file, and a spill reload is one more vector-memory op waited for with vmcnt(0))
         if (has_next) {
             set_tile(v + gridDim.x);
-            if (loads_in_epilogue) { dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1); }
+            dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
         }
     }
 }
@@ -842,6 +838,7 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     AVS_CHECK_ARG(act >= 0 && act <= 2 && (act != 1 || out2) && (act != 2 || aux), "gemm_nt: bad activation arguments");
     AVS_CHECK_ARG(!(out_f32 && act != 0), "gemm_nt: fp32 output is supported with act 0 only");
     AVS_CHECK_ARG(!(out_f32 && colsum), "gemm_nt: the fused column sum is implemented for bf16 output");
+    AVS_CHECK_ARG(!res || out_f32, "gemm_nt: the residual add is implemented for fp32 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
