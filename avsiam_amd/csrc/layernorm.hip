@@ -20,14 +20,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    // the row's modality and output row are requested FIRST and the affine rows before the statistics: loaded where they are
+    // used (after the two reductions) they formed a chain of three dependent memory round trips behind the row itself
+    const int mod = row_mod ? row_mod[row] : 0;
+    const int orow = out_map ? out_map[row] : row;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
     float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
+    const float4* gp = reinterpret_cast<const float4*>(mod ? g1 : g0);
+    const float4* bp = reinterpret_cast<const float4*>(mod ? b1 : b0);
+    float4 gv[NV], bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { gv[i] = gp[i * 64 + lane]; bv[i] = bp[i * 64 + lane]; }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        v[i] = xr[i * 64 + lane];
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(s) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
@@ -37,13 +45,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     const float var = wave_sum(q) * (1.0f / D);
     const float rs = 1.0f / sqrtf(var + eps);
-    const int mod = row_mod ? row_mod[row] : 0;
-    const float4* gp = reinterpret_cast<const float4*>(mod ? g1 : g0);
-    const float4* bp = reinterpret_cast<const float4*>(mod ? b1 : b0);
-    const int orow = out_map ? out_map[row] : row;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const float4 g = gp[i * 64 + lane], b = bp[i * 64 + lane];
+        const float4 g = gv[i], b = bv[i];
         const float4 r = make_float4(v[i].x * rs * g.x + b.x, v[i].y * rs * g.y + b.y, v[i].z * rs * g.z + b.z,
                                      v[i].w * rs * g.w + b.w);
         if (F32IO) {
@@ -69,7 +73,7 @@ constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
 constexpr int LN_SETS = 5;                   // dgamma0, dbeta0, dgamma1, dbeta1, column-sum of dx
 constexpr int LN_REDUCE_CHUNKS = 64;
 
-template <int NV, bool F32IO>
+template <int NV, bool F32IO, bool HAS_RES>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ g0, const float* __restrict__ g1,
@@ -86,21 +90,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         dg0[i] = make_float4(0, 0, 0, 0); db0[i] = dg0[i]; dg1[i] = dg0[i]; db1[i] = dg0[i]; dc[i] = dg0[i];
     }
     const int row0 = blockIdx.x * LN_ROWS_PER_BLOCK + wave * LN_ROWS_PER_WAVE;
+    // lane r (< 16) fetches the per-row scalars of the wave's r-th row once; the row loop reads them with v_readlane.
+    // Loaded inside the loop (modality -> gamma pointer, statistics, output row) they were dependent memory round trips
+    // in front of every row, each a vmcnt(0) that also waited for the previous row's stores.
+    const int lrow = min(row0 + (lane & (LN_ROWS_PER_WAVE - 1)), rows - 1);
+    const int l_mod = row_mod ? row_mod[lrow] : 0;
+    const float l_mean = mean_in[lrow], l_rs = rstd_in[lrow];
+    const int l_drow = out_map ? out_map[lrow] : lrow;
     for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
         const int row = row0 + rr;
         if (row >= rows) break;
-        const int mod = row_mod ? row_mod[row] : 0;
-        const float mean = mean_in[row], rs = rstd_in[row];
-        const int drow = out_map ? out_map[row] : row;
+        const int mod = __builtin_amdgcn_readlane(l_mod, rr);
+        const float mean = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l_mean), rr));
+        const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l_rs), rr));
+        const int drow = __builtin_amdgcn_readlane(l_drow, rr);
         const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
         const float4* gp = reinterpret_cast<const float4*>(mod ? g1 : g0);
         float4 xh[NV], gy[NV], rsd[NV];
         float s1 = 0.f, s2 = 0.f;
         // the residual-gradient row is loaded together with x and dy (not after the two reductions, where its latency
         // would be exposed once per row)
-        const float4* drr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * D) : nullptr;
+        const float4* drr = reinterpret_cast<const float4*>(dres + (size_t)row * D);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) rsd[i] = drr ? drr[i * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NV; ++i) rsd[i] = HAS_RES ? drr[i * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float4 xv = xr[i * 64 + lane];
@@ -207,7 +219,11 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
     AVS_CHECK_ARG(dy && x && mean && rstd && g0 && dx && ws, "layernorm_bwd: null pointer");
     const int nblocks = ceil_div(rows, LN_ROWS_PER_BLOCK);
     dim3 grid(nblocks), block(256);
-#define LN_BWD(NV, F) ln_bwd_kernel<NV, F><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows)
+#define LN_BWD(NV, F)                                                                                                                          \
+    do {                                                                                                                                       \
+        if (dres) ln_bwd_kernel<NV, F, true><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);   \
+        else ln_bwd_kernel<NV, F, false><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);       \
+    } while (0)
     if (dy_f32) {
         if (D == 512) LN_BWD(2, true); else if (D == 768) LN_BWD(3, true); else LN_BWD(4, true);
     } else {
