@@ -82,6 +82,16 @@ int avs_attn_bwd(const avs_bf16* qkv, long long ld, int D, int H, const int* til
                  const int* tile_q0, int ntiles, int tile_rows, const avs_bf16* out, const avs_bf16* dout, long long ldo,
                  const float* lse, float* delta, int rows_total, avs_bf16* dqkv, avs_stream_t stream);
 
+/* ---- input normalisation on the device (what the reference dataloader does per sample on the host: dataloader.py:505-513
+ * fbank = (fbank - norm_mean) / norm_std [+ rand * amp, roll(shift) when `noise`]; :461-462,152-155 frame / 255 then
+ * (x - mean_c) / std_c).  audio: in/out [B, T, F] fp32, out of place, F%4==0; shift/amp per sample or NULL; the noise is a
+ * Philox stream keyed by seed.  frames: in [n_images, 3, plane] uint8 -> out fp32, plane = H*W, plane%4==0; mean3/std3
+ * are HOST pointers to 3 floats. */
+int avs_normalize_audio(const float* in, float* out, int B, int T, int F, float mean, float std, const int* shift,
+                        const float* amp, unsigned long long seed, avs_stream_t stream);
+int avs_normalize_frames_u8(const uint8_t* in, float* out, int n_images, int plane, const float* mean3, const float* std3,
+                            avs_stream_t stream);
+
 /* ---- patch gather of the kept tokens (PatchEmbed input side + random_masking gather: cav_mae_base.py:96-99,
  * 382,431,444-455) */
 int avs_im2col_audio(const float* a, const int* row_b, const int* row_tok, avs_bf16* out, int rows, int tlen, int mel,

@@ -492,3 +492,30 @@ def test_mask_plan_kernel_properties():
     assert torch.equal(ids2, ids)
     o.mask_plan(dev(d), d, 0x1234ABCD5679, row_src, row_tok, dev(tl), dev(th), dev(fm), src_row, mask, ids2)
     assert not torch.equal(ids2, ids)
+
+
+def test_input_normalisation_matches_dataloader_formulas():
+    """fbank / frame normalisation of the reference dataloader (dataloader.py:505-513, 461-462, 152-155)."""
+    import numpy as np
+    from avsiam_amd import preprocess as pp
+    B, T, Fm = 5, 1024, 128
+    fb = torch.randn(B, T, Fm, device=DEV) * 4 - 5
+    out = pp.normalize_fbank(fb, -5.081, 4.4849)
+    assert torch.allclose(out, (fb - (-5.081)) / 4.4849, rtol=1e-6, atol=1e-6)
+    # noise + roll: same amp / shift stream as the wrapper draws, noise within [0, amp), reproducible per seed
+    rng = np.random.default_rng(11)
+    amp = (rng.random(B) / 10).astype(np.float32)
+    shift = rng.integers(-T, T, B)
+    o1 = pp.normalize_fbank(fb, -5.081, 4.4849, noise=True, seed=11)
+    o2 = pp.normalize_fbank(fb, -5.081, 4.4849, noise=True, seed=11)
+    assert torch.equal(o1, o2)
+    for b in range(B):
+        base = torch.roll((fb[b] - (-5.081)) / 4.4849, int(shift[b]), 0)           # fbank = roll(fbank + noise, shift, 0)  (:511-513)
+        d = o1[b] - base
+        assert float(d.min()) >= -1e-5 and float(d.max()) < amp[b] + 1e-5, (b, float(d.min()), float(d.max()), amp[b])
+        assert abs(float(d.mean()) - amp[b] / 2) < 0.02 * amp[b] + 1e-6
+    fr = torch.randint(0, 256, (3, 4, 3, 224, 224), device=DEV, dtype=torch.uint8)
+    got = pp.normalize_frames(fr)
+    mean = torch.tensor(pp.IMAGENET_DEFAULT_MEAN, device=DEV).view(1, 1, 3, 1, 1)
+    std = torch.tensor(pp.IMAGENET_DEFAULT_STD, device=DEV).view(1, 1, 3, 1, 1)
+    assert torch.allclose(got, (fr.float() / 255 - mean) / std, rtol=1e-5, atol=1e-6)
