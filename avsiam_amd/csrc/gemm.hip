@@ -6,10 +6,17 @@
 //
 // Replaces Attention.qkv/.proj (/root/reference/src/models/cav_mae_base.py:51,55,60,77), timm Mlp fc1/fc2 (:138-143),
 // PatchEmbed.proj (:96-99), decoder_embed / decoder_pred_* (:600,634-635) and their autograd backward.
-// Both kernels: 128x128 block tile, K-step 64, 4 waves (2x2) of 64x64, operands streamed HBM -> LDS with
-// global_load_lds (16 B/lane, no VGPR round trip), double-buffered, one barrier per K-step; the LDS image is
-// lane-linear so the bank-conflict swizzle is applied to the per-lane SOURCE address and again on the read.
-// fp32 accumulation on v_mfma_f32_16x16x32_bf16 (nt) / v_mfma_f32_32x32x16_bf16 (tn).
+// Four kernels.  All stream their operands HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip); the LDS image
+// is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and again on the read; fp32
+// accumulation on v_mfma_f32_16x16x32_bf16 (nt) / v_mfma_f32_32x32x16_bf16 (tn, operands by ds_read_b64_tr_b16).
+//   gemm_nt8_kernel  256x256x64 tile, 8-phase schedule (two wave groups offset by a barrier, 16-KiB staging granules,
+//                    counted vmcnt): the forward/dgrad GEMMs whose tiling fills the chip - whole rounds of tiles
+//   gemm_nt_kernel   two-buffer schedule, one barrier per K-step: <.,4,8> 256x256 (here: the rows left over after the
+//                    whole rounds, as 128x256 tiles) and <.,2,4> 128x128 (small problems, 2 workgroups per CU)
+//   gemm_tn8_kernel  256x256 wgrad tile, 8-phase schedule, fp32 atomics; from 12 output tiles and 16384 rows
+//   gemm_tn_kernel   two-buffer wgrad, 128x128 (<2,2>) or 256x256 (<4,4>, A/B reference) tiles
+// One epilogue (nt_epilogue) serves all nt kernels: LDS-staged transposition to 16-B/lane row stores, bias, fp32 residual,
+// column-range scale, GELU dual output, GELU', fused column sum.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
