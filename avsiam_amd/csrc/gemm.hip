@@ -883,9 +883,9 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
         }
-        // Whole rounds: with T tiles on C CUs the last of ceil(T/C) rounds may be nearly empty (1122 tiles -> 4.4 rounds
-        // cost 5).  When the last round would be less than half full, the row panels that fill floor(T/C) rounds stay
-        // 256^2 tiles and the remaining rows become 128 x 256 tiles of the SAME launch: twice as many, half as long.
+        // Two-buffer kernel (8-phase kernels switched off): with T tiles on C CUs the last of ceil(T/C) rounds may be nearly
+        // empty (1122 tiles -> 4.4 rounds cost 5).  When the last round would be less than half full, the row panels that fill
+        // floor(T/C) rounds stay 256^2 tiles and the remaining rows become 128 x 256 tiles of the SAME launch.
         const int nt_n = N / 256, nt_m = ceil_div(M, 256);
         GemmNtArgs b = a;
         if (g_persistent && g_force_tile == 0 && big_tiles > ncu) {
@@ -894,37 +894,15 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
         }
         if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
         if (g_nt8 == 1 && K >= 128 && g_persistent && g_force_tile == 0) {
-            // 8-phase kernel on the whole rounds of full tiles; the leftover rows (if any) as half-height tiles of the
-            // two-buffer kernel (m_full = 0: every row is a half tile) on the shifted operands
-            GemmNtArgs f = a;
-            f.M = b.m_full;
-            f.m_full = b.m_full;
-            const int tiles8 = ceil_div(f.M, 256) * nt_n;
+            // 8-phase kernel, every tile a full 256x256 tile: a partial last round costs it the same as handing the leftover rows
+            // to the half-height-tile kernel in a second dispatch (measured: 185.7 vs 186.0 ms/step), so it keeps one dispatch
+            const int tiles8 = nt_m * nt_n;
             const int grid8 = tiles8 < ncu ? tiles8 : ncu;
-            if (act == 0) gemm_nt8_kernel<0><<<grid8, 512, 131072, stream>>>(f);
-            else if (act == 1) gemm_nt8_kernel<1><<<grid8, 512, 131072, stream>>>(f);
-            else gemm_nt8_kernel<2><<<grid8, 512, 131072, stream>>>(f);
+            if (act == 0) gemm_nt8_kernel<0><<<grid8, 512, 131072, stream>>>(a);
+            else if (act == 1) gemm_nt8_kernel<1><<<grid8, 512, 131072, stream>>>(a);
+            else gemm_nt8_kernel<2><<<grid8, 512, 131072, stream>>>(a);
             AVS_LAUNCH_CHECK("gemm_nt8");
             ++g_nt_dispatches;
-            if (b.m_full < M) {
-                GemmNtArgs r = a;
-                const size_t o = (size_t)b.m_full;
-                r.M = M - b.m_full;
-                r.m_full = 0;
-                r.A = a.A + o * a.lda;
-                if (a.res && !a.res_idx) r.res = a.res + o * a.ldr;
-                if (a.res_idx) r.res_idx = a.res_idx + o;
-                if (a.aux) r.aux = a.aux + o * a.ldaux;
-                r.out = a.out_f32 ? (void*)((float*)a.out + o * a.ldo) : (void*)((bf16_t*)a.out + o * a.ldo);
-                if (a.out2) r.out2 = a.out2 + o * a.ldo2;
-                const int tiles_r = ceil_div(r.M, 128) * nt_n;
-                const int grid_r = tiles_r < ncu ? tiles_r : ncu;
-                if (act == 0) gemm_nt_kernel<0, 4, 8><<<grid_r, 512, 131072, stream>>>(r);
-                else if (act == 1) gemm_nt_kernel<1, 4, 8><<<grid_r, 512, 131072, stream>>>(r);
-                else gemm_nt_kernel<2, 4, 8><<<grid_r, 512, 131072, stream>>>(r);
-                AVS_LAUNCH_CHECK("gemm_nt (leftover rows)");
-                ++g_nt_dispatches;
-            }
             return 0;
         }
         const int tiles_b = ceil_div(b.m_full, 256) * nt_n + (b.m_full < M ? ceil_div(M - b.m_full, 128) * nt_n : 0);
