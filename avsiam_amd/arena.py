@@ -31,32 +31,34 @@ def _needs_transpose(info):
 
 
 class ParamArena:
-    def __init__(self, cfg: AVSiamConfig):
+    def __init__(self, cfg: AVSiamConfig, spec=None, transposed=True, grads=True):
+        """spec: parameter schema (default: CAVMAE_BASE's); transposed=False skips the [K,N] weight copies, which only
+        the backward (dgrad) GEMMs read, and grads=False the flat gradient buffer - inference-only models need neither."""
         self.cfg = cfg
-        spec = build_spec(cfg)
+        self.with_grads = grads
+        spec = build_spec(cfg) if spec is None else spec
         order = ([s for s in spec if s.live == P1] + [s for s in spec if s.live == (P1 | P2)] +
                  [s for s in spec if s.live == P2] + [s for s in spec if s.live == 0])
         self.info = {s.name: s for s in spec}
         self.offset = {}
         off = 0
-        marks = {}
-        prev = None
+        begin = {}                       # first offset of each liveness class present
         for s in order:
-            cls = s.live
-            if cls != prev:
-                marks[cls] = off
-                prev = cls
+            begin.setdefault(s.live, off)
             self.offset[s.name] = off
             off += (math.prod(s.shape) + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
-        self.live_end = marks.get(0, off)
-        self.range = {P1: (marks[P1], marks[P2]), P2: (marks[P1 | P2], self.live_end)}
+        self.live_end = begin.get(0, off)
+        b2 = begin.get(P2, self.live_end)            # classes that are absent collapse to empty ranges
+        b12 = begin.get(P1 | P2, b2)
+        b1 = begin.get(P1, b12)
+        self.range = {P1: (b1, b2), P2: (b12, self.live_end)}
         self.names = [s.name for s in order]
         # transposed-copy arena
         self.t_offset = {}
         toff = 0
         for s in order:
-            if _needs_transpose(s):
+            if transposed and _needs_transpose(s):
                 self.t_offset[s.name] = toff
                 toff += (math.prod(s.shape) + ALIGN - 1) // ALIGN * ALIGN
         self.t_total = toff
@@ -77,7 +79,7 @@ class ParamArena:
         self.p = self.p.to(device)
         self._tr_tables = {}
         if self.p.is_cuda:
-            self.g = torch.zeros(self.live_end, dtype=torch.float32, device=device)
+            self.g = torch.zeros(self.live_end, dtype=torch.float32, device=device) if self.with_grads else None
             self.pb = torch.zeros(self.live_end, dtype=torch.bfloat16, device=device)
             self.wt = torch.zeros(self.t_total, dtype=torch.bfloat16, device=device)
         else:

@@ -193,15 +193,16 @@ extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, 
 extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
                                  const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
                                  int rows, int D, float eps, hipStream_t stream) {
-    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
+    // D = 1536: the concatenated audio|video feature of the fusion classification head (forward only)
+    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1536), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(x && g0 && b0 && y && mean && rstd, "layernorm_fwd: null pointer");
     AVS_CHECK_ARG(!row_mod || (g1 && b1), "layernorm_fwd: row_mod given without second affine set");
     dim3 grid(ceil_div(rows, 4)), block(256);
 #define LN_FWD(NV, F) ln_fwd_kernel<NV, F><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps)
     if (y_f32) {
-        if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else LN_FWD(4, true);
+        if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else if (D == 1024) LN_FWD(4, true); else LN_FWD(6, true);
     } else {
-        if (D == 512) LN_FWD(2, false); else if (D == 768) LN_FWD(3, false); else LN_FWD(4, false);
+        if (D == 512) LN_FWD(2, false); else if (D == 768) LN_FWD(3, false); else if (D == 1024) LN_FWD(4, false); else LN_FWD(6, false);
     }
 #undef LN_FWD
     AVS_LAUNCH_CHECK("layernorm_fwd");

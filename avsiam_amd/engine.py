@@ -37,16 +37,18 @@ class Linear:
 
     def __init__(self, arena: ParamArena, wname, bname, need_t=True):
         self.w = arena.wb(wname)
-        self.wt = arena.wtb(wname) if need_t else None
+        self.wt = arena.wtb(wname) if need_t and wname in arena.t_offset else None
         self.b = arena.w(bname)
-        self.gw = arena.gw(wname)
-        self.gb = arena.gw(bname)
+        grads = arena.g is not None
+        self.gw = arena.gw(wname) if grads else None
+        self.gb = arena.gw(bname) if grads else None
 
 
 class Norm:
     def __init__(self, arena: ParamArena, prefix):
         self.g, self.b = arena.w(prefix + ".weight"), arena.w(prefix + ".bias")
-        self.dg, self.db = arena.gw(prefix + ".weight"), arena.gw(prefix + ".bias")
+        grads = arena.g is not None
+        self.dg, self.db = (arena.gw(prefix + ".weight"), arena.gw(prefix + ".bias")) if grads else (None, None)
 
 
 class BlockParams:
@@ -80,24 +82,41 @@ def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, 
 class Stack:
     """`nblocks` transformer blocks over a packed [rows, D] fp32 residual stream with saved activations."""
 
-    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None):
+    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None, inference=False):
+        """inference=True: forward only - no activation is kept, every block reuses one set of buffers (the residual stream
+        ping-pongs between two) and the backward scratch is not allocated."""
         assert sum(seq_lens) == rows
         self.rows, self.D, self.H, self.hidden, self.nblocks = rows, D, H, hidden, nblocks
         self.row_mod = row_mod
+        self.inference = inference
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
         self.tiles = ops.AttnTiles(seq_lens, dev)
         self.q_scale = ops.attn_q_scale(D // H)          # q leaves the qkv GEMM ready for the attention kernels
-        self.x = [_z((rp, D), F32, dev) for _ in range(nblocks + 1)]     # x[i] = input of block i; x[-1] = output
-        self.xmid = [_z((rp, D), F32, dev) for _ in range(nblocks)]
-        self.ln1 = [_z((rp, D), BF16, dev) for _ in range(nblocks)]
-        self.ln2 = [_z((rp, D), BF16, dev) for _ in range(nblocks)]
-        self.qkv = [_z((rp, 3 * D), BF16, dev) for _ in range(nblocks)]
-        self.att = [_z((rp, D), BF16, dev) for _ in range(nblocks)]
-        self.fc1 = [_z((rp, hidden), BF16, dev) for _ in range(nblocks)]
-        self.act = [_z((rp, hidden), BF16, dev) for _ in range(nblocks)]
-        self.lse = [_z((H, rp), F32, dev) for _ in range(nblocks)]
-        self.stats = [[_z((rp,), F32, dev) for _ in range(4)] for _ in range(nblocks)]   # mean1 rstd1 mean2 rstd2
+
+        def per_block(shape, dtype):
+            if inference:
+                one = _z(shape, dtype, dev)
+                return [one] * nblocks
+            return [_z(shape, dtype, dev) for _ in range(nblocks)]
+
+        if inference:
+            ping = [_z((rp, D), F32, dev) for _ in range(2)]
+            self.x = [ping[i & 1] for i in range(nblocks + 1)]
+        else:
+            self.x = [_z((rp, D), F32, dev) for _ in range(nblocks + 1)]     # x[i] = input of block i; x[-1] = output
+        self.xmid = per_block((rp, D), F32)
+        self.ln1 = per_block((rp, D), BF16)
+        self.ln2 = self.ln1 if inference else per_block((rp, D), BF16)
+        self.qkv = per_block((rp, 3 * D), BF16)
+        self.att = per_block((rp, D), BF16)
+        self.fc1 = per_block((rp, hidden), BF16)
+        self.act = per_block((rp, hidden), BF16)
+        self.lse = per_block((H, rp), F32)
+        st = [_z((rp,), F32, dev) for _ in range(4)] if inference else None
+        self.stats = [st if inference else [_z((rp,), F32, dev) for _ in range(4)] for _ in range(nblocks)]   # mean1 rstd1 mean2 rstd2
+        if inference:
+            return
         # backward scratch (shared by all blocks)
         self.dx = [_z((rp, D), F32, dev) for _ in range(2)]
         self.dxb = [_z((rp, D), BF16, dev) for _ in range(2)]
@@ -129,6 +148,7 @@ class Stack:
         Bias gradients of fc2 / proj are column sums of the residual-stream gradient and come out of the LayerNorm
         backward that produces it (`dcol`); `last_fc2_bias_done` says the caller's LN backward already did that for
         the last block."""
+        assert not self.inference, "Stack(inference=True) keeps no activations"
         M = self.rows
         dxo, dxm = self.dx
         dbo, dbm = self.dxb
@@ -167,7 +187,7 @@ class PatchEmbedder:
         pname = "vit_base.pos_embed_a" if audio else "vit_base.pos_embed"
         D = cfg.embed_dim
         self.pos = arena.view(pname).view(-1, D)
-        self.gpos = arena.gview(pname).view(-1, D)
+        self.gpos = arena.gview(pname).view(-1, D) if arena.g is not None else None
         K = cfg.patch * cfg.patch * (1 if audio else cfg.in_chans)
         rp = ops.pad_rows(rows, 128)
         self.cols = _z((rp, K), BF16, dev)

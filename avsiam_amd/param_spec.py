@@ -117,6 +117,49 @@ def build_spec(cfg: AVSiamConfig):
     return spec
 
 
+def build_spec_ft(cfg: AVSiamConfig, label_dim: int):
+    """Unique tensors of ``CAVMAEFT_BASE`` (/root/reference/src/models/cav_mae_base.py:744-825): the Siamese ViT with its
+    per-modality norms and audio embedding (:747-804), four classification heads LayerNorm+Linear (:809-815) and the two
+    fusion blocks, copies of blocks 10 / 11 (:821-822).  There is one pass (inference), so every tensor the forward modes
+    (:827-1035) read is tagged P1 and the rest 0."""
+    D, p = cfg.embed_dim, cfg.patch
+    spec = []
+    for s in _tower("vit_base", cfg, "vit"):
+        spec.append(ParamInfo(s.name, s.shape, s.kind, P1 if s.live else 0))
+    spec += [
+        ParamInfo("my_patch_embed.proj.weight", (D, cfg.in_chans, p, p), "conv_w", 0),
+        ParamInfo("my_patch_embed.proj.bias", (D,), "bias", 0),
+        ParamInfo("my_patch_embed_a.proj.weight", (D, 1, p, p), "conv_w", 0),
+        ParamInfo("my_patch_embed_a.proj.bias", (D,), "bias", 0),
+    ]
+    for n, width in (("mlp_head", D), ("mlp_head_a", D), ("mlp_head_mm", 2 * D), ("mlp_head_mm_v2", D)):
+        lv = 0 if n == "mlp_head_mm_v2" else P1                              # mm_v2 is constructed (:815) but no mode reads it
+        spec += [
+            ParamInfo(f"{n}.0.weight", (width,), "ln_w", lv),
+            ParamInfo(f"{n}.0.bias", (width,), "ln_b", lv),
+            ParamInfo(f"{n}.1.weight", (label_dim, width), "linear_w", lv),
+            ParamInfo(f"{n}.1.bias", (label_dim,), "bias", lv),
+        ]
+    for n in ("mm_layer_1", "mm_layer_2"):                                   # applied with 'a' norms :946-947,1023-1024
+        spec += _block(n, D, D * cfg.mlp_ratio, 0, P1, 0, P1)
+    names = [s.name for s in spec]
+    assert len(set(names)) == len(names)
+    return spec
+
+
+def state_dict_keys_ft(cfg: AVSiamConfig, label_dim: int):
+    """Keys of ``CAVMAEFT_BASE.state_dict()`` in module-registration order (553 at ViT-B): vit_base, my_blocks (alias),
+    my_patch_embed, my_patch_embed_a, the four heads, mm_layer_1/2."""
+    spec = build_spec_ft(cfg, label_dim)
+    vit = [s.name for s in spec if s.name.startswith("vit_base.")]
+    keys = list(vit)
+    keys += ["my_blocks." + n[len("vit_base.blocks."):] for n in vit if n.startswith("vit_base.blocks.")]
+    for pre in ("my_patch_embed.", "my_patch_embed_a.", "mlp_head.", "mlp_head_a.", "mlp_head_mm.", "mlp_head_mm_v2.",
+                "mm_layer_1.", "mm_layer_2."):
+        keys += [s.name for s in spec if s.name.startswith(pre)]
+    return keys
+
+
 def alias_of(name: str) -> str:
     """``my_blocks.*`` is the same module object as ``vit_base.blocks.*`` (cav_mae_base.py:248,278)."""
     if name.startswith("my_blocks."):

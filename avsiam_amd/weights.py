@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from .config import AVSiamConfig
-from .param_spec import alias_of, build_spec
+from .param_spec import alias_of, build_spec, build_spec_ft
 
 
 def _stream(seed: int, name: str):
@@ -44,9 +44,9 @@ def _random_tensor(info, seed):
     return torch.from_numpy(x.reshape(info.shape))
 
 
-def synth_state(cfg: AVSiamConfig, seed: int = 0, mode: str = "init", include_dead: bool = True):
-    """Returns {name: fp32 tensor} for the unique tensors of the schema."""
-    spec = build_spec(cfg)
+def synth_state(cfg: AVSiamConfig, seed: int = 0, mode: str = "init", include_dead: bool = True, spec=None):
+    """Returns {name: fp32 tensor} for the unique tensors of the schema (`spec`: default CAVMAE_BASE's)."""
+    spec = build_spec(cfg) if spec is None else spec
     out = {}
     for info in spec:
         if not include_dead and info.live == 0:
@@ -65,6 +65,19 @@ def synth_state(cfg: AVSiamConfig, seed: int = 0, mode: str = "init", include_de
     if mode == "init":
         _tie_init(out, cfg)
     return out
+
+
+def synth_state_ft(cfg: AVSiamConfig, label_dim: int, seed: int = 0, mode: str = "init"):
+    """State of ``CAVMAEFT_BASE`` (553 keys / 313 unique tensors at ViT-B).  Tensors are keyed by name, so the shared ViT
+    equals ``synth_state``'s for the same seed; mode 'init' also applies the constructor's identities, where the fusion
+    blocks are copies of blocks 10 AND 11 (cav_mae_base.py:821-822), not twice the last one as in the pre-training model."""
+    st = synth_state(cfg, seed, mode, spec=build_spec_ft(cfg, label_dim))
+    if mode == "init":
+        pre = f"vit_base.blocks.{cfg.depth - 2}."
+        for k in list(st.keys()):
+            if k.startswith(pre):
+                st["mm_layer_1." + k[len(pre):]] = st[k].clone()
+    return st
 
 
 def _tie_init(st, cfg):

@@ -275,3 +275,64 @@ def adam_step(p, g, m, v, step, lr, beta1=0.95, beta2=0.999, eps=1e-8, weight_de
     bc2 = 1 - beta2 ** step
     denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
     p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# =====================================================================================================
+# CAVMAEFT_BASE inference modes (cav_mae_base.py:827-1035).  P holds the fine-tuned model's state dict.
+def _head(x, P, name):
+    """nn.Sequential(LayerNorm, Linear) heads, :809-815."""
+    return F.linear(_ln(x, P, name + ".0", LN_EPS_BLOCK), P[name + ".1.weight"], P[name + ".1.bias"])
+
+
+def ft_encode_audio(P, cfg, a):
+    """:829-841 - all 512 audio tokens through the shared blocks with the '_a' norms, then norm_a."""
+    a = embed_audio(P, a)
+    for i in range(cfg.depth):
+        a = block(a, P, f"vit_base.blocks.{i}", cfg.num_heads, "a")
+    return _ln(a, P, "vit_base.norm_a", LN_EPS_FINAL)
+
+
+def ft_encode_video(P, cfg, v):
+    """:851-860 - v [B,T,3,H,W] folded to (b t); '_v' norms, then norm.  -> [(b t), Lv, D]"""
+    vv = v.reshape(v.shape[0] * v.shape[1], *v.shape[2:])
+    vv = embed_video(P, vv)
+    for i in range(cfg.depth):
+        vv = block(vv, P, f"vit_base.blocks.{i}", cfg.num_heads, "v")
+    return _ln(vv, P, "vit_base.norm", LN_EPS_FINAL)
+
+
+def _ft_fuse(P, cfg, a, vt):
+    """:944-952 / :1022-1029 - concat tokens, two fusion blocks with the 'a' norms, per-part means side by side."""
+    La = a.shape[1]
+    av = torch.cat((a, vt), dim=1)
+    av = block(av, P, "mm_layer_1", cfg.num_heads, "a")
+    av = block(av, P, "mm_layer_2", cfg.num_heads, "a")
+    av = torch.cat((av[:, :La].mean(dim=1), av[:, La:].mean(dim=1)), dim=-1)
+    return _head(av, P, "mlp_head_mm")
+
+
+def ft_forward(P, cfg, a, v, mode, is_eval=False):
+    """CAVMAEFT_BASE.forward, :827-1035."""
+    if mode == "audioonly":
+        out = _head(ft_encode_audio(P, cfg, a).mean(dim=1), P, "mlp_head_a")
+        return out.unsqueeze(1) if is_eval else out                                       # :845-847
+    if mode == "videoonly":
+        B, T = v.shape[:2]
+        x = _head(ft_encode_video(P, cfg, v).mean(dim=1), P, "mlp_head")
+        return x.reshape(B, T, -1).squeeze(1)                                             # :865
+    if mode == "retrieval":
+        B, T = v.shape[:2]
+        ta = ft_encode_audio(P, cfg, a)
+        tv = ft_encode_video(P, cfg, v)
+        return ta, tv.reshape(B, T, *tv.shape[1:])[:, 5]                                  # :892
+    if mode == "mm_grad":
+        B, T = v.shape[:2]
+        ta = ft_encode_audio(P, cfg, a)
+        tv = ft_encode_video(P, cfg, v)
+        if is_eval:
+            tv = tv.reshape(B, T, *tv.shape[1:])
+            return torch.stack([_ft_fuse(P, cfg, ta, tv[:, t]) for t in range(10)], dim=1)   # :940-961  [B,10,L]
+        out_a = _head(ta.mean(dim=1), P, "mlp_head_a")                                    # :1019
+        out_v = _head(tv.mean(dim=1), P, "mlp_head")                                      # :1020
+        return _ft_fuse(P, cfg, ta, tv), out_a, out_v                                     # :1035
+    return None

@@ -40,7 +40,12 @@ def import_reference_module():
     return importlib.import_module("models.cav_mae_base")
 
 
-def build_reference_model():
+def build_reference_ft_model(label_dim):
+    """Construct the reference ``CAVMAEFT_BASE(label_dim)`` on CPU (weights are loaded by the caller)."""
+    return build_reference_model("CAVMAEFT_BASE", label_dim)
+
+
+def build_reference_model(cls="CAVMAE_BASE", *ctor_args):
     """Construct the reference ``CAVMAE_BASE()`` on CPU (random init; weights are loaded by the caller)."""
     import torch
     mod = import_reference_module()
@@ -58,7 +63,7 @@ def build_reference_model():
         import contextlib
         import io
         with contextlib.redirect_stdout(io.StringIO()):
-            model = mod.CAVMAE_BASE()
+            model = getattr(mod, cls)(*ctor_args)
     finally:
         torch.load = real_load
     return model

@@ -47,3 +47,24 @@ def check_grads_against_golden(d, grads, rel_l2=1e-4, abs_samples=None):
         assert err <= tol * 10, (n, err, tol)
         worst = max(worst, abs(l2 - gl2[i]) / max(gl2[i], 1e-12))
     return worst
+
+
+FT_CASES = ["ft_audio", "ft_audio_eval", "ft_video", "ft_retrieval", "ft_mm", "ft_mm_eval"]
+
+
+def ft_case_inputs(d, cfg):
+    """Inputs of a fine-tuned-model golden case (oracle/gen_golden_ft.py::ft_inputs): a [B,1024,128], v [B,T,3,224,224]."""
+    import dataclasses
+    from avsiam_amd.weights import synth_inputs
+    B, T = int(d["batch"]), int(d["frames"])
+    a, v = synth_inputs(dataclasses.replace(cfg, frames=T), B, int(d["input_seed"]))
+    return a, (v.unsqueeze(1) if T == 1 else v)
+
+
+def ft_outputs_as_dict(d, out):
+    """Name the outputs of CAVMAEFT_BASE.forward the way the golden files do."""
+    if str(d["mode"]) == "retrieval":
+        return {"tokens_a": out[0], "tokens_v": out[1]}
+    if isinstance(out, tuple):
+        return dict(zip(("out", "out_a", "out_v"), out))
+    return {"out": out}

@@ -1,0 +1,134 @@
+"""Fine-tuned model (CAVMAEFT_BASE) inference modes on a real MI355X, through the C ABI: against the golden vectors the
+unmodified reference produced (tests/golden/ft_*.npz), against the CPU oracle at a shape the goldens do not cover, and
+through size-independent properties at a serving-size batch.
+
+Tolerance (bf16 GEMM/attention operands with fp32 accumulation and an fp32 residual stream vs the fp32 reference): logits
+have sigma ~ 0.55-0.8 here; every logit row must have cosine >= 0.999 with the reference row and max |error| <= 0.05;
+token matrices (retrieval) relative L2 error <= 2e-2 on the sampled elements."""
+import numpy as np
+import pytest
+import torch
+
+from avsiam_amd.config import AVSiamConfig
+from avsiam_amd.weights import synth_state_ft
+from tests.helpers import FT_CASES, ft_case_inputs, ft_outputs_as_dict, load_golden, sample_positions
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_ABS, LOGIT_COS, TOKEN_REL = 0.05, 0.999, 2e-2
+
+
+def _model(label_dim, seed, mode="random"):
+    from avsiam_amd.models import CAVMAEFT_BASE
+    return CAVMAEFT_BASE(label_dim, init_seed=seed, init_mode=mode).cuda()
+
+
+def _check_logits(got, ref, what):
+    got = torch.as_tensor(got).double().cpu()
+    ref = torch.as_tensor(ref).double()
+    assert tuple(got.shape) == tuple(ref.shape), (what, got.shape, ref.shape)
+    g, r = got.reshape(-1, got.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    cos = torch.nn.functional.cosine_similarity(g, r, dim=1)
+    err = float((g - r).abs().max())
+    assert float(cos.min()) >= LOGIT_COS and err <= LOGIT_ABS, (what, float(cos.min()), err)
+    return float(cos.min()), err
+
+
+_models = {}
+
+
+def _golden_model(d):
+    key = (int(d["label_dim"]), int(d["weight_seed"]))
+    if key not in _models:
+        _models[key] = _model(*key)
+    return _models[key]
+
+
+@pytest.mark.parametrize("name", FT_CASES)
+def test_ft_modes_match_reference_golden(name):
+    d = load_golden(name)
+    cfg = AVSiamConfig()
+    a, v = ft_case_inputs(d, cfg)
+    m = _golden_model(d)
+    out = m(a.cuda(), v.cuda(), str(d["mode"]), is_eval=bool(d["is_eval"]))
+    for k, t in ft_outputs_as_dict(d, out).items():
+        if k.startswith("tokens"):
+            assert tuple(t.shape) == tuple(d[k + "_shape"])
+            p = t.double().cpu().reshape(-1)
+            idx = sample_positions(k, p.numel(), 256)
+            s = np.array([p[i].item() for i in idx])
+            rel = np.linalg.norm(s - d[k + "_samples"]) / np.linalg.norm(d[k + "_samples"])
+            assert rel <= TOKEN_REL, (k, rel)
+            assert abs(p.norm().item() / float(d[k + "_l2"]) - 1) <= 1e-2
+        else:
+            _check_logits(t, d[k], f"{name}.{k}")
+
+
+def test_ft_mm_grad_matches_oracle_odd_batch():
+    """B = 3 (not a power of two), label_dim = 10 (padded to 128 columns inside the head GEMM), init-mode weights."""
+    from oracle import ref_cpu
+    from avsiam_amd.weights import synth_inputs
+    torch.set_num_threads(16)
+    cfg = AVSiamConfig()
+    a, v = synth_inputs(cfg, 3, 5)
+    v = v.unsqueeze(1)
+    m = _model(10, 7, "init")
+    out = m(a.cuda(), v.cuda(), "mm_grad")
+    P = synth_state_ft(cfg, 10, 7, "init")
+    with torch.no_grad():
+        ref = ref_cpu.ft_forward(P, cfg, a, v, "mm_grad")
+    for g, r, k in zip(out, ref, ("out", "out_a", "out_v")):
+        g, r = g.double().cpu(), r.double()
+        assert g.shape == r.shape == (3, 10)
+        assert float((g - r).abs().max()) <= 0.05 * max(1.0, float(r.abs().max())), (k, float((g - r).abs().max()))
+
+
+def test_ft_serving_batch_properties():
+    """16 clips x 10 frames (8 192 audio + 31 360 frame rows in the encoder, 113 280 rows in the fusion blocks): logits are finite, clip order does not
+    matter (every clip is its own set of sequences), the audio-only / video-only modes agree with the per-modality heads
+    of the same clips, and a changed weight is picked up after mark_weights_changed()."""
+    cfg = AVSiamConfig()
+    B, T, L = 16, 10, 527
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(B, cfg.audio_len, cfg.n_mels, generator=g).cuda()
+    v = torch.randn(B, T, 3, cfg.img_size, cfg.img_size, generator=g).cuda()
+    m = _golden_model({"label_dim": L, "weight_seed": 4321})
+    out = m(a, v, "mm_grad", is_eval=True)
+    assert out.shape == (B, 10, L) and bool(torch.isfinite(out).all())
+    perm = torch.randperm(B, generator=g).cuda()
+    out_p = m(a[perm], v[perm], "mm_grad", is_eval=True)
+    assert float((out_p - out[perm]).abs().max()) <= 2e-3          # same kernels, different tile neighbours only
+    oa = m(a, None, "audioonly", is_eval=True)
+    ov = m(None, v, "videoonly")
+    assert oa.shape == (B, 1, L) and ov.shape == (B, T, L)
+    ta, tv = m(a, v, "retrieval")
+    assert ta.shape == (B, cfg.audio_tokens, cfg.embed_dim) and tv.shape == (B, cfg.video_tokens, cfg.embed_dim)
+    # the video-only logits of frame 5 come from the mean of exactly the frame-5 tokens the retrieval mode returns
+    sd = m.state_dict()
+    pooled = tv.mean(dim=1)
+    h = torch.nn.functional.layer_norm(pooled, (cfg.embed_dim,), sd["mlp_head.0.weight"], sd["mlp_head.0.bias"], 1e-5)
+    ref5 = h @ sd["mlp_head.1.weight"].t() + sd["mlp_head.1.bias"]
+    assert float((ref5 - ov[:, 5]).abs().max()) <= 0.03
+    with torch.no_grad():
+        m.get_parameter("mlp_head_a.1.bias").add_(1.0)
+    m.mark_weights_changed()
+    oa2 = m(a, None, "audioonly", is_eval=True)
+    assert float((oa2 - oa - 1.0).abs().max()) <= 1e-4
+    with torch.no_grad():
+        m.get_parameter("mlp_head_a.1.bias").sub_(1.0)
+    m.mark_weights_changed()
+
+
+def test_ft_rejects_shapes_the_reference_cannot_run():
+    cfg = AVSiamConfig()
+    m = _golden_model({"label_dim": 527, "weight_seed": 4321})
+    a = torch.zeros(2, cfg.audio_len, cfg.n_mels).cuda()
+    v3 = torch.zeros(2, 3, 3, cfg.img_size, cfg.img_size).cuda()
+    with pytest.raises(ValueError):            # torch.cat of [B,...] and [B*T,...] tokens (:1022) fails for T != 1
+        m(a, v3, "mm_grad")
+    with pytest.raises(ValueError):            # `for t_idx in range(10)` (:940) needs 10 frames
+        m(a, v3, "mm_grad", is_eval=True)
+    with pytest.raises(IndexError):            # v[:, 5] (:892)
+        m(a, v3, "retrieval")
+    with pytest.raises(ValueError):
+        m(a[:, :100], v3, "audioonly")
