@@ -3,7 +3,8 @@ unmodified reference produced (tests/golden/ft_*.npz), against the CPU oracle at
 through size-independent properties at a serving-size batch.
 
 Tolerance (bf16 GEMM/attention operands with fp32 accumulation and an fp32 residual stream vs the fp32 reference): logits
-have sigma ~ 0.55-0.8 here; every logit row must have cosine >= 0.999 with the reference row and max |error| <= 0.05;
+have sigma ~ 0.55-0.8 here; every logit row must have cosine >= 0.9999 with the reference row and max |error| <= 0.03
+(measured: 0.99999 and 0.012, tools/bench_ft.py --errors);
 token matrices (retrieval) relative L2 error <= 2e-2 on the sampled elements."""
 import numpy as np
 import pytest
@@ -15,7 +16,7 @@ from tests.helpers import FT_CASES, ft_case_inputs, ft_outputs_as_dict, load_gol
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_ABS, LOGIT_COS, TOKEN_REL = 0.05, 0.999, 2e-2
+LOGIT_ABS, LOGIT_COS, TOKEN_REL = 0.03, 0.9999, 2e-2
 
 
 def _model(label_dim, seed, mode="random"):
