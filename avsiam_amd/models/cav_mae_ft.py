@@ -20,6 +20,7 @@ from ..weights import synth_state_ft
 from .cav_mae_base import _attach
 
 MODES = ("audioonly", "videoonly", "retrieval", "mm_grad")
+MAX_ENGINES = 4          # (batch, frames) shapes whose activation buffers are kept resident
 
 
 class CAVMAEFT_BASE(nn.Module):
@@ -85,7 +86,11 @@ class CAVMAEFT_BASE(nn.Module):
         key = (batch, frames)
         if key not in self._engines:
             from ..ft_engine import FtForward
+            while len(self._engines) >= MAX_ENGINES:               # serving with many batch shapes: drop the oldest buffers
+                self._engines.pop(next(iter(self._engines)))
             self._engines[key] = FtForward(self.arena, self.cfg, self.label_dim, batch, frames, self.arena.p.device)
+        else:
+            self._engines[key] = self._engines.pop(key)            # most recently used last
         return self._engines[key]
 
     def forward(self, a, v, mode, is_eval=False):
