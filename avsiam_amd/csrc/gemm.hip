@@ -65,6 +65,23 @@ __device__ __forceinline__ void epi_apply4(float alpha, int ACT, float (&v)[4], 
     v[0] *= alpha; v[1] *= alpha; v[2] *= alpha; v[3] *= alpha;
 }
 
+// LDS traffic of the epilogue goes through inline asm (like the fragment reads of the 8-phase loops): to hipcc an LDS-DMA in
+// flight is a pending LDS store it cannot disambiguate, so beside the next tile's first K-tile DMAs it would put
+// s_waitcnt vmcnt(0) in front of every compiler-visible ds_read - which also waits for every global store issued so far.
+// An asm statement is opaque to that logic; completion is waited for by hand (epi_lds_wait).
+template <int OFF>
+__device__ __forceinline__ void epi_lds_w128(unsigned addr, const f32x4& v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void epi_lds_r128(f32x4& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void epi_lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Operands the epilogue reads from HBM (fp32 residual rows / bf16 GELU' pre-activations) are loaded in groups that are
 // double-buffered in registers: a load in the epilogue is synchronous (its latency is paid by the one workgroup of the
 // CU), so group g+1 is in flight while group g is transposed and stored, and group 0 is issued by the caller BEFORE the
@@ -134,16 +151,21 @@ template <int ACT, int MI>
 __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], EpiPrefetch<MI>& pf, char* smem, int wave, int lane,
                                             int mw0, int nw0) {
     const int fr = lane & 15, fq = lane >> 4;
-    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+    // this wave's 16 x 68-float transpose patch and its 64 staged bias values, as LDS byte addresses for the asm accessors
+    const unsigned smem_lds = (unsigned)(size_t)(LDS_AS const char*)smem;
+    const unsigned stg_lds = smem_lds + wave * (16 * 68) * 4;
+    const unsigned sbias_lds = smem_lds + ((blockDim.x >> 6) * (16 * 68) + wave * 64) * 4;       // staged by nt_epilogue_stage_bias
+    const unsigned waddr = stg_lds + (fr * 68 + fq * 4) * 4;                       // accumulator block ni goes 64 B further
     const float alpha = nw0 < a.scale_cols ? a.alpha * a.col_scale : a.alpha;      // wave-uniform (a wave owns 64 columns)
     // The wave's 64 bias values go through LDS (one coalesced load per tile, re-read per row group with ds_read): kept in
     // registers they do not fit next to 128 accumulators, and hipcc then RE-LOADS them from global memory in front of
     // every row group - each reload a vmcnt(0) that also waits for the stores just issued, i.e. a fully serialised
     // store -> load -> store chain over the whole epilogue.
-    const float* sbias = reinterpret_cast<const float*>(smem) + (blockDim.x >> 6) * (16 * 68) + wave * 64;     // staged by nt_epilogue_stage_bias
     if (ACT == 0 && a.out_f32) {                                                   // fp32 output exists without activation only
         const int cc = (lane & 15) * 4, rq = lane >> 4;
         const int n = nw0 + cc;
+        float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
+        const float* sbias = reinterpret_cast<const float*>(smem) + (blockDim.x >> 6) * (16 * 68) + wave * 64;
         constexpr int RG = EpiPrefetch<MI>::RG, NG = MI / RG;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -151,6 +173,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
 #pragma unroll
             for (int mj = 0; mj < RG; ++mj) {
                 const int mi = g * RG + mj;
+                // (compiler-visible LDS accesses on this path: it never runs beside a pending LDS-DMA, and hipcc interleaves
+                //  these reads with the residual loads better than a hand-placed lgkmcnt(0) per row block does: -4..9 % measured)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
 #pragma unroll
@@ -169,6 +193,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
     } else {
         const int cc = (lane & 7) * 8, rq = lane >> 3;
         const int n = nw0 + cc;
+        const unsigned raddr = stg_lds + (rq * 68 + cc) * 4, baddr = sbias_lds + cc * 4;      // rows rq and rq + 8: 2176 B apart
         constexpr int AG = EpiPrefetch<MI>::AG, NG = MI / AG;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
 #pragma unroll
@@ -177,22 +202,25 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
 #pragma unroll
             for (int mj = 0; mj < AG; ++mj) {
                 const int mi = g * AG + mj;
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(stg + fr * 68 + ni * 16 + fq * 4) = acc[ni][mi];
+                epi_lds_w128<0>(waddr, acc[0][mi]); epi_lds_w128<64>(waddr, acc[1][mi]);
+                epi_lds_w128<128>(waddr, acc[2][mi]); epi_lds_w128<192>(waddr, acc[3][mi]);
+                f32x4 tq[2][2], bq[2];
+                epi_lds_r128<0>(tq[0][0], raddr); epi_lds_r128<16>(tq[0][1], raddr);
+                epi_lds_r128<2176>(tq[1][0], raddr); epi_lds_r128<2176 + 16>(tq[1][1], raddr);
+                epi_lds_r128<0>(bq[0], baddr); epi_lds_r128<16>(bq[1], baddr);
+                epi_lds_wait();
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int rr = i * 8 + rq;
-                    const float4 t0 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc);
-                    const float4 t1 = *reinterpret_cast<const float4*>(stg + rr * 68 + cc + 4);
                     const int m = mw0 + mi * 16 + rr;
                     if (m >= a.M) continue;
-                    float v0[4] = {t0.x, t0.y, t0.z, t0.w}, v1[4] = {t1.x, t1.y, t1.z, t1.w};
+                    float v0[4] = {tq[i][0][0], tq[i][0][1], tq[i][0][2], tq[i][0][3]}, v1[4] = {tq[i][1][0], tq[i][1][1], tq[i][1][2], tq[i][1][3]};
                     // (no residual here: it exists for fp32 output only - an optional per-row load in this loop would put a
                     //  vmcnt(0) at its join point in front of every row group's stores, taken or not)
                     u32x4 ax = {0, 0, 0, 0};
                     if (ACT == 2) ax = pf.ax[mj][i];
                     const f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-                    const float4 bias_lo = *reinterpret_cast<const float4*>(sbias + cc), bias_hi = *reinterpret_cast<const float4*>(sbias + cc + 4);
+                    const float4 bias_lo = make_float4(bq[0][0], bq[0][1], bq[0][2], bq[0][3]), bias_hi = make_float4(bq[1][0], bq[1][1], bq[1][2], bq[1][3]);
                     epi_apply4(alpha, ACT, v0, bias_lo, make_uint2(ax[0], ax[1]), false, r0);
                     epi_apply4(alpha, ACT, v1, bias_hi, make_uint2(ax[2], ax[3]), false, r1);
                     if (a.colsum) {
@@ -514,25 +542,38 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
         __syncthreads();                                      // every wave is done with both buffers, nothing in flight
         nt_epilogue_stage_bias(a, smem + BUF_BYTES, wave, lane, en);
         const bool has_next = v + (int)gridDim.x < ntiles;
-        // The epilogue runs with NO LDS-DMA in flight; the next tile's first K-tile is requested after it.  Beside a pending
-        // DMA hipcc waits vmcnt(0) for every ordinary load it uses (bias, fp32 residual rows, GELU' operands) and - because
-        // a DMA is a pending LDS write it cannot disambiguate - in front of every group of LDS patch reads, so every row
-        // group's stores would wait for the previous group's stores: a fully serialised epilogue.
+        // Beside a pending LDS-DMA hipcc waits vmcnt(0) for every ordinary load it uses (bias, fp32 residual rows, GELU'
+        // operands) and - because a DMA is a pending LDS write it cannot disambiguate - in front of every group of
+        // compiler-visible LDS reads, so every row group's stores would wait for the previous group's stores: a fully
+        // serialised epilogue.  Hence: epilogues that load from global memory run with NO DMA in flight (the next tile's first
+        // K-tile is requested after them); the others use asm LDS accessors and get it requested before (`early` below).
         // the epilogue's lane-derived constants are recomputed per tile from an opaque copy of the lane id: hoisted out of the
         // tile loop they would be spilled (the K loop owns the register file) and every reload is a vmcnt(0) in the epilogue
         int elane = lane;
         asm volatile("" : "+v"(elane));
         EpiPrefetch<MI> pf;
         nt_epilogue_prefetch<ACT, MI>(a, pf, elane, em, en);
+        // Epilogues that read nothing from global memory (bf16 output without / with the GELU pair: bias comes from LDS, all LDS
+        // traffic is inline asm) run with the next tile's first K-tile already in flight into buffer 0 - the patches live in
+        // buffer 1 - so the 64 KiB land under the stores instead of in front of the next tile's first MFMA.  The other
+        // epilogues keep the order "epilogue, then request": their residual / GELU' loads would each be waited for with
+        // vmcnt(0) beside a pending DMA (see above).
+        const bool early = has_next && ACT != 2 && !a.out_f32;
+        int vnext = v + (int)gridDim.x;
+        if (early) {
+            set_tile(vnext);
+            dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
+        }
         nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
         // a compiler-visible full drain: the K loop reuses registers the epilogue loaded into, and hipcc would otherwise
         // re-wait for those loads (vmcnt(0)) at the head of EVERY K-tile.  The next tile's first wait drains the stores anyway.
         wait_vm<0>();
-        // (the eight DMA source pointers are also only computed here: alive during the epilogue they pushed its fp32-residual
-        //  path over the register file, and a spill reload is one more vector-memory op waited for with vmcnt(0))
+        // (the eight DMA source pointers are only computed here - for the early case RE-computed from an opaque copy of the tile
+        //  id: alive during the epilogue they push it over the register file, and a spill reload is one more vector-memory op)
         if (has_next) {
-            set_tile(v + gridDim.x);
-            dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
+            asm volatile("" : "+s"(vnext));
+            set_tile(vnext);
+            if (!early) { dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1); }
         }
     }
 }
