@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--audio-tokens", type=int, default=512)
+    ap.add_argument("--model", choices=("vit_base", "vit_large"), default="vit_base",
+                    help="vit_base = BASELINE.json's metric (configs[1]); vit_large = configs[3]'s shape, an extra data point")
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -116,7 +118,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = AVSiamConfig(audio_tokens=args.audio_tokens, frames=args.frames)
+    if args.model == "vit_large":
+        from avsiam_amd.config import vit_large
+        cfg = vit_large(audio_tokens=args.audio_tokens, frames=args.frames)
+    else:
+        cfg = AVSiamConfig(audio_tokens=args.audio_tokens, frames=args.frames)
+    mname = "ViT-B/16" if args.model == "vit_base" else "ViT-L/16"
     torch.manual_seed(87 + rank)
     log(f"building model (frames={args.frames}, batch={args.batch}/GPU, world={world})")
     model = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
@@ -158,10 +165,10 @@ def main():
         sps = world * args.batch * args.steps / dt
         gf = gflop_per_sample(cfg, args.batch)
         line = {
-            "metric": "AV pretrain samples/sec (ViT-B/16, 75% mask)", "value": sps, "unit": "samples/s", "n_gpus": world,
+            "metric": f"AV pretrain samples/sec ({mname}, 75% mask)", "value": sps, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), ViT-B/16, {args.frames} frames x196 + "
+            "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x196 + "
                                    f"{args.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": args.audio_tokens,
                        "parallelism": f"dp{world}", "gflop_per_sample": gf},
