@@ -39,6 +39,9 @@ struct GemmNtArgs {
     int scale_cols; float col_scale;         // columns [0, scale_cols) are multiplied by col_scale as well (scale_cols % 64 == 0)
     float* colsum;                           // bf16 output only: colsum[n] += sum_m out[m][n] (bias gradient of the layer that produced A)
     int m_full;                              // rows [0, m_full) in full tiles, [m_full, M) in half-height tiles (m_full == M: none)
+    // two weight sets in one launch (avs_gemm_nt_bf16_dual): rows [m_split, M) use B2 / bias2 / colsum2 instead of
+    // B / bias / colsum.  m_split is a multiple of 256, so a tile (full or half-height) never straddles it.
+    int m_split; const bf16_t* B2; const float* bias2; float* colsum2;
 };
 
 
@@ -142,9 +145,10 @@ __device__ __forceinline__ void nt_epilogue_prefetch(const GemmNtArgs& a, EpiPre
 
 // called by the kernels BEFORE they put the next tile's LDS-DMAs in flight: the one global load of the bias path is then
 // waited for on its own (beside a pending DMA hipcc's wait for it is vmcnt(0), i.e. it would wait for the DMAs as well)
-__device__ __forceinline__ void nt_epilogue_stage_bias(const GemmNtArgs& a, char* smem, int wave, int lane, int nw0) {
+__device__ __forceinline__ void nt_epilogue_stage_bias(const GemmNtArgs& a, char* smem, int wave, int lane, int mw0, int nw0) {
     float* sbias = reinterpret_cast<float*>(smem) + (blockDim.x >> 6) * (16 * 68) + wave * 64;       // behind the waves' transpose patches
-    sbias[lane] = a.bias ? a.bias[nw0 + lane] : 0.f;
+    const float* bias = mw0 >= a.m_split ? a.bias2 : a.bias;
+    sbias[lane] = bias ? bias[nw0 + lane] : 0.f;
 }
 
 template <int ACT, int MI>
@@ -157,6 +161,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
     const unsigned sbias_lds = smem_lds + ((blockDim.x >> 6) * (16 * 68) + wave * 64) * 4;       // staged by nt_epilogue_stage_bias
     const unsigned waddr = stg_lds + (fr * 68 + fq * 4) * 4;                       // accumulator block ni goes 64 B further
     const float alpha = nw0 < a.scale_cols ? a.alpha * a.col_scale : a.alpha;      // wave-uniform (a wave owns 64 columns)
+    float* const colsum = mw0 >= a.m_split ? a.colsum2 : a.colsum;                 // wave-uniform (a tile lies on one side of m_split)
     // The wave's 64 bias values go through LDS (one coalesced load per tile, re-read per row group with ds_read): kept in
     // registers they do not fit next to 128 accumulators, and hipcc then RE-LOADS them from global memory in front of
     // every row group - each reload a vmcnt(0) that also waits for the stores just issued, i.e. a fully serialised
@@ -223,7 +228,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     const float4 bias_lo = make_float4(bq[0][0], bq[0][1], bq[0][2], bq[0][3]), bias_hi = make_float4(bq[1][0], bq[1][1], bq[1][2], bq[1][3]);
                     epi_apply4(alpha, ACT, v0, bias_lo, make_uint2(ax[0], ax[1]), false, r0);
                     epi_apply4(alpha, ACT, v1, bias_hi, make_uint2(ax[2], ax[3]), false, r1);
-                    if (a.colsum) {
+                    if (colsum) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { cs[j] += v0[j]; cs[4 + j] += v1[j]; }
                     }
@@ -240,7 +245,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 }
             }
         }
-        if (a.colsum) {
+        if (colsum) {
             // lanes with the same (lane & 7) hold the same 8 columns for different rows: fold the 8 row groups, then one
             // atomic per column and wave (fp32 atomics, like the weight gradients)
 #pragma unroll
@@ -253,7 +258,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
             }
             if (rq == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) atomicAdd(a.colsum + n + j, cs[j]);
+                for (int j = 0; j < 8; ++j) atomicAdd(colsum + n + j, cs[j]);
             }
         }
     }
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
             const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
-            srcB[i] = a.B + (size_t)(n0 + row) * a.ldb + c * 8;
+            srcB[i] = (m0 >= a.m_split ? a.B2 : a.B) + (size_t)(n0 + row) * a.ldb + c * 8;
         }
     };
     auto stage = [&](int buf, int k0) {
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(128 * NWN) void gemm_nt_kernel(GemmNtArgs a) {
         const int em = m0 + wm * (MIT * 16), en = n0 + wn * 64;
         __syncthreads();                                   // every wave is done reading the K-slab buffers
         // both LDS buffers are free now: prefetch the next tile's first slab into buffer 0, stage the epilogue through buffer 1
-        nt_epilogue_stage_bias(a, smem + BUF_BYTES, wave, lane, en);
+        nt_epilogue_stage_bias(a, smem + BUF_BYTES, wave, lane, em, en);
         // (the epilogue runs with no LDS-DMA in flight, see gemm_nt8_kernel: the next tile's first slab is requested after it)
         const bool has_next = v + (int)gridDim.x < ntiles;
         EpiPrefetch<MIT> pf;
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
             for (int j = 0; j < 2; ++j) {
                 const int p = j * NT + tid, lr = p >> 3, c = (p & 7) ^ (lr & 7);
                 sA[h][j] = a.A + (size_t)min(m0 + h * 128 + lr, a.M - 1) * a.lda + c * 8;
-                sB[h][j] = a.B + (size_t)(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31)) * a.ldb + c * 8;
+                sB[h][j] = (m0 >= a.m_split ? a.B2 : a.B) + (size_t)(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31)) * a.ldb + c * 8;
             }
     };
     // LDS destination of this wave's j-th instruction of a granule (wave-uniform; the hardware adds lane*16)
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
         if (g == 0) bar();                                    // pairs with G1's last barrier
         const int em = m0 + g * 128, en = n0 + wc * 64;
         __syncthreads();                                      // every wave is done with both buffers, nothing in flight
-        nt_epilogue_stage_bias(a, smem + BUF_BYTES, wave, lane, en);
+        nt_epilogue_stage_bias(a, smem + BUF_BYTES, wave, lane, em, en);
         const bool has_next = v + (int)gridDim.x < ntiles;
         // Beside a pending LDS-DMA hipcc waits vmcnt(0) for every ordinary load it uses (bias, fp32 residual rows, GELU'
         // operands) and - because a DMA is a pending LDS write it cannot disambiguate - in front of every group of
@@ -875,10 +880,11 @@ extern "C" int avs_gemm_set_tile(int tile) {
     return 0;
 }
 
-extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
-                                const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
-                                long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
-                                float alpha, int act, int scale_cols, float col_scale, float* colsum, hipStream_t stream) {
+static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
+                          const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
+                          long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
+                          float alpha, int act, int scale_cols, float col_scale, float* colsum,
+                          int m_split, const bf16_t* B2, const float* bias2, float* colsum2, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % BN) == 0 && (K % BK) == 0, "gemm_nt: need N%%128==0, K%%64==0 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out, "gemm_nt: null operand");
     AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (!out2 || (ldo2 % 8) == 0) && (!aux || (ldaux % 8) == 0),
@@ -888,7 +894,8 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     AVS_CHECK_ARG(!(out_f32 && colsum), "gemm_nt: the fused column sum is implemented for bf16 output");
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt: the residual add is implemented for fp32 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
-    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M};
+    GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M,
+                 m_split, B2, bias2, colsum2};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;
@@ -957,6 +964,26 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     AVS_LAUNCH_CHECK("gemm_nt");
     ++g_nt_dispatches;
     return 0;
+}
+
+extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
+                                const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
+                                long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
+                                float alpha, int act, int scale_cols, float col_scale, float* colsum, hipStream_t stream) {
+    return gemm_nt_launch(A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols,
+                          col_scale, colsum, 0x7fffffff, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int avs_gemm_nt_bf16_dual(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
+                                     const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
+                                     long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
+                                     float alpha, int act, int scale_cols, float col_scale, float* colsum,
+                                     int m_split, const bf16_t* B2, const float* bias2, float* colsum2, hipStream_t stream) {
+    AVS_CHECK_ARG(m_split > 0 && m_split < M && (m_split % 256) == 0, "gemm_nt_dual: m_split=%d must be a multiple of 256 inside (0, M=%d)", m_split, M);
+    AVS_CHECK_ARG(B2 && (bias == nullptr) == (bias2 == nullptr) && (colsum == nullptr) == (colsum2 == nullptr),
+                  "gemm_nt_dual: the second weight set must mirror the first (B2, bias2, colsum2)");
+    return gemm_nt_launch(A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols,
+                          col_scale, colsum, m_split, B2, bias2, colsum2, stream);
 }
 
 extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, float* C, long long ldc,

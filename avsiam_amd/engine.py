@@ -16,6 +16,8 @@ MI355X-first restructuring of ``CAVMAE_BASE.forward`` (/root/reference/src/model
 
 The mask plan (which tokens each sample keeps) is an explicit input - see maskplan.py.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -131,49 +133,72 @@ class Stack:
     def out(self):
         return self.x[self.nblocks]
 
-    def forward(self, blocks):
+    def forward(self, blocks, blocks2=None, split=0):
+        """blocks2 / split: rows [split, rows) run through a SECOND set of blocks (the MAE pass's visual tower next to its
+        audio tower, cav_mae_base.py:487,489) in the same launches - every GEMM takes both weight sets
+        (ops.gemm_nt(dual=...)), the LayerNorm picks the affine per row (row_mod: 0 below split, 1 from it)."""
         M = self.rows
         for i, bp in enumerate(blocks):
             x, st = self.x[i], self.stats[i]
-            _ln_fwd(x, bp.n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
-            ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale)
+            b2 = blocks2[i] if blocks2 is not None else None
+            n1 = bp.n1 if b2 is None else [bp.n1[0], b2.n1[0]]
+            n2 = bp.n2 if b2 is None else [bp.n2[0], b2.n2[0]]
+            dq = dp = d1 = d2 = None
+            if b2 is not None:
+                dq, dp = (split, b2.qkv.w, b2.qkv.b, None), (split, b2.proj.w, b2.proj.b, None)
+                d1, d2 = (split, b2.fc1.w, b2.fc1.b, None), (split, b2.fc2.w, b2.fc2.b, None)
+            _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
+            ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq)
             ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i])
-            ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x)
-            _ln_fwd(self.xmid[i], bp.n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)
-            ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1)
-            ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i])
+            ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x, dual=dp)
+            _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)
+            ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1)
+            ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2)
 
-    def backward(self, blocks, last_fc2_bias_done=False):
+    def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0):
         """In: d(out) in self.dx[0] (fp32) and self.dxb[0] (bf16).  Out: d(x[0]) in the same two buffers.
         Bias gradients of fc2 / proj are column sums of the residual-stream gradient and come out of the LayerNorm
         backward that produces it (`dcol`); `last_fc2_bias_done` says the caller's LN backward already did that for
-        the last block."""
+        the last block.
+        blocks2 / split (see forward): the input-gradient GEMMs take both weight sets in one launch; everything that
+        reduces over rows into a parameter gradient (weight-gradient GEMMs, bias column sums, LayerNorm backward with its
+        gamma/beta/bias sums) runs once per row range on row slices of the same buffers."""
         assert not self.inference, "Stack(inference=True) keeps no activations"
         M = self.rows
         dxo, dxm = self.dx
         dbo, dbm = self.dxb
+        ranges = [(0, M, blocks)] if blocks2 is None else [(0, split, blocks), (split, M, blocks2)]
         for i in reversed(range(self.nblocks)):
             bp, st = blocks[i], self.stats[i]
+            b2 = blocks2[i] if blocks2 is not None else None
             # fc2: d(gelu out) fused with GELU' -> d(fc1 pre-activation)
-            ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb)     # + fc1 bias gradient
-            ops.gemm_tn(dbo, self.act[i], bp.fc2.gw, M)
-            if i == self.nblocks - 1 and not last_fc2_bias_done:
-                ops.colsum(dbo, bp.fc2.gb, M)
+            ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
+                        dual=(split, b2.fc2.wt, None, b2.fc1.gb) if b2 is not None else None)
+            for lo, hi, bl in ranges:
+                ops.gemm_tn(dbo[lo:], self.act[i][lo:], bl[i].fc2.gw, hi - lo)
+                if i == self.nblocks - 1 and not last_fc2_bias_done:
+                    ops.colsum(dbo[lo:], bl[i].fc2.gb, hi - lo)
             # fc1
-            ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M)
-            ops.gemm_tn(self.dfc1, self.ln2[i], bp.fc1.gw, M)
-            _ln_bwd(self.dln, self.xmid[i], st[2], st[3], bp.n2, dxm, self.lnws, M, self.row_mod, dres=dxo, dx_bf16=dbm,
-                    dcol=bp.proj.gb)
+            ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M, dual=(split, b2.fc1.wt, None, None) if b2 is not None else None)
+            for lo, hi, bl in ranges:
+                ops.gemm_tn(self.dfc1[lo:], self.ln2[i][lo:], bl[i].fc1.gw, hi - lo)
+                one = blocks2 is not None            # a row range has ONE affine set; the packed single-tower case selects by row_mod
+                _ln_bwd(self.dln[lo:], self.xmid[i][lo:], st[2][lo:], st[3][lo:], bl[i].n2, dxm[lo:], self.lnws, hi - lo,
+                        None if one else self.row_mod, dres=dxo[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb)
             # proj
-            ops.gemm_nt(dbm, bp.proj.wt, self.datt, M)
-            ops.gemm_tn(dbm, self.att[i], bp.proj.gw, M)
+            ops.gemm_nt(dbm, bp.proj.wt, self.datt, M, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
+            for lo, hi, bl in ranges:
+                ops.gemm_tn(dbm[lo:], self.att[i][lo:], bl[i].proj.gw, hi - lo)
             ops.attn_bwd(self.qkv[i], self.tiles, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
             # qkv
-            ops.gemm_nt(self.dqkv, bp.qkv.wt, self.dln, M)
-            ops.gemm_tn(self.dqkv, self.ln1[i], bp.qkv.gw, M)
-            ops.colsum(self.dqkv, bp.qkv.gb, M)
-            _ln_bwd(self.dln, self.x[i], st[0], st[1], bp.n1, dxo, self.lnws, M, self.row_mod, dres=dxm, dx_bf16=dbo,
-                    dcol=blocks[i - 1].fc2.gb if i > 0 else None)
+            ops.gemm_nt(self.dqkv, bp.qkv.wt, self.dln, M, dual=(split, b2.qkv.wt, None, None) if b2 is not None else None)
+            for lo, hi, bl in ranges:
+                ops.gemm_tn(self.dqkv[lo:], self.ln1[i][lo:], bl[i].qkv.gw, hi - lo)
+                ops.colsum(self.dqkv[lo:], bl[i].qkv.gb, hi - lo)
+                one = blocks2 is not None
+                _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, dxo[lo:], self.lnws, hi - lo,
+                        None if one else self.row_mod, dres=dxm[lo:], dx_bf16=dbo[lo:],
+                        dcol=bl[i - 1].fc2.gb if i > 0 else None)
 
 
 class PatchEmbedder:
@@ -450,8 +475,17 @@ class MaePass:
         self.n_enc = ka + T * kv
         self.Ltot = La + T * Lv
         hid = D * cfg.mlp_ratio
-        self.st_a = Stack(dev, self.rows_a, D, cfg.num_heads, hid, [ka] * B, cfg.depth)
-        self.st_v = Stack(dev, self.rows_v, D, cfg.num_heads, hid, [kv] * (B * T), cfg.depth)
+        # The audio tower (ast_base blocks, plain norms) and the visual tower (vit_base blocks, '_v' norms) are independent and
+        # structurally identical: when the audio rows end on a 256-row tile boundary they run as ONE packed stack whose GEMMs
+        # take both weight sets per launch (8 192 audio rows alone fill 37 % of the chip with 256^2 tiles).  Otherwise two stacks.
+        self.grouped = self.rows_a % 256 == 0 and os.environ.get("AVSIAM_GROUP_TOWERS", "1") != "0"      # env: A/B measurements
+        if self.grouped:
+            row_mod = torch.cat([torch.zeros(self.rows_a, dtype=U8), torch.ones(self.rows_v, dtype=U8)]).to(dev)
+            self.st_t = Stack(dev, self.rows_a + self.rows_v, D, cfg.num_heads, hid, [ka] * B + [kv] * (B * T), cfg.depth, row_mod)
+            self.st_a = self.st_v = None
+        else:
+            self.st_a = Stack(dev, self.rows_a, D, cfg.num_heads, hid, [ka] * B, cfg.depth)
+            self.st_v = Stack(dev, self.rows_v, D, cfg.num_heads, hid, [kv] * (B * T), cfg.depth)
         self.st_mm = Stack(dev, B * self.n_enc, D, cfg.num_heads, hid, [self.n_enc] * B, 2)
         self.st_dec = Stack(dev, B * self.Ltot, Dd, cfg.dec_heads, Dd * cfg.mlp_ratio, [self.Ltot] * B, cfg.dec_depth)
         self.blk_a = [BlockParams(arena, f"ast_base.blocks.{i}", "") for i in range(cfg.depth)]      # :489
@@ -467,8 +501,8 @@ class MaePass:
         self.dec_embed = Linear(arena, "decoder_embed.weight", "decoder_embed.bias")
         self.pred_a = Linear(arena, "decoder_pred_a.weight", "decoder_pred_a.bias")
         self.pred_v = Linear(arena, "decoder_pred_v.weight", "decoder_pred_v.bias")
-        self.fstat_a = [_z((self.st_a.rp,), F32, dev) for _ in range(2)]
-        self.fstat_v = [_z((self.st_v.rp,), F32, dev) for _ in range(2)]
+        self.fstat_a = [_z((ops.pad_rows(self.rows_a, 128),), F32, dev) for _ in range(2)]
+        self.fstat_v = [_z((ops.pad_rows(self.rows_v, 128),), F32, dev) for _ in range(2)]
         # static row maps: tower rows -> joint [B, n_enc] layout (torch.cat((ca, cv), dim=1), :503)
         b = torch.arange(B).view(B, 1)
         self.map_a = (b * self.n_enc + torch.arange(ka).view(1, ka)).reshape(-1).to(I32).to(dev)
@@ -565,13 +599,22 @@ class MaePass:
         if plan is not None:
             self._set_plan(plan)
         self.audio, self.imgs = audio, _fold_frames(imgs, T)
-        self.emb_a.forward(audio, self.st_a.x[0])
-        self.emb_v.forward(self.imgs, self.st_v.x[0])
-        self.st_a.forward(self.blk_a)
-        self.st_v.forward(self.blk_v)
+        ra = self.rows_a
+        if self.grouped:
+            st = self.st_t
+            self.emb_a.forward(audio, st.x[0][:ra])
+            self.emb_v.forward(self.imgs, st.x[0][ra:])
+            st.forward(self.blk_a, self.blk_v, ra)
+            out_a, out_v = st.out[:ra], st.out[ra:]
+        else:
+            self.emb_a.forward(audio, self.st_a.x[0])
+            self.emb_v.forward(self.imgs, self.st_v.x[0])
+            self.st_a.forward(self.blk_a)
+            self.st_v.forward(self.blk_v)
+            out_a, out_v = self.st_a.out, self.st_v.out
         xj = self.st_mm.x[0]
-        _ln_fwd(self.st_a.out, self.fin_a, xj, self.fstat_a[0], self.fstat_a[1], self.rows_a, LN_EPS_FINAL, out_map=self.map_a)
-        _ln_fwd(self.st_v.out, self.fin_v, xj, self.fstat_v[0], self.fstat_v[1], self.rows_v, LN_EPS_FINAL, out_map=self.map_v)
+        _ln_fwd(out_a, self.fin_a, xj, self.fstat_a[0], self.fstat_a[1], self.rows_a, LN_EPS_FINAL, out_map=self.map_a)
+        _ln_fwd(out_v, self.fin_v, xj, self.fstat_v[0], self.fstat_v[1], self.rows_v, LN_EPS_FINAL, out_map=self.map_v)
         self.st_mm.forward(self.blk_mm)
         rows_j = B * self.n_enc
         ops.cast_scale(self.st_mm.out, self.xj_b, rows_j * cfg.embed_dim, 1.0)
@@ -618,6 +661,16 @@ class MaePass:
         ops.colsum(self.dde_b, self.dec_embed.gb, rows_j)
         ops.cast_scale(sm.dx[0], sm.dxb[0], rows_j * D, 1.0)
         sm.backward(self.blk_mm)
+        if self.grouped:
+            st, ra = self.st_t, self.rows_a
+            for lo, fin, fstat, omap, rows, blks in ((0, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.blk_a),
+                                                     (ra, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.blk_v)):
+                _ln_bwd(sm.dx[0], st.out[lo:], fstat[0], fstat[1], fin, st.dx[0][lo:], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0][lo:],
+                        dcol=blks[-1].fc2.gb)
+            st.backward(self.blk_a, last_fc2_bias_done=True, blocks2=self.blk_v, split=ra)
+            self.emb_a.backward(st.dx[0][:ra])
+            self.emb_v.backward(st.dx[0][ra:])
+            return
         for st, fin, fstat, omap, rows, emb, blks in ((self.st_a, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.emb_a, self.blk_a),
                                                       (self.st_v, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.emb_v, self.blk_v)):
             _ln_bwd(sm.dx[0], st.out, fstat[0], fstat[1], fin, st.dx[0], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0],

@@ -67,7 +67,7 @@ def _launch(kind, work, cname, *args):
     if prof is None or not prof.wants(kind):
         return _lib.call(cname, *args)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    count = cname == "avs_gemm_nt_bf16"                  # a call is one or two kernel dispatches (leftover rows)
+    count = cname.startswith("avs_gemm_nt_bf16")         # a call is one or two kernel dispatches (leftover rows)
     d0 = _lib.load().avs_gemm_nt_dispatches() if count else 0
     e0.record()
     _lib.call(cname, *args)
@@ -124,9 +124,11 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
 
 
 # ---------------------------------------------------------------------------------------------------
-def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None, alpha=1.0, act=0, scale_cols=0, col_scale=1.0, colsum=None):
+def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None, alpha=1.0, act=0, scale_cols=0, col_scale=1.0, colsum=None,
+            dual=None):
     """out[M,N] = alpha * (A[M,K] @ B[N,K]^T + bias [* gelu'(aux)] + res[res_idx]); columns [0, scale_cols) also * col_scale;
-    colsum[n] += sum_m out[m, n] (bf16 output only)."""
+    colsum[n] += sum_m out[m, n] (bf16 output only).
+    dual = (m_split, B2, bias2, colsum2): rows [m_split, M) use the second weight set (one launch for two towers)."""
     _chk(A, BF16, "gemm.A", 2); _chk(B, BF16, "gemm.B", 2); _chk(bias, F32, "gemm.bias"); _chk(res, F32, "gemm.res", 2)
     _chk(res_idx, I32, "gemm.res_idx"); _chk(aux, BF16, "gemm.aux", 2); _chk(out2, BF16, "gemm.out2", 2)
     if out.dtype not in (BF16, F32) or not out.is_cuda or not out.is_contiguous() or out.dim() != 2:
@@ -148,9 +150,19 @@ def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None
         assert out2 is not None and out2.shape[0] >= M and out2.shape[1] == N
     if act == 2:
         assert aux is not None and aux.shape[0] >= M and aux.shape[1] == N
-    _launch("gemm_nt_act%d" % act, 2.0 * M * N * K, "avs_gemm_nt_bf16", A, A.stride(0), B, B.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
-              res_idx, aux, aux.stride(0) if aux is not None else 0, out, out.stride(0), 1 if out.dtype == F32 else 0, out2,
-              out2.stride(0) if out2 is not None else 0, float(alpha), act, int(scale_cols), float(col_scale), colsum, _stream())
+    args = (A, A.stride(0), B, B.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
+            res_idx, aux, aux.stride(0) if aux is not None else 0, out, out.stride(0), 1 if out.dtype == F32 else 0, out2,
+            out2.stride(0) if out2 is not None else 0, float(alpha), act, int(scale_cols), float(col_scale), colsum)
+    if dual is None:
+        _launch("gemm_nt_act%d" % act, 2.0 * M * N * K, "avs_gemm_nt_bf16", *args, _stream())
+    else:
+        m_split, B2, bias2, colsum2 = dual
+        _chk(B2, BF16, "gemm.B2", 2); _chk(bias2, F32, "gemm.bias2"); _chk(colsum2, F32, "gemm.colsum2")
+        assert B2.shape == B.shape and B2.stride(0) == B.stride(0) and 0 < m_split < M and m_split % 256 == 0
+        assert (bias2 is None) == (bias is None) and (colsum2 is None) == (colsum is None)
+        assert bias2 is None or bias2.numel() == N
+        assert colsum2 is None or colsum2.numel() == N
+        _launch("gemm_nt_act%d" % act, 2.0 * M * N * K, "avs_gemm_nt_bf16_dual", *args, int(m_split), B2, bias2, colsum2, _stream())
 
 
 def gemm_tn(A, B, C, M, splits=0):

@@ -54,6 +54,16 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
                      const float* bias, const float* res, long long ldr, const int* res_idx, const avs_bf16* aux,
                      long long ldaux, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
                      int act, int scale_cols, float col_scale, float* colsum, avs_stream_t stream);
+/* the same GEMM over TWO weight sets in one launch: rows [0, m_split) of A meet B / bias / colsum, rows [m_split, M) meet
+ * B2 / bias2 / colsum2 (same shapes and leading dimension; m_split a multiple of 256).  Replaces the two nn.Linear calls the
+ * reference makes per layer for its separate audio and visual towers (cav_mae_base.py:487,489: `blk(v, 'v')` on
+ * vit_base.blocks and `blk(a)` on ast_base.blocks), whose row counts alone (8 192 / 31 360 at batch 64) leave the chip
+ * partly idle. */
+int avs_gemm_nt_bf16_dual(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, int M, int N, int K,
+                          const float* bias, const float* res, long long ldr, const int* res_idx, const avs_bf16* aux,
+                          long long ldaux, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
+                          int act, int scale_cols, float col_scale, float* colsum, int m_split, const avs_bf16* B2,
+                          const float* bias2, float* colsum2, avs_stream_t stream);
 /* number of kernel dispatches avs_gemm_nt_bf16 has issued so far (a call is one dispatch, or two when the rows left over
  * after the whole rounds of 256x256 tiles go to the half-height-tile kernel): lets bench.py quote a per-DISPATCH average
  * that is directly comparable with rocprofv3's per-kernel statistics */

@@ -168,6 +168,50 @@ def test_gemm_nt_8phase_matches_two_buffer_kernel(M, N, K):
     assert rel_err(want[1], ref + res.double()) < 1e-5
 
 
+@pytest.mark.parametrize("M,split,N,K", [(1000, 256, 768, 768), (39552, 8192, 768, 3072), (39552, 8192, 3072, 768), (2560 + 77, 2560, 256, 128)])
+def test_gemm_nt_two_weight_sets_in_one_launch(M, split, N, K):
+    """avs_gemm_nt_bf16_dual: rows below m_split meet (B, bias, colsum), rows from it (B2, bias2, colsum2).  Must equal the
+    two separate GEMMs over the row ranges - bitwise for the outputs (same accumulation order in every kernel variant),
+    to fp32-atomic order for the fused column sums."""
+    o = ops()
+    A = bf(torch.randn(M, K, device=DEV))
+    W1, W2 = bf(torch.randn(N, K, device=DEV) * 0.05), bf(torch.randn(N, K, device=DEV) * 0.05)
+    b1, b2 = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV)
+    aux = bf(torch.randn(M, N, device=DEV))
+
+    def both(fn):
+        return fn(slice(0, split), split, W1, b1), fn(slice(split, M), M - split, W2, b2)
+
+    # bf16 output with bias and a fused column sum
+    out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    cs1, cs2 = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    o.gemm_nt(A, W1, out, M, bias=b1, colsum=cs1, dual=(split, W2, b2, cs2))
+    want, wcs = torch.zeros_like(out), [torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)]
+    both(lambda sl, m, W, b: o.gemm_nt(A[sl], W, want[sl], m, bias=b, colsum=wcs[0] if sl.start == 0 else wcs[1]))
+    assert torch.equal(out, want)
+    for g, w in ((cs1, wcs[0]), (cs2, wcs[1])):
+        assert rel_err(g, w) < 1e-5
+    # fp32 output with residual
+    outf, wantf = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+    o.gemm_nt(A, W1, outf, M, bias=b1, res=res, dual=(split, W2, b2, None))
+    both(lambda sl, m, W, b: o.gemm_nt(A[sl], W, wantf[sl], m, bias=b, res=res[sl]))
+    assert torch.equal(outf, wantf)
+    # GELU pair and GELU' (no bias on the second: both sets must mirror each other)
+    pre, act, wpre, wact = (torch.zeros(M, N, device=DEV, dtype=torch.bfloat16) for _ in range(4))
+    o.gemm_nt(A, W1, pre, M, bias=b1, out2=act, act=1, dual=(split, W2, b2, None))
+    both(lambda sl, m, W, b: o.gemm_nt(A[sl], W, wpre[sl], m, bias=b, out2=wact[sl], act=1))
+    assert torch.equal(pre, wpre) and torch.equal(act, wact)
+    d, wd = torch.zeros_like(pre), torch.zeros_like(pre)
+    o.gemm_nt(A, W1, d, M, aux=aux, act=2, dual=(split, W2, None, None))
+    both(lambda sl, m, W, b: o.gemm_nt(A[sl], W, wd[sl], m, aux=aux[sl], act=2))
+    assert torch.equal(d, wd)
+    ref = torch.cat([A[:split].double() @ W1.double().t() + b1.double(), A[split:].double() @ W2.double().t() + b2.double()]) + res.double()
+    assert rel_err(outf, ref) < 1e-5
+    with pytest.raises(AssertionError):                    # the split must sit on a 256-row tile boundary
+        o.gemm_nt(A, W1, out, M, bias=b1, dual=(split + 128, W2, b2, None))
+
+
 @pytest.mark.parametrize("M,N1,N2,splits", [(64, 128, 128, 1), (1000, 256, 768, 0), (4099, 768, 256, 3), (333, 2304, 768, 0),
                                             (20001, 2304, 768, 0), (33333, 768, 3072, 0), (16500, 1536, 1024, 7)])
 def test_gemm_tn(M, N1, N2, splits):
