@@ -146,7 +146,7 @@ def main():
         log(f"warm-up step {i} done, mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     if not args.no_kernel_events:
-        # default: every 5th gemm_nt launch (378 per step, co-prime to 5: over 5 or 10 steps every launch position is timed
+        # default: every 5th gemm_nt launch (282 per step, co-prime to 5: over 5 or 10 steps every launch position is timed
         # equally often); --all-kernel-events: every launch of every kernel family (costs ~5 ms/step of event overhead)
         ops.prof = ops.KernelProfiler() if args.all_kernel_events else ops.KernelProfiler(("gemm_nt",), stride=5)
     t0 = time.perf_counter()
