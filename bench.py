@@ -64,7 +64,7 @@ def pmc_traffic(args):
     (FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md) and stored under profiles/;
     null when the stored measurement is for a different workload."""
     path = os.path.join(ROOT, "profiles", "r01", "traffic_gemm_nt.json")
-    if not os.path.exists(path) or args.batch != 64 or args.frames != 10 or args.audio_tokens != 512:
+    if not os.path.exists(path) or args.batch != 64 or args.frames != 10 or args.audio_tokens != 512 or args.model != "vit_base":
         return None
     try:
         with open(path) as f:

@@ -6,8 +6,8 @@
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/pmc_write -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events
     python tools/pmc_summary.py out/pmc_fetch/f_counter_collection.csv out/pmc_write/w_counter_collection.csv [CALLS] > profiles/rNN/traffic_gemm_nt.json
 
-CALLS = number of avs_gemm_nt_bf16 calls in the profiled run (378 per step; a call is one or two dispatches: the 8-phase
-kernel plus the leftover-rows kernel), so that the figure is per launch as bench.py counts launches.
+CALLS = number of avs_gemm_nt_bf16(_dual) calls in the profiled run (282 per step; a call is one dispatch, or two when the
+two-buffer kernels hand leftover rows to a second launch), so that the figure is per launch as bench.py counts launches.
 
 FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads and is doubled
 (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Also prints a per-kernel table (sum over all dispatches) to stderr.
