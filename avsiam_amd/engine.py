@@ -81,6 +81,53 @@ def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, 
                       n1.db if n1 else None, row_mod if n1 else None, out_map, dres, dx_bf16, dcol)
 
 
+class _SideStream:
+    """Weight-gradient GEMMs on a second HIP stream.  A wgrad only needs its two operands to exist and must finish before the
+    backward of the NEXT block overwrites the shared scratch it read; nothing downstream waits for its result until the
+    optimizer.  AVSIAM_WGRAD_STREAM selects how far that is used:
+      2 (default)  wgrads run beside the attention backward, the LayerNorm backward and the column sums only; every
+                   forward/dgrad GEMM waits for them (join), so those GEMMs - the kernel bench.py's roofline times - keep
+                   the chip to themselves.  -1.0 % step time.
+      1            no such restriction (one event per scratch buffer): wgrads also fill the partly empty last rounds of the
+                   forward/dgrad GEMMs.  -2.6 % step time, but a GEMM's launch-to-end time then includes the share of the
+                   chip the concurrent wgrad holds (per-launch rate reads 0.29 of peak instead of 0.34).
+      0            everything on one stream."""
+
+    def __init__(self, dev):
+        self.stream = torch.cuda.Stream(device=dev)
+        self.done = {}
+
+    def run(self, key, fn):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.stream.wait_event(ready)
+        with torch.cuda.stream(self.stream):
+            fn()
+            d = torch.cuda.Event()
+            d.record(self.stream)
+        self.done[key] = d
+
+    def before_write(self, key):
+        e = self.done.pop(key, None)
+        if e is not None:
+            torch.cuda.current_stream().wait_event(e)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.done.clear()
+
+
+class _Inline:
+    def run(self, key, fn):
+        fn()
+
+    def before_write(self, key):
+        pass
+
+    def join(self):
+        pass
+
+
 class Stack:
     """`nblocks` transformer blocks over a packed [rows, D] fp32 residual stream with saved activations."""
 
@@ -168,37 +215,62 @@ class Stack:
         dxo, dxm = self.dx
         dbo, dbm = self.dxb
         ranges = [(0, M, blocks)] if blocks2 is None else [(0, split, blocks), (split, M, blocks2)]
+        one = blocks2 is not None                # a row range has ONE affine set; the packed single-tower case selects by row_mod
+        mode = os.environ.get("AVSIAM_WGRAD_STREAM", "2")
+        side = _SideStream(dxo.device) if mode in ("1", "2") else _Inline()
+        excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
+
+        def wgrads(key, *jobs):
+            def fn():
+                for a, b, name in jobs:
+                    for lo, hi, bl in ranges:
+                        ops.gemm_tn(a[lo:], b[lo:], getattr(bl[i], name).gw, hi - lo)
+            side.run(key, fn)
+
         for i in reversed(range(self.nblocks)):
             bp, st = blocks[i], self.stats[i]
             b2 = blocks2[i] if blocks2 is not None else None
             # fc2: d(gelu out) fused with GELU' -> d(fc1 pre-activation)
+            if excl:
+                side.join()
+            else:
+                side.before_write("dfc1")
             ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
                         dual=(split, b2.fc2.wt, None, b2.fc1.gb) if b2 is not None else None)
-            for lo, hi, bl in ranges:
-                ops.gemm_tn(dbo[lo:], self.act[i][lo:], bl[i].fc2.gw, hi - lo)
-                if i == self.nblocks - 1 and not last_fc2_bias_done:
+            if not excl:
+                wgrads("dbo", (dbo, self.act[i], "fc2"))
+            if i == self.nblocks - 1 and not last_fc2_bias_done:
+                for lo, hi, bl in ranges:
                     ops.colsum(dbo[lo:], bl[i].fc2.gb, hi - lo)
             # fc1
             ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M, dual=(split, b2.fc1.wt, None, None) if b2 is not None else None)
+            if not excl:
+                wgrads("dfc1", (self.dfc1, self.ln2[i], "fc1"))
+                side.before_write("dbm")
             for lo, hi, bl in ranges:
-                ops.gemm_tn(self.dfc1[lo:], self.ln2[i][lo:], bl[i].fc1.gw, hi - lo)
-                one = blocks2 is not None            # a row range has ONE affine set; the packed single-tower case selects by row_mod
                 _ln_bwd(self.dln[lo:], self.xmid[i][lo:], st[2][lo:], st[3][lo:], bl[i].n2, dxm[lo:], self.lnws, hi - lo,
                         None if one else self.row_mod, dres=dxo[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb)
             # proj
             ops.gemm_nt(dbm, bp.proj.wt, self.datt, M, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
-            for lo, hi, bl in ranges:
-                ops.gemm_tn(dbm[lo:], self.att[i][lo:], bl[i].proj.gw, hi - lo)
+            if excl:                  # the three wgrads whose operands exist now run beside the attention backward
+                wgrads("blockA", (dbo, self.act[i], "fc2"), (self.dfc1, self.ln2[i], "fc1"), (dbm, self.att[i], "proj"))
+            else:
+                wgrads("dbm", (dbm, self.att[i], "proj"))
+                side.before_write("dqkv")
             ops.attn_bwd(self.qkv[i], self.tiles, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
             # qkv
+            if excl:
+                side.join()
             ops.gemm_nt(self.dqkv, bp.qkv.wt, self.dln, M, dual=(split, b2.qkv.wt, None, None) if b2 is not None else None)
+            wgrads("dqkv", (self.dqkv, self.ln1[i], "qkv"))
+            if not excl:
+                side.before_write("dbo")
             for lo, hi, bl in ranges:
-                ops.gemm_tn(self.dqkv[lo:], self.ln1[i][lo:], bl[i].qkv.gw, hi - lo)
                 ops.colsum(self.dqkv[lo:], bl[i].qkv.gb, hi - lo)
-                one = blocks2 is not None
                 _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, dxo[lo:], self.lnws, hi - lo,
                         None if one else self.row_mod, dres=dxm[lo:], dx_bf16=dbo[lo:],
                         dcol=bl[i - 1].fc2.gb if i > 0 else None)
+        side.join()
 
 
 class PatchEmbedder:
