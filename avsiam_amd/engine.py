@@ -220,11 +220,11 @@ class Stack:
         side = _SideStream(dxo.device) if mode in ("1", "2") else _Inline()
         excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
 
-        def wgrads(key, *jobs):
+        def wgrads(blk, key, *jobs):
             def fn():
                 for a, b, name in jobs:
                     for lo, hi, bl in ranges:
-                        ops.gemm_tn(a[lo:], b[lo:], getattr(bl[i], name).gw, hi - lo)
+                        ops.gemm_tn(a[lo:], b[lo:], getattr(bl[blk], name).gw, hi - lo)
             side.run(key, fn)
 
         for i in reversed(range(self.nblocks)):
@@ -238,14 +238,14 @@ class Stack:
             ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
                         dual=(split, b2.fc2.wt, None, b2.fc1.gb) if b2 is not None else None)
             if not excl:
-                wgrads("dbo", (dbo, self.act[i], "fc2"))
+                wgrads(i, "dbo", (dbo, self.act[i], "fc2"))
             if i == self.nblocks - 1 and not last_fc2_bias_done:
                 for lo, hi, bl in ranges:
                     ops.colsum(dbo[lo:], bl[i].fc2.gb, hi - lo)
             # fc1
             ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M, dual=(split, b2.fc1.wt, None, None) if b2 is not None else None)
             if not excl:
-                wgrads("dfc1", (self.dfc1, self.ln2[i], "fc1"))
+                wgrads(i, "dfc1", (self.dfc1, self.ln2[i], "fc1"))
                 side.before_write("dbm")
             for lo, hi, bl in ranges:
                 _ln_bwd(self.dln[lo:], self.xmid[i][lo:], st[2][lo:], st[3][lo:], bl[i].n2, dxm[lo:], self.lnws, hi - lo,
@@ -253,16 +253,16 @@ class Stack:
             # proj
             ops.gemm_nt(dbm, bp.proj.wt, self.datt, M, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
             if excl:                  # the three wgrads whose operands exist now run beside the attention backward
-                wgrads("blockA", (dbo, self.act[i], "fc2"), (self.dfc1, self.ln2[i], "fc1"), (dbm, self.att[i], "proj"))
+                wgrads(i, "blockA", (dbo, self.act[i], "fc2"), (self.dfc1, self.ln2[i], "fc1"), (dbm, self.att[i], "proj"))
             else:
-                wgrads("dbm", (dbm, self.att[i], "proj"))
+                wgrads(i, "dbm", (dbm, self.att[i], "proj"))
                 side.before_write("dqkv")
             ops.attn_bwd(self.qkv[i], self.tiles, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
             # qkv
             if excl:
                 side.join()
             ops.gemm_nt(self.dqkv, bp.qkv.wt, self.dln, M, dual=(split, b2.qkv.wt, None, None) if b2 is not None else None)
-            wgrads("dqkv", (self.dqkv, self.ln1[i], "qkv"))
+            wgrads(i, "dqkv", (self.dqkv, self.ln1[i], "qkv"))
             if not excl:
                 side.before_write("dbo")
             for lo, hi, bl in ranges:
