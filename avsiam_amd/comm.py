@@ -1,0 +1,130 @@
+"""Collectives of the data-parallel path, injected into the model.
+
+The reference gets its collectives from two places: ``GatherLayer`` (/root/reference/src/models/gather_layer.py:21-37:
+all_gather forward, all_reduce backward) and DistributedDataParallel's bucketed gradient all-reduce
+(/root/reference/src/traintest_cavmae_base.py:58-59).  Here they are two calls on a small object:
+
+    all_gather(out, inp)            out[W * n] <- every rank's inp[n]          (c2: ONE packed [2,B,D] message per rank)
+    all_reduce_async(t) -> handle   SUM over ranks, in place; handle.wait() orders the caller's stream behind it   (c1)
+
+``TorchDistComm`` is the product implementation: torch.distributed with backend "nccl", which on ROCm is RCCL over xGMI.
+Tests inject their own implementation (gloo with host staging: two ranks cannot share one GPU under RCCL), so no test-only
+branch lives in the product code.  ``GradReducer`` is the DDP-bucket equivalent on the flat gradient arena: contiguous
+chunks are all-reduced as soon as the backward schedule declares them final, overlapping the rest of the backward.
+"""
+import os
+
+import torch
+
+
+class LocalComm:
+    """World size 1: nothing to exchange."""
+    world, rank, active = 1, 0, False
+
+    def all_gather(self, out, inp):
+        out.view(-1)[:inp.numel()].copy_(inp.reshape(-1))
+
+    def all_reduce_async(self, t):
+        return _Done()
+
+    def all_reduce(self, t):
+        pass
+
+
+class _Done:
+    def wait(self):
+        pass
+
+
+class TorchDistComm:
+    """torch.distributed ("nccl" == RCCL on ROCm).  Asynchronous all-reduces run on the backend's own stream: the call
+    orders them behind the work already queued on the current stream, handle.wait() orders the current stream behind them."""
+
+    def __init__(self, group=None, always=False):
+        """always=True: issue the collectives at world size 1 too (a one-rank RCCL group is the most a single-GPU box can
+        run of this path; tests/test_boundary_gpu.py)."""
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.active = self.world > 1 or always
+
+    def all_gather(self, out, inp):
+        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_reduce_async(self, t):
+        return self.dist.all_reduce(t, group=self.group, async_op=True)
+
+    def all_reduce(self, t):
+        self.dist.all_reduce(t, group=self.group)
+
+
+def default_comm(world):
+    if world <= 1:
+        return LocalComm()
+    return TorchDistComm()
+
+
+class GradReducer:
+    """All-reduce(SUM) of one pass's live gradient range [lo, hi) of the flat arena, in chunks.
+
+    The backward schedule calls ``ready(a, b)`` when the gradients in [a, b) are final (all kernels writing them are
+    queued on the current stream, side streams joined); the chunk's all-reduce starts right away and overlaps the rest
+    of the backward.  ``finish()`` reduces whatever part of [lo, hi) was never declared and waits for everything.
+    Ranges may arrive in any order and may touch; they must not overlap.  Small ready-ranges are coalesced until
+    ``min_elems`` are pending, so that xGMI sees few, large messages (ring collectives are per-link bound).
+
+    mode (AVSIAM_DP_OVERLAP): "1" (default) chunks as described; "0" one blocking message in finish() - what round 1 did.
+    """
+
+    def __init__(self, comm, g, lo, hi, min_elems=16 << 20, overlap=None):
+        self.comm, self.g, self.lo, self.hi = comm, g, lo, hi
+        self.min_elems = min_elems
+        if overlap is None:
+            overlap = os.environ.get("AVSIAM_DP_OVERLAP", "1") != "0"
+        self.active = getattr(comm, "active", comm.world > 1)
+        self.overlap = overlap and self.active
+        self.sent = []            # [a, b) ranges already handed to the collective
+        self.pending = []         # declared final, not yet sent
+        self.handles = []
+        self.messages = 0
+
+    def ready(self, a, b):
+        if not self.overlap or b <= a:
+            return
+        a, b = max(a, self.lo), min(b, self.hi)
+        if b <= a:
+            return
+        self.pending.append((a, b))
+        if sum(y - x for x, y in self.pending) >= self.min_elems:
+            self._flush()
+
+    def _merge(self, ranges):
+        out = []
+        for a, b in sorted(ranges):
+            if out and a <= out[-1][1]:
+                assert a == out[-1][1], "GradReducer: overlapping ready ranges"
+                out[-1] = (out[-1][0], b)
+            else:
+                out.append((a, b))
+        return out
+
+    def _flush(self):
+        for a, b in self._merge(self.pending):
+            self.handles.append(self.comm.all_reduce_async(self.g[a:b]))
+            self.messages += 1
+            self.sent.append((a, b))
+        self.pending = []
+
+    def finish(self):
+        if not self.active:
+            return
+        self._flush()
+        cur = self.lo
+        for a, b in self._merge(self.sent) + [(self.hi, self.hi)]:
+            if a > cur:
+                self.handles.append(self.comm.all_reduce_async(self.g[cur:a]))
+                self.messages += 1
+            cur = max(cur, b)
+        for h in self.handles:
+            h.wait()
+        self.handles, self.sent = [], []

@@ -16,6 +16,7 @@ MI355X-first restructuring of ``CAVMAE_BASE.forward`` (/root/reference/src/model
 
 The mask plan (which tokens each sample keeps) is an explicit input - see maskplan.py.
 """
+import math
 import os
 
 import numpy as np
@@ -53,11 +54,27 @@ class Norm:
         self.dg, self.db = (arena.gw(prefix + ".weight"), arena.gw(prefix + ".bias")) if grads else (None, None)
 
 
+def grad_ranges(arena, prefix, min_elems=1 << 20):
+    """Contiguous ranges of the flat gradient arena covered by the live parameters named `prefix`*, smallest first.
+    Only ranges of at least `min_elems` elements are returned: the reducer sends what is left (LayerNorm vectors sitting in
+    another liveness class of the arena, embeddings, heads) in its final message instead of one tiny message each."""
+    spans = sorted((arena.offset[n], arena.offset[n] + (math.prod(s.shape) + 63) // 64 * 64) for n, s in arena.info.items()
+                   if n.startswith(prefix) and s.live)
+    out = []
+    for a, b in spans:
+        if out and a == out[-1][1]:
+            out[-1][1] = b
+        else:
+            out.append([a, b])
+    return [(a, b) for a, b in out if b - a >= min_elems]
+
+
 class BlockParams:
     """One transformer Block (cav_mae_base.py:102-211); `sfx0`/`sfx1` name the LayerNorm sets for row_mod 0/1
     ('' plain, '_a', '_v')."""
 
     def __init__(self, arena, prefix, sfx0, sfx1=None):
+        self.ranges = grad_ranges(arena, prefix + ".")
         self.n1 = [Norm(arena, f"{prefix}.norm1{sfx0}")] + ([Norm(arena, f"{prefix}.norm1{sfx1}")] if sfx1 is not None else [])
         self.n2 = [Norm(arena, f"{prefix}.norm2{sfx0}")] + ([Norm(arena, f"{prefix}.norm2{sfx1}")] if sfx1 is not None else [])
         self.qkv = Linear(arena, f"{prefix}.attn.qkv.weight", f"{prefix}.attn.qkv.bias")
@@ -115,6 +132,20 @@ class _SideStream:
     def join(self):
         torch.cuda.current_stream().wait_stream(self.stream)
         self.done.clear()
+
+
+WGRAD_STREAM_MODE = os.environ.get("AVSIAM_WGRAD_STREAM", "2")     # read once (A/B runs set it before the import)
+_side_streams = {}
+
+
+def _side_stream(dev):
+    """One second stream per device for the whole process (a torch.cuda.Stream per backward call would leak pool entries)."""
+    key = (dev.type, dev.index)
+    if key not in _side_streams:
+        _side_streams[key] = _SideStream(dev)
+    s = _side_streams[key]
+    s.done.clear()
+    return s
 
 
 class _Inline:
@@ -202,8 +233,9 @@ class Stack:
             ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1)
             ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2)
 
-    def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0):
+    def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0, reducer=None):
         """In: d(out) in self.dx[0] (fp32) and self.dxb[0] (bf16).  Out: d(x[0]) in the same two buffers.
+        reducer (comm.GradReducer, data parallel): told which ranges of the gradient arena are final as the blocks complete.
         Bias gradients of fc2 / proj are column sums of the residual-stream gradient and come out of the LayerNorm
         backward that produces it (`dcol`); `last_fc2_bias_done` says the caller's LN backward already did that for
         the last block.
@@ -216,9 +248,17 @@ class Stack:
         dbo, dbm = self.dxb
         ranges = [(0, M, blocks)] if blocks2 is None else [(0, split, blocks), (split, M, blocks2)]
         one = blocks2 is not None                # a row range has ONE affine set; the packed single-tower case selects by row_mod
-        mode = os.environ.get("AVSIAM_WGRAD_STREAM", "2")
-        side = _SideStream(dxo.device) if mode in ("1", "2") else _Inline()
+        mode = WGRAD_STREAM_MODE
+        side = _side_stream(dxo.device) if mode in ("1", "2") else _Inline()
         excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
+
+        def block_done(j):
+            """Every kernel writing block j's parameter gradients is queued on the current stream or joined into it."""
+            if reducer is not None:
+                for bl in (blocks, blocks2):
+                    if bl is not None:
+                        for a, b in bl[j].ranges:
+                            reducer.ready(a, b)
 
         def wgrads(blk, key, *jobs):
             def fn():
@@ -233,6 +273,8 @@ class Stack:
             # fc2: d(gelu out) fused with GELU' -> d(fc1 pre-activation)
             if excl:
                 side.join()
+                if i + 1 < self.nblocks:
+                    block_done(i + 1)          # its last wgrad (qkv) was the side stream's tail; fc2's bias came from this LN backward
             else:
                 side.before_write("dfc1")
             ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
@@ -271,6 +313,9 @@ class Stack:
                         None if one else self.row_mod, dres=dxm[lo:], dx_bf16=dbo[lo:],
                         dcol=bl[i - 1].fc2.gb if i > 0 else None)
         side.join()
+        if reducer is not None:
+            for j in ([0] if excl else reversed(range(self.nblocks))):
+                block_done(j)
 
 
 class PatchEmbedder:
@@ -331,8 +376,11 @@ def _fold_frames(imgs, T):
 class ContrastivePass:
     """Pass 1 (forward_encoder_mmixed + forward_contrastive, cav_mae_base.py:508-594,641-661)."""
 
-    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, world=1, rank=0):
+    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, world=1, rank=0, comm=None):
         self.arena, self.cfg, self.B, self.dev, self.world, self.rank = arena, cfg, batch, dev, world, rank
+        self.comm = comm
+        assert world == 1 or comm is not None, "data parallel needs a collective (model.set_distributed)"
+        self.dp = comm is not None and getattr(comm, "active", world > 1)
         T, D = cfg.frames, cfg.embed_dim
         sizes = group_sizes(batch, cfg.n_groups)
         self.sizes = sizes
@@ -491,14 +539,8 @@ class ContrastivePass:
         ops.segment_mean_fwd(self.yf, self.seg_start, self.reps_slot, 2 * self.B)
         self.reps.index_copy_(0, self.slot_to_row, self.reps_slot)        # slot order -> sample order
         B, W, D = self.B, self.world, cfg.embed_dim
-        if W > 1:
-            import torch.distributed as dist
-            if dist.get_backend() == "gloo":                  # test path (2 ranks sharing one GPU): gloo has no device all-gather-into-tensor
-                host = [torch.empty(2 * B, D) for _ in range(W)]
-                dist.all_gather(host, self.reps.cpu())
-                self.all_reps.copy_(torch.stack(host))
-            else:
-                dist.all_gather_into_tensor(self.all_reps.view(W * 2 * B, D), self.reps)   # c2: one [2,B,D] message per rank (RCCL)
+        if self.dp:
+            self.comm.all_gather(self.all_reps.view(W * 2 * B, D), self.reps)             # c2: one [2,B,D] message per rank (RCCL)
             self.A.copy_(self.all_reps[:, :B].reshape(W * B, D))
             self.V.copy_(self.all_reps[:, B:].reshape(W * B, D))
         else:
@@ -511,7 +553,7 @@ class ContrastivePass:
         ops.infonce_fwd(self.total, self.nstats, self.nout, weight)
         return self.nout[2:3], self.nout[1:2]
 
-    def backward(self, gout, weight):
+    def backward(self, gout, weight, reducer=None):
         """gout: [1] fp32 device tensor (d loss / d loss_c_weighted); weight = contrast_loss_weight."""
         cfg, st = self.cfg, self.stack
         B, W, D, N = self.B, self.world, cfg.embed_dim, self.N
@@ -529,7 +571,7 @@ class ContrastivePass:
         ops.segment_mean_bwd(self.dreps_slot, self.seg_start, self.yf, 2 * B, float(W))
         _ln_bwd(self.yf, st.out, self.fstat[0], self.fstat[1], self.final, st.dx[0], st.lnws, self.rows, st.row_mod,
                 dx_bf16=st.dxb[0], dcol=self.blocks[-1].fc2.gb)
-        st.backward(self.blocks, last_fc2_bias_done=True)
+        st.backward(self.blocks, last_fc2_bias_done=True, reducer=reducer)
         self.emb_a.backward(st.dx[0][:self.rows_a])
         self.emb_v.backward(st.dx[0][self.rows_a:])
 
@@ -705,7 +747,7 @@ class MaePass:
                          total=self.losses[2:3], total_init=False)                                          # loss_mae = a + v (:707)
         return self.losses[2:3], self.losses[0:1], self.losses[1:2], self.mask_a, self.mask_v
 
-    def backward(self, gout):
+    def backward(self, gout, reducer=None):
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         La, Lv, D, Dd = cfg.audio_tokens, cfg.video_tokens, cfg.embed_dim, cfg.dec_dim
         ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a)
@@ -721,7 +763,7 @@ class MaePass:
         rows_d = B * self.Ltot
         _ln_bwd(self.ddn, sd.out, self.dn_stat[0], self.dn_stat[1], self.dec_norm, sd.dx[0], sd.lnws, rows_d,
                 out_map=self.dn_map, dx_bf16=sd.dxb[0], dcol=self.blk_dec[-1].fc2.gb)
-        sd.backward(self.blk_dec, last_fc2_bias_done=True)
+        sd.backward(self.blk_dec, last_fc2_bias_done=True, reducer=reducer)
         g = self.gtok
         ops.unshuffle_bwd(sd.dx[0], self.src_row, B, T, La, Lv, self.dde, g["decoder_pos_embed_a"], g["decoder_pos_embed_v"],
                           g["mask_token"], g["decoder_modality_a"], g["decoder_modality_v"])
@@ -732,14 +774,14 @@ class MaePass:
         ops.gemm_tn(self.dde_b, self.xj_b, self.dec_embed.gw, rows_j)
         ops.colsum(self.dde_b, self.dec_embed.gb, rows_j)
         ops.cast_scale(sm.dx[0], sm.dxb[0], rows_j * D, 1.0)
-        sm.backward(self.blk_mm)
+        sm.backward(self.blk_mm, reducer=reducer)
         if self.grouped:
             st, ra = self.st_t, self.rows_a
             for lo, fin, fstat, omap, rows, blks in ((0, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.blk_a),
                                                      (ra, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.blk_v)):
                 _ln_bwd(sm.dx[0], st.out[lo:], fstat[0], fstat[1], fin, st.dx[0][lo:], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0][lo:],
                         dcol=blks[-1].fc2.gb)
-            st.backward(self.blk_a, last_fc2_bias_done=True, blocks2=self.blk_v, split=ra)
+            st.backward(self.blk_a, last_fc2_bias_done=True, blocks2=self.blk_v, split=ra, reducer=reducer)
             self.emb_a.backward(st.dx[0][:ra])
             self.emb_v.backward(st.dx[0][ra:])
             return
@@ -747,5 +789,5 @@ class MaePass:
                                                       (self.st_v, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.emb_v, self.blk_v)):
             _ln_bwd(sm.dx[0], st.out, fstat[0], fstat[1], fin, st.dx[0], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0],
                     dcol=blks[-1].fc2.gb)
-            st.backward(blks, last_fc2_bias_done=True)
+            st.backward(blks, last_fc2_bias_done=True, reducer=reducer)
             emb.backward(st.dx[0])

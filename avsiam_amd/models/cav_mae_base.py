@@ -97,10 +97,30 @@ class _HotPath(torch.autograd.Function):
             lo, hi = arena.range[P2]
             lo = max(lo, arena.range[P1][1]) if live & P1 else lo
             arena.g[lo:hi].zero_()
+        # data parallel: the gradient all-reduce belongs to backward, as under DDP (traintest_cavmae_base.py:58-59) - chunks of
+        # the flat arena are reduced as soon as the schedule declares them final (comm.GradReducer).  A backward with BOTH
+        # passes live accumulates two passes into the shared range, so it is reduced once, at the end.
+        red = {}
+        if model._dp and model.reduce_in_backward:
+            if live == (P1 | P2):
+                red[0] = model._make_reducer(arena.range[P1][0], arena.range[P2][1], overlap=False)
+            else:
+                red[live] = model._make_reducer(*arena.range[live])
         if live & P2:
-            model._engine("mae", B).backward(g_mae.reshape(1).float().contiguous())
+            model._engine("mae", B).backward(g_mae.reshape(1).float().contiguous(), reducer=red.get(P2))
         if live & P1:
-            model._engine("contrastive", B).backward(g_c.reshape(1).float().contiguous(), ctx.contrast_w)
+            model._engine("contrastive", B).backward(g_c.reshape(1).float().contiguous(), ctx.contrast_w, reducer=red.get(P1))
+        for r in red.values():
+            r.finish()
+            model.last_reduce_messages = r.messages
+        if red:
+            for w in (P1, P2):
+                if live & w:
+                    model._grad_scale[w] = 1.0 / model._world          # the SUM is in the arena; DDP's mean is still owed
+            if model.publish_grads:                                    # an external optimizer reads .grad: deliver the mean now
+                for w in (P1, P2):
+                    if live & w:
+                        model._average(w, live)
         if model.publish_grads:
             model._publish(live)
         return (None,) * 7
@@ -132,6 +152,11 @@ class CAVMAE_BASE(nn.Module):
         self._engines = {}
         self._opt_state = {}
         self._world, self._rank = 1, 0
+        self._comm, self._dp = None, False
+        self.reduce_in_backward = True             # data parallel: loss.backward() all-reduces, like DDP (False: call allreduce_grads)
+        self._grad_scale = {P1: 1.0, P2: 1.0}      # factor the arena's gradients still owe (1/W after a SUM all-reduce)
+        self._versions = None
+        self.last_reduce_messages = 0
         self._gen = None
         self._pyrng = None
         self._plan_seed = plan_seed
@@ -169,9 +194,31 @@ class CAVMAE_BASE(nn.Module):
         """Call after modifying parameters outside adam_step() (e.g. an external optimizer)."""
         self._shadow_dirty = True
 
-    def set_distributed(self, world, rank):
+    def set_distributed(self, world, rank, comm=None):
+        """comm: the collectives to use (comm.TorchDistComm = RCCL by default; tests inject their own)."""
+        from ..comm import default_comm
         self._world, self._rank = world, rank
+        self._comm = comm if comm is not None else default_comm(world)
+        assert self._comm.world == world and self._comm.rank == rank, "comm does not match (world, rank)"
+        self._dp = getattr(self._comm, "active", world > 1)        # collectives on the path (always at world > 1)
         self._engines.clear()
+
+    def _make_reducer(self, lo, hi, overlap=None):
+        from ..comm import GradReducer
+        return GradReducer(self._comm, self.arena.ensure_grads(), lo, hi, overlap=overlap)
+
+    def _average(self, which, live=None):
+        """Apply the factor the gradients of pass `which` still owe (DDP's 1/W).  With both passes live in one backward the
+        two ranges share the middle of the arena: the union is scaled once."""
+        s = self._grad_scale[which]
+        if s == 1.0:
+            return
+        lo, hi = self.arena.range[which]
+        if live == (P1 | P2):
+            lo, hi = self.arena.range[P1][0], self.arena.range[P2][1]
+            self._grad_scale[P1] = self._grad_scale[P2] = 1.0
+        self.arena.g[lo:hi].mul_(s)
+        self._grad_scale[which] = 1.0
 
     # ---- engines ---------------------------------------------------------------------------------------------
     def _require_gpu(self):
@@ -188,10 +235,18 @@ class CAVMAE_BASE(nn.Module):
             if which == "mae":
                 self._engines[key] = MaePass(self.arena, self.cfg, batch, dev)
             else:
-                self._engines[key] = ContrastivePass(self.arena, self.cfg, batch, dev, self._world, self._rank)
+                self._engines[key] = ContrastivePass(self.arena, self.cfg, batch, dev, self._world, self._rank, self._comm)
         return self._engines[key]
 
     def _sync_shadows(self):
+        # an optimizer the model does not know about (the reference loop's torch.optim.Adam, p.data edits, EMA) changes the fp32
+        # masters in place: every such op bumps the tensor's version counter, so a changed sum marks the bf16 shadows stale.
+        # Only checked when gradients are published for an external optimizer; adam_step() refreshes the shadows itself.
+        if self.publish_grads:
+            v = sum(p._version for p in self._params.values())
+            if v != self._versions:
+                self._versions = v
+                self._shadow_dirty = True
         if self._shadow_dirty:
             self.arena.refresh_shadows(None)
             self._shadow_dirty = False
@@ -284,18 +339,23 @@ class CAVMAE_BASE(nn.Module):
         return loss, loss_mae, la, lv, loss_c, mask_a, mask_v, c_acc
 
     # ---- fused data-parallel + optimizer step over the flat arena -------------------------------------------------
-    def allreduce_grads(self, which):
-        """c1: ONE all-reduce(SUM) over exactly the live gradient range of the pass (RCCL over xGMI); the 1/W of DDP's
-        mean is folded into adam_step's grad_scale."""
-        if self._world > 1:
-            import torch.distributed as dist
-            g = self.arena.live_slice(self.arena.ensure_grads(), which)
-            if g.is_cuda and dist.get_backend() == "gloo":    # test path: stage through the host
-                h = g.cpu()
-                dist.all_reduce(h)
-                g.copy_(h)
-            else:
-                dist.all_reduce(g)
+    def allreduce_grads(self, which, average=True, already_reduced=None):
+        """c1: all-reduce over exactly the live gradient range of pass `which` (RCCL over xGMI).  ``loss.backward()`` has
+        normally done the SUM already (chunked, overlapped with the backward, like DDP's buckets); gradients written into
+        the arena by other means (host-side tests) are reduced here in one message - pass already_reduced=False.
+        average=True (default) leaves DDP's MEAN in the arena / in ``.grad``, so the reference recipe
+        ``loss.backward(); optimizer.step()`` with any torch optimizer sees what it would under DDP.  train_step passes
+        average=False: the 1/W is then folded into the fused Adam kernel's grad_scale."""
+        if not self._dp:
+            return
+        if already_reduced is None:
+            already_reduced = self._grad_scale[which] != 1.0
+        if not already_reduced:
+            r = self._make_reducer(*self.arena.range[which], overlap=False)
+            r.finish()
+            self._grad_scale[which] = 1.0 / self._world
+        if average:
+            self._average(which)
 
     def adam_step(self, which, lr, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=5e-7):
         """torch.optim.Adam(lr, weight_decay=5e-7, betas=(0.95, 0.999)) of the reference loop (:64-66) on the pass's
@@ -309,8 +369,47 @@ class CAVMAE_BASE(nn.Module):
             self._opt_state[which] = st
         st["step"] += 1
         ops.adam(a.p[lo:hi], a.g[lo:hi], st["m"], st["v"], a.pb[lo:hi], hi - lo, lr, st["step"], beta1, beta2, eps,
-                 weight_decay, 1.0 / self._world)
+                 weight_decay, self._grad_scale[which])
+        self._grad_scale[which] = 1.0
         a.refresh_shadows(which, cast=False)
+
+    # ---- optimizer state in torch.optim.Adam's format (best_optim_state.pth, traintest_cavmae_base.py:230) -----------
+    def optimizer_state_dict(self, which, lr, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=5e-7):
+        """State of the pass's Adam as ``torch.optim.Adam(trainables, ...).state_dict()`` would hold it: parameters indexed in
+        ``parameters()`` order; parameters the pass never touched (grad None) have no state, as in torch."""
+        a = self.arena
+        lo, hi = a.range[which]
+        st = self._opt_state.get(which)
+        state = {}
+        params = list(self.parameters())
+        index = {id(p): i for i, p in enumerate(params)}
+        if st is not None:
+            for name, p in self._params.items():
+                info = a.info[name]
+                if not (info.live & which):
+                    continue
+                o, n = a.offset[name] - lo, p.numel()
+                state[index[id(p)]] = {"step": torch.tensor(float(st["step"])),
+                                       "exp_avg": st["m"][o:o + n].view(p.shape).detach().cpu().clone(),
+                                       "exp_avg_sq": st["v"][o:o + n].view(p.shape).detach().cpu().clone()}
+        group = {"lr": lr, "betas": (beta1, beta2), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, which, sd):
+        a = self.arena
+        lo, hi = a.range[which]
+        dev = a.p.device
+        st = {"m": torch.zeros(hi - lo, device=dev), "v": torch.zeros(hi - lo, device=dev), "step": 0}
+        params = list(self.parameters())
+        name_of = {id(p): n for n, p in self._params.items()}
+        for i, s in sd["state"].items():
+            name = name_of[id(params[int(i)])]
+            o, n = a.offset[name] - lo, params[int(i)].numel()
+            st["m"][o:o + n].copy_(s["exp_avg"].reshape(-1))
+            st["v"][o:o + n].copy_(s["exp_avg_sq"].reshape(-1))
+            st["step"] = int(s["step"])
+        self._opt_state[which] = st
 
 
 class _NoCtx:

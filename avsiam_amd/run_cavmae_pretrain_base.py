@@ -5,8 +5,11 @@
 
 Flags the reference parses but its model ignores (masking ratios, mask_mode, norm_pix_loss, tr_pos: SURVEY.md section 5)
 are accepted and equally inert.  Data flags: with --data-train '' (or 'synthetic') AudioSet-shaped synthetic
-batches are used - the sqlite/wav/mp4 input pipeline (src/dataloader.py) is out of scope for this path.
---frames is an extension (T frames per sample).
+batches are used - the sqlite/wav/mp4 input pipeline (src/dataloader.py) is out of scope for this path; --data-val
+'synthetic' adds a synthetic validation loader so validate() and the best-model bookkeeping run.
+Extensions: --frames (T frames per sample), --steps-per-epoch / --val-steps (synthetic epoch lengths), --raw-input (the
+loader hands over what the reference's dataset holds BEFORE normalisation - un-normalised fbank, uint8 frames - and the
+dataloader's arithmetic, incl. --noise, runs on the device: avsiam_amd/preprocess.py).
 """
 import argparse
 import ast
@@ -64,14 +67,34 @@ def build_parser():
     # extensions
     parser.add_argument('--frames', default=1, type=int, help="frames per sample (extension; reference pre-training uses 1)")
     parser.add_argument('--steps-per-epoch', dest="steps_per_epoch", default=20, type=int, help="synthetic-data epoch length")
+    parser.add_argument('--val-steps', dest="val_steps", default=2, type=int, help="synthetic validation batches per epoch")
+    parser.add_argument('--raw-input', dest="raw_input", action="store_true",
+                        help="feed un-normalised fbank + uint8 frames and normalise on the device (dataloader.py:505-513,461-462)")
     return parser
+
+
+def make_preprocess(args):
+    """The reference dataset's per-sample arithmetic as a device-side hook (a_raw, v_raw, train) -> (a, v):
+    (fbank - dataset_mean) / dataset_std, + noise and time roll in training when --noise (dataloader.py:505-513);
+    uint8 frames -> (x / 255 - mean_c) / std_c (:461-462, 152-155)."""
+    import numpy as np
+    from . import preprocess
+    rng = np.random.default_rng(87 + getattr(args, "local_rank", 0))
+    step = [0]
+
+    def prep(a_raw, v_raw, train=True):
+        step[0] += 1
+        a = preprocess.normalize_fbank(a_raw.contiguous(), args.dataset_mean, args.dataset_std, noise=bool(args.noise) and train,
+                                       seed=step[0], rng=rng)
+        return a, preprocess.normalize_frames(v_raw.contiguous())
+    return prep
 
 
 def main(argv=None):
     import torch
     from . import models, utils
     from .config import AVSiamConfig
-    from .traintest_cavmae_base import train
+    from .traintest_cavmae_base import SyntheticAVLoader, train
     print("I am process %s, running on %s: starting (%s)" % (os.getpid(), os.uname()[1], time.asctime()))
     args = build_parser().parse_args(argv)
     if args.masking_ratio_a is None:
@@ -79,6 +102,15 @@ def main(argv=None):
     args.local_rank = int(os.environ.get("LOCAL_RANK", 0))
     utils.init_seeds(87 + args.local_rank)                                    # :113
     utils.init_distributed_mode(args)                                         # :114
+    try:
+        return _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train)
+    finally:
+        utils.restore_print()
+        if args.distributed and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
+
+def _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train):
     print('current mae loss {:.3f}, and contrastive loss {:.3f}'.format(args.mae_loss_weight, args.contrast_loss_weight))
     if args.data_train not in ('', 'synthetic'):
         raise SystemExit("only synthetic AudioSet-shaped data is supported on this path (see module docstring)")
@@ -93,10 +125,16 @@ def main(argv=None):
             pickle.dump(args, f)
         with open(args.exp_dir + '/args.json', 'w') as f:
             json.dump(args.__dict__, f, indent=2)
+    val_loader = None
+    if args.data_val == 'synthetic':
+        val_loader = SyntheticAVLoader(cfg, args.batch_size, args.val_steps, torch.device("cuda", args.gpu), 1087 + args.rank,
+                                       raw=args.raw_input)
+    if args.raw_input:
+        args._preprocess = make_preprocess(args)
     print('Now starting training for {:d} epochs.'.format(args.n_epochs))
-    train(audio_model, None, [None, None], [None, None], None, args, None)                                        # :212
-    if args.distributed:
-        torch.distributed.destroy_process_group()
+    train(audio_model, None, [val_loader, None], [None, None], None, args, None)                                  # :212
+    args.__dict__.pop("_preprocess", None)
+    return audio_model
 
 
 if __name__ == "__main__":

@@ -107,6 +107,22 @@ def _tie_init(st, cfg):
             st[k] = st["vit_base." + k[len("my_"):]].clone()
 
 
+def synth_vit_checkpoint(cfg: AVSiamConfig, seed: int = 0):
+    """A timm-shaped ViT state dict (the keys of ``jx_vit_base_patch16_224_in21k``: cls_token, pos_embed,
+    patch_embed.proj.*, blocks.N.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}.*, norm.*, head.*) with name-keyed
+    synthetic values - a stand-in for the checkpoint the reference constructor loads (cav_mae_base.py:236-240) on machines
+    without network; also what the pretrained-init golden vector was generated from (oracle/gen_golden.py)."""
+    out = {}
+    for k, t in synth_state(cfg, seed, "random").items():
+        if not k.startswith("vit_base."):
+            continue
+        kk = k[len("vit_base."):]
+        if "_a." in kk or "_v." in kk or kk.endswith("_a"):         # derived by the constructor, not part of the checkpoint
+            continue
+        out[kk] = t.clone()
+    return out
+
+
 def state_from_vit(vit_sd, cfg: AVSiamConfig, seed: int = 0):
     """Initial state of CAVMAE_BASE from a timm ViT checkpoint (``jx_vit_base_patch16_224_in21k``: keys ``cls_token``,
     ``pos_embed``, ``patch_embed.proj.*``, ``blocks.N.*``, ``norm.*``, ``head.*``), the way the reference constructor

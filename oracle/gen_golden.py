@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 from avsiam_amd.config import AVSiamConfig                      # noqa: E402
 from avsiam_amd.maskplan import ContrastivePlan, MaePlan, group_sizes, plan_to_arrays   # noqa: E402
 from avsiam_amd.param_spec import state_dict_keys, alias_of    # noqa: E402
-from avsiam_amd.weights import synth_inputs, synth_state       # noqa: E402
+from avsiam_amd.weights import synth_inputs, synth_state, synth_vit_checkpoint       # noqa: E402
 from oracle import ref_import                                  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -57,11 +57,19 @@ def full_state(cfg, seed, mode):
     return {k: st[alias_of(k)] for k in state_dict_keys(cfg)}
 
 
-def plan_from_recorder(rec, cfg, B, which):
+def plan_from_recorder(rec, cfg, B, which, calls=None, perms=None):
+    calls = rec.calls if calls is None else calls
+    perms = rec.perms if perms is None else perms
+    if which == "both":
+        # the combined forward (:694-739) runs forward_encoder first - two masking calls and two UNUSED randperms (:465-470) -
+        # then forward_encoder_mmixed
+        return {"mae": plan_from_recorder(rec, cfg, B, "mae", calls[:2], perms[:2]),
+                "contrastive": plan_from_recorder(rec, cfg, B, "contrastive", calls[2:], perms[2:])}
     if which == "mae":
-        (_, ka, ra), (_, kv, rv) = rec.calls
+        (_, ka, ra), (_, kv, rv) = calls
         return MaePlan(ka, ra, kv.unsqueeze(1), rv.unsqueeze(1))
-    perm_a, perm_v = rec.perms[0], rec.perms[1]
+    perm_a, perm_v = perms[0], perms[1]
+    rec = type("R", (), {"calls": calls})
     sizes = group_sizes(B, cfg.n_groups)
     a_group = torch.zeros(B, dtype=torch.int64)
     v_group = torch.zeros(B, dtype=torch.int64)
@@ -77,6 +85,9 @@ def plan_from_recorder(rec, cfg, B, which):
             v_keep[bv] = [kv[i].clone()]
         off += n
     return ContrastivePlan(a_group, v_group, a_keep, v_keep)
+
+
+COMBINED_WEIGHTS = (3.0, 0.01)       # run_cavmae_pretrain_base.py defaults (--mae_loss_weight 3.0 --contrast_loss_weight 0.01): what validate() passes
 
 
 def run_case(model, cfg, which, B, input_seed, constant=None, rank=0):
@@ -100,6 +111,8 @@ def run_case(model, cfg, which, B, input_seed, constant=None, rank=0):
     with ref_import.PlanRecorder(model) as rec:
         if which == "mae":
             out = model(a, v, 0.75, 0.75, mae_loss_weight=1, contrast_loss_weight=0)
+        elif which == "both":
+            out = model(a, v, 0.75, 0.75, mae_loss_weight=COMBINED_WEIGHTS[0], contrast_loss_weight=COMBINED_WEIGHTS[1])
         else:
             out = model(a, v, 0.75, 0.75, mae_loss_weight=0, contrast_loss_weight=1)
     out[0].backward()
@@ -108,17 +121,26 @@ def run_case(model, cfg, which, B, input_seed, constant=None, rank=0):
     d = {"which": np.array(which), "batch": np.array(B), "input_seed": np.array(input_seed),
          "constant": np.array(np.nan if constant is None else constant), "weight_seed": np.array(WEIGHT_SEED),
          "rank": np.array(rank)}
-    for k, t in plan_to_arrays(plan).items():
-        d["plan_" + k] = t.numpy()
+    if which == "both":
+        for k, t in plan_to_arrays(plan["mae"]).items():
+            d["planm_" + k] = t.numpy()
+        for k, t in plan_to_arrays(plan["contrastive"]).items():
+            d["planc_" + k] = t.numpy()
+        d["loss_weights"] = np.array(COMBINED_WEIGHTS)
+        assert out[5] is None and out[6] is None                  # the mixed encoder's None masks win (:722)
+    else:
+        for k, t in plan_to_arrays(plan).items():
+            d["plan_" + k] = t.numpy()
     d["out_scalars"] = np.array([out[i].item() for i in (0, 1, 2, 3, 4, 7)], dtype=np.float64)
     if which == "mae":
         d["mask_a"], d["mask_v"] = out[5].numpy(), out[6].numpy()
+    if which in ("mae", "both"):
         for k in ("pred_a", "pred_v"):
             p = cap[k].double().reshape(-1)
             d[k + "_sum"] = np.array(p.sum().item())
             d[k + "_l2"] = np.array(p.norm().item())
             d[k + "_samples"] = np.array([p[i].item() for i in sample_positions(k, p.numel(), 64)])
-    else:
+    if which != "mae":
         ra = torch.nn.functional.normalize(cap["rep_a"], dim=-1)
         rv = torch.nn.functional.normalize(cap["rep_v"], dim=-1)
         d["logits"] = (torch.mm(ra, rv.t()) / 0.05).numpy()
@@ -157,7 +179,8 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     single = [("c_w1_b4", "contrastive", 4, 87, None),
               ("m_w1_b4", "mae", 4, 87, None),
-              ("m_w1_b2_const", "mae", 2, 87, 0.01)]
+              ("m_w1_b2_const", "mae", 2, 87, 0.01),
+              ("mc_w1_b4", "both", 4, 91, None)]
     _worker(0, 1, 29611, single, GOLDEN)
     import torch.multiprocessing as mp
     multi = [("c_w2_b3", "contrastive", 3, 87, None)]
@@ -172,6 +195,45 @@ def main():
         json.dump({"n_keys": len(keys), "n_params": sum(p.numel() for p in model.parameters()),
                    "shapes": shapes, "ln_eps": eps}, f)
     print("schema ok:", len(keys), "keys")
+    pretrained_init_golden()
+
+
+VIT_SEED = 4242
+
+
+def pretrained_init_golden():
+    """Row 8(f)1: run the reference CONSTRUCTOR (cav_mae_base.py:236-307) with its torch.load of the hard-coded checkpoint path
+    answered by a synthetic timm-shaped state dict, and record a checksum of every tensor it derives from it."""
+    import torch as _t
+    cfg = AVSiamConfig()
+    ckpt = synth_vit_checkpoint(cfg, VIT_SEED)
+    mod = ref_import.import_reference_module()
+    real_load = _t.load
+
+    def fake_load(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/mnt/"):
+            return {k2: v.clone() for k2, v in ckpt.items()}
+        return real_load(path, *a, **k)
+
+    _t.load = fake_load
+    try:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = mod.CAVMAE_BASE()
+    finally:
+        _t.load = real_load
+    derived = ("vit_base.", "ast_base.", "mm_layer_1.", "mm_layer_2.", "my_patch_embed.", "my_patch_embed_a.", "my_blocks.")
+    zero = ("decoder_pos_embed_a", "decoder_pos_embed_v", "mask_token", "decoder_modality_a", "decoder_modality_v")
+    rec = {}
+    for k, v in model.state_dict().items():
+        if k.startswith(derived) or k in zero:
+            t = v.detach().contiguous()
+            rec[k] = {"crc32": zlib.crc32(t.numpy().tobytes()), "sum": float(t.double().sum()), "l2": float(t.double().norm()),
+                      "shape": list(t.shape)}
+    with open(os.path.join(GOLDEN, "pretrained_init.json"), "w") as f:
+        json.dump({"vit_seed": VIT_SEED, "n_checkpoint_keys": len(ckpt), "tensors": rec}, f)
+    print("pretrained-init golden:", len(rec), "tensors from", len(ckpt), "checkpoint keys")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,272 @@
+"""The drop-in boundary beyond the two single-pass calls of the training step (SURVEY.md section 8(b), (f) rows 1-2, P13, P16
+and the entry point): the COMBINED forward validate() makes, validate()/train() bookkeeping, the pretrained-ViT
+initialisation, an external torch optimizer, the command-line entry and the process-group setup on the real backend.
+Everything runs through the C ABI on the GPU; tolerances as in tests/test_parity_gpu.py."""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from avsiam_amd.config import AVSiamConfig
+from avsiam_amd.param_spec import P1, P2
+from avsiam_amd.weights import synth_inputs, synth_state
+from tests.helpers import ROOT, golden_grads, golden_plan, load_golden, record_margin, sample_positions
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 3e-3            # measured worst case ~6e-4 (profiles/r02/parity_margins.json)
+
+
+def _model(cfg, seed=1234, mode="random", **kw):
+    from avsiam_amd.models import CAVMAE_BASE
+    return CAVMAE_BASE(cfg=cfg, init_seed=seed, init_mode=mode, verbose=False, **kw).cuda()
+
+
+def test_combined_forward_matches_reference_golden():
+    """forward(mae_loss_weight=3.0, contrast_loss_weight=0.01) - what validate() calls (traintest_cavmae_base.py:401) - against
+    the unmodified reference's outputs AND gradients for the same call (tests/golden/mc_w1_b4.npz)."""
+    d = load_golden("mc_w1_b4")
+    cfg = AVSiamConfig()
+    B = int(d["batch"])
+    wm, wc = (float(x) for x in d["loss_weights"])
+    a, v = synth_inputs(cfg, B, int(d["input_seed"]))
+    plan = golden_plan(d)
+    m = _model(cfg, int(d["weight_seed"]))
+    with torch.no_grad():
+        out0 = m(a.cuda(), v.cuda(), 0.75, 0.75, mae_loss_weight=wm, contrast_loss_weight=wc, mask_plan=plan)
+    out = m(a.cuda(), v.cuda(), 0.75, 0.75, mae_loss_weight=wm, contrast_loss_weight=wc, mask_plan=plan)
+    got0 = np.array([out0[i].item() for i in (0, 1, 2, 3, 4, 7)])
+    got = np.array([out[i].item() for i in (0, 1, 2, 3, 4, 7)])
+    np.testing.assert_array_equal(got0, got)                     # no-grad and grad forwards are the same kernels
+    np.testing.assert_allclose(got[:5], d["out_scalars"][:5], rtol=LOSS_RTOL, atol=1e-6)
+    assert abs(got[5] - d["out_scalars"][5]) <= 1.0 / B + 1e-6
+    record_margin("combined_golden", loss_rel=float(np.max(np.abs(got[:5] - d["out_scalars"][:5]) / np.abs(d["out_scalars"][:5]))))
+    assert out[5] is None and out[6] is None                     # the mixed encoder's None masks win (cav_mae_base.py:722)
+    assert abs(got[0] - (got[1] + got[4])) < 1e-6                # loss = loss_c + loss_mae (:739), loss_mae NOT weighted
+    np.testing.assert_allclose(m._engine("contrastive", B).total.cpu().numpy(), d["logits"], atol=0.25)
+    out[0].backward()
+    names, none, gsum, gl2, gsamp = golden_grads(d)
+    worst = 0.0
+    for i, n in enumerate(names):
+        g = m._params[n].grad
+        assert g is not None, n
+        g = g.double().reshape(-1).cpu()
+        rel = abs(float(g.norm()) - gl2[i]) / max(gl2[i], 1e-12)
+        assert rel <= 0.05, (n, float(g.norm()), gl2[i])
+        worst = max(worst, rel)
+    for n in none:
+        g = m._params[n].grad
+        assert g is None or float(g.abs().max()) == 0.0, n
+    record_margin("combined_golden", grad_l2_rel=worst)
+
+
+def test_combined_forward_matches_oracle():
+    """Same call against the oracle at configs[0]'s shape with full per-tensor gradient comparison (both passes live in ONE
+    backward: the shared range of the arena accumulates both)."""
+    import random
+    from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
+    from oracle import ref_cpu
+    from tests.test_parity_gpu import _compare_grads
+    cfg = AVSiamConfig(audio_tokens=128)
+    B, wm, wc = 5, 3.0, 0.01
+    a, v = synth_inputs(cfg, B, 31)
+    gen = torch.Generator().manual_seed(4)
+    plan = {"mae": make_mae_plan(cfg, B, gen), "contrastive": make_contrastive_plan(cfg, B, gen, random.Random(4))}
+    m = _model(cfg, 555)
+    out = m(a.cuda(), v.cuda(), mae_loss_weight=wm, contrast_loss_weight=wc, mask_plan=plan)
+    out[0].backward()
+    torch.set_num_threads(16)
+    P = {k: t.clone().requires_grad_(True) for k, t in synth_state(cfg, 555, "random", include_dead=False).items()}
+    ref = ref_cpu.forward(P, cfg, a, v, plan, mae_loss_weight=wm, contrast_loss_weight=wc)
+    ref[0].backward()
+    for i in (0, 1, 2, 3, 4):
+        assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+    worst = _compare_grads(m, {k: p.grad for k, p in P.items()})
+    record_margin("combined_oracle", worst_cos=worst[0], worst_tensor=worst[1])
+
+
+def _args(tmp, **kw):
+    d = dict(n_epochs=1, batch_size=4, lr=1e-3, lrscheduler_start=10, lrscheduler_step=5, lrscheduler_decay=0.5, n_print_steps=50,
+             exp_dir=str(tmp), save_model=False, rank=0, gpu=0, world_size=1, steps_per_epoch=3, masking_ratio=0.75, masking_ratio_a=0.75,
+             mask_mode="unstructured", mae_loss_weight=3.0, contrast_loss_weight=0.01)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_validate_uses_the_run_loss_weights_and_matches_oracle(tmp_path):
+    """validate(audio_model, val_loader, val_sampler, args) (reference signature, :381): the forward gets
+    args.mae_loss_weight / args.contrast_loss_weight (:401).  One batch: read the plans the device drew and feed the oracle."""
+    from avsiam_amd.traintest_cavmae_base import SyntheticAVLoader, validate
+    from oracle import ref_cpu
+    cfg = AVSiamConfig(audio_tokens=128)
+    B = 4
+    m = _model(cfg, 77, plan_seed=11)
+    val = SyntheticAVLoader(cfg, B, 1, "cuda", seed=5)
+    args = _args(tmp_path)
+    ev = validate(m, val, None, args)
+    assert len(ev) == 6 and all(np.isfinite(ev))
+    plans = m.last_plans(B)
+    torch.set_num_threads(16)
+    P = {k: t.clone() for k, t in synth_state(cfg, 77, "random", include_dead=False).items()}
+    with torch.no_grad():
+        ref = ref_cpu.forward(P, cfg, val.a.cpu(), val.v.cpu(), plans, mae_loss_weight=3.0, contrast_loss_weight=0.01)
+    want = [ref[i].item() for i in (0, 1, 2, 3, 4)]
+    for g, w in zip(ev[:5], want):
+        assert abs(g - w) <= LOSS_RTOL * abs(w) + 1e-6, (ev, want)
+    assert abs(ev[5] - ref[7].item()) <= 1.0 / B + 1e-6
+    # the contrastive term carries its weight (x 0.01), the MAE term does not carry 3.0 (:735,739)
+    args1 = _args(tmp_path, contrast_loss_weight=1.0)
+    m2 = _model(cfg, 77, plan_seed=11)
+    ev1 = validate(m2, val, None, args1)
+    assert abs(ev1[4] * 0.01 - ev[4]) <= 1e-5 * abs(ev[4]) + 1e-9 and abs(ev1[1] - ev[1]) <= 1e-6 * abs(ev[1])
+    # several batches: the mean over batches (:417-422)
+    m3 = _model(cfg, 77, plan_seed=11)
+    val3 = SyntheticAVLoader(cfg, B, 3, "cuda", seed=5)
+    ev3 = validate(m3, val3, None, args)
+    assert all(np.isfinite(ev3)) and abs(ev3[0] - ev[0]) < 0.2 * abs(ev[0])          # same data, other masks
+
+
+def test_train_loop_bookkeeping(tmp_path):
+    """train(): epoch means come from EVERY step even when no step of the epoch is a print step (device-side accumulation),
+    best_audio_model.pth / best_optim_state.pth are written when the evaluation loss improves (:221-230), the optimizer state
+    has torch.optim.Adam's format, and without a validation loader no 'best' model is invented."""
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.traintest_cavmae_base import SyntheticAVLoader, train
+    cfg = AVSiamConfig(audio_tokens=128)
+    m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=1)
+    args = _args(tmp_path, n_epochs=2, save_model=True, n_print_steps=50, steps_per_epoch=3)
+    val = SyntheticAVLoader(cfg, 4, 1, "cuda", seed=5)
+    train(m, None, [val, None], [None, None], None, args, None)
+    res = np.loadtxt(tmp_path / "result.csv", delimiter=",")
+    assert res.shape == (2, 10)
+    # epoch 2 (global steps 3..5) holds no print step (50): its train-loss columns must still be real means
+    assert (res[:, :4] > 0).all() and (res[:, 4:9] >= 0).all() and np.isfinite(res).all(), res
+    assert abs(res[1, 3] - (res[1, 0] + res[1, 1])) < 1e-4        # pass-2 total = MAE a + v (contrastive weight 0 in pass 2)
+    assert res[0, 9] == 1e-3
+    models = tmp_path / "models"
+    sd = torch.load(models / "best_audio_model.pth")
+    assert len(sd) == 963 and all(k.startswith("module.") for k in sd)
+    assert (models / "audio_model.1.pth").exists() and (models / "audio_model.2.pth").exists()
+    osd = torch.load(models / "best_optim_state.pth", weights_only=False)
+    params = list(m.parameters())
+    opt = torch.optim.Adam(params, 1e-3, weight_decay=5e-7, betas=(0.95, 0.999))
+    opt.load_state_dict(osd)                                       # torch's own format
+    live1 = sum(1 for n, p in m._params.items() if m.arena.info[n].live & P1)
+    assert len(osd["state"]) == live1
+    some = next(iter(osd["state"].values()))
+    assert float(some["step"]) >= 3 and some["exp_avg"].abs().sum() > 0
+    # round trip through the model's own loader
+    m.load_optimizer_state_dict(P1, osd)
+    assert m._opt_state[P1]["step"] == int(float(some["step"]))
+    # no validation loader: no best model
+    m2 = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=1)
+    d2 = tmp_path / "noval"
+    train(m2, None, [None, None], [None, None], None, _args(d2, steps_per_epoch=2), None)
+    assert not (d2 / "models" / "best_audio_model.pth").exists()
+    assert np.loadtxt(d2 / "result.csv", delimiter=",").reshape(1, 10)[0, 3] > 0
+
+
+def test_pretrained_vit_checkpoint_forward_matches_oracle():
+    """SURVEY 8(f) row 1 on the device: a timm-shaped checkpoint loaded the reference constructor's way
+    (tests/test_oracle_golden.py pins that derivation bit-exactly to the reference) runs through the HIP path and agrees with
+    the oracle on the same state - the bf16 shadows and transposed copies are rebuilt from the loaded masters."""
+    import random
+    from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
+    from avsiam_amd.weights import state_from_vit, synth_vit_checkpoint
+    from oracle import ref_cpu
+    cfg = AVSiamConfig(audio_tokens=128)
+    B = 4
+    ckpt = synth_vit_checkpoint(AVSiamConfig(), 4242)
+    ckpt = {k: v for k, v in ckpt.items()}
+    m = _model(cfg, 3, mode="init")
+    a, v = synth_inputs(cfg, B, 8)
+    gen = torch.Generator().manual_seed(2)
+    pm, pc = make_mae_plan(cfg, B, gen), make_contrastive_plan(cfg, B, gen, random.Random(2))
+    before = m(a.cuda(), v.cuda(), mae_loss_weight=1, contrast_loss_weight=0, mask_plan=pm)[0].item()
+    m.load_vit_pretrained(ckpt, seed=3)
+    st = state_from_vit(ckpt, cfg, seed=3)
+    assert torch.equal(m._params["ast_base.blocks.4.mlp.fc1.weight"].cpu(), ckpt["blocks.4.mlp.fc1.weight"])
+    torch.set_num_threads(16)
+    P = {k: t.clone().requires_grad_(True) for k, t in st.items()}
+    for mae, plan in ((True, pm), (False, pc)):
+        out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
+        ref = ref_cpu.forward(P, cfg, a, v, plan, mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1)
+        assert abs(out[0].item() - ref[0].item()) <= LOSS_RTOL * abs(ref[0].item()), (mae, out[0].item(), ref[0].item())
+        if mae:
+            assert abs(out[0].item() - before) > 1e-3              # the load changed the weights the kernels see
+
+
+def test_external_torch_optimizer_without_mark_weights_changed():
+    """The reference loop's recipe - optimizer.zero_grad(); loss.backward(); optimizer.step() with torch.optim.Adam on
+    model.parameters() (:64-66,137-139) - must see its own updates at the next forward WITHOUT any extra call: the bf16 weight
+    shadows are refreshed when a parameter's version counter moved."""
+    from oracle import ref_cpu
+    import random
+    from avsiam_amd.maskplan import make_mae_plan
+    cfg = AVSiamConfig(audio_tokens=128)
+    B = 4
+    m = _model(cfg, 9)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], 1e-3, weight_decay=5e-7, betas=(0.95, 0.999))
+    a, v = synth_inputs(cfg, B, 12)
+    plan = make_mae_plan(cfg, B, torch.Generator().manual_seed(6))
+    out = m(a.cuda(), v.cuda(), mae_loss_weight=1, contrast_loss_weight=0, mask_plan=plan)
+    l0 = out[0].item()
+    opt.zero_grad()
+    out[0].backward()
+    opt.step()
+    l1 = m(a.cuda(), v.cuda(), mae_loss_weight=1, contrast_loss_weight=0, mask_plan=plan)[0].item()
+    assert l1 < l0 - 1e-3, (l0, l1)                                # the step was seen by the kernels
+    torch.set_num_threads(16)
+    P = {k: p.detach().cpu().clone() for k, p in m._params.items() if m.arena.info[k].live}
+    with torch.no_grad():
+        ref = ref_cpu.forward(P, cfg, a, v, plan, mae_loss_weight=1, contrast_loss_weight=0)
+    assert abs(l1 - ref[0].item()) <= LOSS_RTOL * abs(ref[0].item()), (l1, ref[0].item())
+
+
+def test_entry_point_main_runs_two_steps(tmp_path, capsys):
+    """run_cavmae_pretrain_base.main(argv) with the reference's flags (synthetic data): trains, validates, writes the
+    reference's artefacts.  --raw-input routes un-normalised fbank / uint8 frames through the device-side normalisation."""
+    from avsiam_amd import run_cavmae_pretrain_base as entry
+    exp = tmp_path / "exp"
+    env_keep = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        model = entry.main(["--model", "cav-mae", "--dataset", "audioset", "--target_length", "256", "--batch-size", "4", "--lr", "2e-4",
+                            "--n-epochs", "1", "--steps-per-epoch", "2", "--n-print-steps", "1", "--exp-dir", str(exp), "--save_model", "True",
+                            "--data-val", "synthetic", "--val-steps", "1", "--mae_loss_weight", "3.0", "--contrast_loss_weight", "0.01",
+                            "--raw-input", "--noise", "True", "--norm_pix_loss", "True", "--tr_pos", "False", "--masking_ratio", "0.75"])
+    finally:
+        for k, val in env_keep.items():
+            if val is not None:
+                os.environ[k] = val
+    out = capsys.readouterr().out
+    assert "Not using distributed mode" in out and "Epoch: [1][0/2]" in out and "Eval Total Loss" in out and "training diverged" not in out
+    for f in ("args.json", "args.pkl", "result.csv", "progress.pkl", "models/audio_model.1.pth", "models/best_audio_model.pth",
+              "models/best_optim_state.pth"):
+        assert (exp / f).exists(), f
+    res = np.loadtxt(exp / "result.csv", delimiter=",").reshape(1, 10)
+    assert np.isfinite(res).all() and res[0, 3] > 0 and res[0, 7] > 0
+    assert model.cfg.audio_tokens == 128
+
+
+def test_torchrun_entry_forms_the_rccl_group_and_runs(tmp_path):
+    """The way the reference is launched (torchrun, one process per GPU): utils.init_distributed_mode reads RANK / WORLD_SIZE /
+    LOCAL_RANK, forms the "nccl" (= RCCL) process group - at world size 1 too, like the reference (utils.py:288) - and the
+    entry point trains.  A second child process then runs the data-parallel code path itself on a one-rank RCCL group: the
+    embedding all-gather and the chunked gradient all-reduce are ISSUED (comm.TorchDistComm(always=True)) and must leave
+    losses and gradients unchanged."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", "-m", "avsiam_amd.run_cavmae_pretrain_base", "--target_length", "256", "--batch-size", "4",
+           "--n-epochs", "1", "--steps-per-epoch", "2", "--n-print-steps", "1", "--exp-dir", str(tmp_path / "e1")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "| distributed init (rank 0): env://, gpu 0" in r.stdout and "Epoch: [1][1/2]" in r.stdout
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29579", os.path.join(ROOT, "tools", "rccl_selfcheck.py"), "--engine"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "engine path on rccl ok" in r.stdout, r.stdout[-1500:]

@@ -24,7 +24,7 @@ from tests.helpers import check_grads_against_golden, golden_plan, load_golden
 def _init(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(4)
+    torch.set_num_threads(max(1, 8 // world))
 
 
 def _golden_worker(rank, world, port, q):
@@ -83,9 +83,11 @@ def _dp_worker(rank, world, port, q):
         from avsiam_amd.param_spec import P1
         _init(rank, world, port)
         cfg = AVSiamConfig(**SMALL)
-        B = 3
+        B = 3                                              # per-GPU batch is fixed (weak scaling); the PLANS differ per rank
         model = CAVMAE_BASE(cfg=cfg, init_seed=11, init_mode="random", verbose=False)
-        model.set_distributed(world, rank)
+        from tests.helpers import HostStagedComm
+        comm = HostStagedComm()
+        model.set_distributed(world, rank, comm)
         arena = model.arena
         # every rank knows all inputs/plans so it can also evaluate the single-process global reference
         ins = [synth_inputs(cfg, B, 50 + r) for r in range(world)]
@@ -118,9 +120,11 @@ def _dp_worker(rank, world, port, q):
         for k, p in P.items():
             if p.grad is not None:
                 arena.gview(k).copy_(p.grad)
-        model.allreduce_grads(P1)                                           # c1: one all-reduce over the live range
+        # c1: the gradients were written into the arena by hand, so the reduction runs here: all-reduce(SUM) over the live
+        # range and, with average=True, DDP's mean (the fused training step keeps the 1/W for the Adam kernel instead)
+        model.allreduce_grads(P1, average=True, already_reduced=False)
         lo, hi = arena.range[P1]
-        g[lo:hi].mul_(1.0 / world)                                          # folded into adam_step's grad_scale on the GPU
+        assert sum(comm.messages) == hi - lo and model._grad_scale[P1] == 1.0
         for k, w in want.items():
             got = arena.gview(k)
             assert torch.allclose(got, w, rtol=2e-4, atol=1e-7), (k, float((got - w).abs().max()))
@@ -137,3 +141,64 @@ def _dp_worker(rank, world, port, q):
 
 def test_dp_scheme_equals_global_gradient_w2():
     _run(_dp_worker, port=29741)
+
+
+@pytest.mark.parametrize("world,port", [(4, 29745), (8, 29749)])
+def test_dp_scheme_equals_global_gradient_w4_w8(world, port):
+    """The same algebra at the world sizes the scaling bench runs (own-slice x W, SUM all-reduce over the live range, 1/W):
+    every rank draws its own mask plan, so the per-rank group structures differ."""
+    _run(_dp_worker, world=world, port=port)
+
+
+def _reducer_worker(rank, world, port, q):
+    """comm.GradReducer under a real backend: chunks declared in backward order, some never declared, must equal ONE
+    all-reduce of the whole range - and must leave everything outside [lo, hi) alone."""
+    try:
+        from avsiam_amd.comm import GradReducer, TorchDistComm
+        _init(rank, world, port)
+        comm = TorchDistComm()
+        n, lo, hi = 10_000, 100, 9_000
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        want = g.clone()
+        want[lo:hi] = torch.arange(n, dtype=torch.float32)[lo:hi] * sum(r + 1 for r in range(world))
+        red = GradReducer(comm, g, lo, hi, min_elems=1500, overlap=True)
+        for a, b in ((8000, 8500), (7000, 8000), (4000, 5000), (3000, 4000), (50, 300)):      # touching, out of order, clipped
+            red.ready(a, b)
+        red.finish()
+        assert torch.equal(g, want), float((g - want).abs().max())
+        assert 2 <= red.messages <= 8
+        g2 = torch.ones(n) * (rank + 1)
+        blocking = GradReducer(comm, g2, lo, hi, overlap=False)
+        blocking.ready(200, 300)
+        blocking.finish()
+        assert blocking.messages == 1 and float(g2[lo]) == sum(r + 1 for r in range(world)) and float(g2[0]) == rank + 1
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_grad_reducer_chunks_equal_one_allreduce_w2():
+    _run(_reducer_worker, port=29753)
+
+
+def test_grad_reducer_rejects_overlapping_ranges():
+    from avsiam_amd.comm import GradReducer
+
+    class Fake:
+        world, rank = 2, 0
+
+        def all_reduce_async(self, t):
+            class H:
+                def wait(self):
+                    pass
+            return H()
+
+    red = GradReducer(Fake(), torch.zeros(100), 0, 100, min_elems=1000, overlap=True)
+    red.ready(0, 50)
+    red.ready(40, 60)
+    with pytest.raises(AssertionError):
+        red.finish()

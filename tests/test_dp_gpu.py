@@ -1,5 +1,6 @@
-"""The data-parallel path on the REAL kernels: 2 processes share the single GPU of the test box (gloo for the two
-collectives - RCCL refuses two ranks on one device), each runs the contrastive pass of its own batch, and the results are
+"""The data-parallel path on the REAL kernels: 2 processes share the single GPU of the test box (the collectives are
+injected: tests.helpers.HostStagedComm = gloo through the host - RCCL refuses two ranks on one device), each runs the
+contrastive pass of its own batch, and the results are
 compared with what the unmodified reference produced with 2 gloo ranks (tests/golden/c_w2_b3_r{0,1}.npz): the global
 [6,6] logits, the loss, and every live tensor's LOCAL gradient (before the mean all-reduce) - i.e. the build's
 "own slice x W, no backward collective" must equal GatherLayer's all-reduce + slice (gather_layer.py:35-37).
@@ -30,27 +31,41 @@ def _worker(rank, world, port, q):
         B = int(d["batch"])
         a, v = synth_inputs(cfg, B, int(d["input_seed"]))
         m = CAVMAE_BASE(cfg=cfg, init_seed=int(d["weight_seed"]), init_mode="random", verbose=False).cuda()
-        m.set_distributed(world, rank)
+        from tests.helpers import HostStagedComm
+        comm = HostStagedComm()
+        m.set_distributed(world, rank, comm)
+        m.reduce_in_backward = False                    # first look at the LOCAL gradients, as the golden file holds them
         out = m(a.cuda(), v.cuda(), mae_loss_weight=0, contrast_loss_weight=1, mask_plan=golden_plan(d))
         out[0].backward()
         got = np.array([out[i].item() for i in (0, 4)])
         np.testing.assert_allclose(got, d["out_scalars"][[0, 4]], rtol=2e-2)
         eng = m._engine("contrastive", B)
         np.testing.assert_allclose(eng.total.cpu().numpy(), d["logits"], atol=0.25)
-        names, none, gsum, gl2, gsamp = golden_grads(d)
-        for i, n in enumerate(names):
-            g = m._params[n].grad
-            assert g is not None, n
-            l2 = float(g.double().norm())
-            assert abs(l2 - gl2[i]) <= 0.08 * gl2[i] + 1e-7, (n, l2, gl2[i])
+        from tests.helpers import gpu_grads_vs_golden
+        gpu_grads_vs_golden(d, lambda n: m._params[n].grad, f"golden_c_w2_b3_r{rank}", l2_rel=0.08, samp_rel=1.0, sum_rel=1.0)
         # c1: one all-reduce over the live range, then 1/W -> both ranks hold the same mean gradient
-        m.allreduce_grads(P1)
+        m.allreduce_grads(P1, average=True)
         lo, hi = m.arena.range[P1]
-        mean = (m.arena.g[lo:hi] / world).cpu()
+        assert comm.messages == [hi - lo]
+        mean = m.arena.g[lo:hi].cpu()
         other = [torch.empty_like(mean) for _ in range(world)]
         dist.all_gather(other, mean)
         assert torch.equal(other[0], other[1])
         assert float(mean.abs().sum()) > 0
+        # the default path: loss.backward() reduces by itself, in chunks declared by the backward schedule (comm.GradReducer),
+        # and .grad then holds DDP's mean - equal to the one-message result above up to the order of the fp32 atomics
+        m.reduce_in_backward = True
+        comm.messages.clear()
+        out = m(a.cuda(), v.cuda(), mae_loss_weight=0, contrast_loss_weight=1, mask_plan=golden_plan(d))
+        out[0].backward()
+        assert len(comm.messages) >= 2 and sum(comm.messages) == hi - lo, comm.messages
+        again = m.arena.g[lo:hi].cpu()
+        cos = float(torch.dot(again.double(), mean.double()) / (again.double().norm() * mean.double().norm()))
+        assert cos > 0.99999 and abs(float(again.norm() / mean.norm()) - 1) < 1e-4, cos
+        g0 = m._params["vit_base.blocks.3.mlp.fc1.weight"].grad
+        assert g0.data_ptr() == m.arena.gview("vit_base.blocks.3.mlp.fc1.weight").data_ptr()
+        m.allreduce_grads(P1)                            # nothing left to do: no further message
+        assert sum(comm.messages) == hi - lo
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback

@@ -47,6 +47,58 @@ def test_oracle_matches_reference(name):
     check_grads_against_golden(d, grads, rel_l2=1e-4)
 
 
+def test_oracle_matches_reference_combined_forward():
+    """The call validate() makes (traintest_cavmae_base.py:401): both branches in one forward at the run's loss weights
+    (mae 3.0 / contrastive 0.01).  The MAE branch only switches on its weight (:694,739); the contrastive loss is scaled (:735)."""
+    torch.set_num_threads(8)
+    d = load_golden("mc_w1_b4")
+    cfg = AVSiamConfig()
+    B = int(d["batch"])
+    a, v = synth_inputs(cfg, B, int(d["input_seed"]))
+    P = {k: t.clone().requires_grad_(True) for k, t in synth_state(cfg, int(d["weight_seed"]), "random").items()}
+    plan = golden_plan(d)
+    assert set(plan) == {"mae", "contrastive"}
+    wm, wc = (float(x) for x in d["loss_weights"])
+    extras = {}
+    out = ref_cpu.forward(P, cfg, a, v, plan, mae_loss_weight=wm, contrast_loss_weight=wc, extras=extras)
+    out[0].backward()
+    got = np.array([out[i].item() for i in (0, 1, 2, 3, 4, 7)])
+    np.testing.assert_allclose(got, d["out_scalars"], rtol=1e-5, atol=1e-6)
+    assert out[5] is None and out[6] is None                                   # :722 - the mixed encoder's None masks win
+    np.testing.assert_allclose(extras["logits"].detach().numpy(), d["logits"], rtol=1e-4, atol=2e-4)
+    for k in ("pred_a", "pred_v"):
+        p = extras[k].detach().double().reshape(-1)
+        assert abs(p.norm().item() - d[k + "_l2"]) <= 1e-5 * d[k + "_l2"]
+    check_grads_against_golden(d, {k: p.grad for k, p in P.items()}, rel_l2=1e-4)
+
+
+def test_pretrained_init_matches_reference_constructor(golden_dir):
+    """SURVEY 8(f) row 1, pinned to the reference: oracle/gen_golden.py ran the reference CONSTRUCTOR
+    (/root/reference/src/models/cav_mae_base.py:236-307) with its checkpoint load answered by
+    weights.synth_vit_checkpoint(cfg, seed) and stored a CRC-32 of every tensor it derived.  weights.state_from_vit on the
+    same checkpoint must reproduce all of them BIT-exactly (copies, the RGB-mean audio kernel, the nearest-interpolated
+    position table, the deep-copied towers and joint layers, the zero decoder tokens)."""
+    import json
+    import os
+    import zlib
+    from avsiam_amd.param_spec import alias_of
+    from avsiam_amd.weights import state_from_vit, synth_vit_checkpoint
+    with open(os.path.join(golden_dir, "pretrained_init.json")) as f:
+        g = json.load(f)
+    cfg = AVSiamConfig()
+    ckpt = synth_vit_checkpoint(cfg, g["vit_seed"])
+    assert len(ckpt) == g["n_checkpoint_keys"] == 152
+    st = state_from_vit(ckpt, cfg, seed=0)
+    assert len(g["tensors"]) >= 790
+    bad = []
+    for k, rec in g["tensors"].items():
+        t = st[alias_of(k)].contiguous()
+        assert list(t.shape) == rec["shape"], k
+        if zlib.crc32(t.numpy().tobytes()) != rec["crc32"]:
+            bad.append((k, float(t.double().sum()), rec["sum"]))
+    assert not bad, bad[:5]
+
+
 def test_schema_matches_reference(golden_dir):
     import json
     import os

@@ -64,12 +64,13 @@ def test_train_loop_and_validate(tmp_path):
     cfg = AVSiamConfig(audio_tokens=128)
     m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=1)
     args = argparse.Namespace(n_epochs=1, batch_size=4, lr=1e-3, lrscheduler_start=10, lrscheduler_step=5, lrscheduler_decay=0.5,
-                              n_print_steps=1, exp_dir=str(tmp_path), save_model=True, rank=0, gpu=0, world_size=1, steps_per_epoch=6)
+                              n_print_steps=1, exp_dir=str(tmp_path), save_model=True, rank=0, gpu=0, world_size=1, steps_per_epoch=6,
+                              masking_ratio=0.75, masking_ratio_a=0.75, mask_mode="unstructured", mae_loss_weight=3.0, contrast_loss_weight=0.01)
     val = SyntheticAVLoader(cfg, 4, 1, "cuda", seed=5)
     train(m, None, [val, None], [None, None], None, args, None)
     sd = torch.load(tmp_path / "models" / "audio_model.1.pth")
     assert len(sd) == 963 and all(k.startswith("module.") for k in sd)
-    ev = validate(m, val)
+    ev = validate(m, val, None, args)
     assert all(map(lambda x: x == x, ev)) and ev[0] > 0            # finite losses
     # the saved checkpoint loads back through the reference's consumer path (strip 'module.')
     m2 = CAVMAE_BASE(cfg=cfg, verbose=False)

@@ -7,9 +7,12 @@ fp32 range, all_reduce(MAX) of the fp64 timing scalar, barrier).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/rccl_selfcheck.py
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
@@ -31,7 +34,45 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     print(f"rank {rank}/{world}: rccl collectives ok (backend {dist.get_backend()})", flush=True)
+    if "--engine" in sys.argv:
+        engine_path(rank, world, dev)
     dist.destroy_process_group()
+
+
+def engine_path(rank, world, dev):
+    """The data-parallel code path of the model itself on this process group: with comm.TorchDistComm(always=True) the embedding
+    all-gather (engine.ContrastivePass.forward) and the chunked asynchronous gradient all-reduce (comm.GradReducer, issued from
+    engine.Stack.backward) run on RCCL even at world size 1, where they must change nothing."""
+    import random
+    from avsiam_amd.comm import TorchDistComm
+    from avsiam_amd.config import AVSiamConfig
+    from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.param_spec import P1, P2
+    from avsiam_amd.weights import synth_inputs
+    cfg = AVSiamConfig(audio_tokens=128)
+    B = 4
+    a, v = synth_inputs(cfg, B, 87 + rank)
+    a, v = a.to(dev), v.to(dev)
+    gen = torch.Generator().manual_seed(1)
+    pm, pc = make_mae_plan(cfg, B, gen), make_contrastive_plan(cfg, B, gen, random.Random(1))
+    res = []
+    for use_rccl in (False, True):
+        m = CAVMAE_BASE(cfg=cfg, init_seed=5, init_mode="random", verbose=False).to(dev)
+        m.set_distributed(world, rank, TorchDistComm(always=True) if use_rccl else None)
+        m.publish_grads = False
+        outs = []
+        for mae, plan, which in ((False, pc, P1), (True, pm, P2)):
+            out = m(a, v, mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
+            out[0].backward()
+            lo, hi = m.arena.range[which]
+            outs.append((out[0].item(), m.arena.g[lo:hi].double().norm().item(), m.last_reduce_messages))
+        res.append(outs)
+    torch.cuda.synchronize()
+    for (l0, g0, _), (l1, g1, msgs) in zip(*res):
+        assert l0 == l1 and abs(g0 - g1) <= 1e-5 * g0, (l0, l1, g0, g1)
+        assert world > 1 or msgs >= 2, msgs                 # the chunked reducer really issued several all-reduces
+    print(f"rank {rank}/{world}: engine path on rccl ok (messages per pass: {[r[2] for r in res[1]]})", flush=True)
 
 
 if __name__ == "__main__":
