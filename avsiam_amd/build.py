@@ -28,6 +28,9 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    extra = os.environ.get("AVSIAM_HIPCC_EXTRA", "").split()       # diagnostic builds (tools/ab_lib.sh); forces a rebuild
+    if extra:
+        force = True
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -37,7 +40,7 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

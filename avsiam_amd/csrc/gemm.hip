@@ -35,7 +35,7 @@ struct GemmNtArgs {
     const bf16_t* aux; long long ldaux;
     void* out; long long ldo; int out_f32;
     bf16_t* out2; long long ldo2;
-    float alpha; int act;                    // 0 none | 1 gelu (out = pre-activation, out2 = gelu) | 2 gelu-backward (aux = pre-activation)
+    float alpha; int act;                    // 0 none | 1 gelu (out = gelu'(x), out2 = gelu(x), x = the pre-activation) | 2 gelu-backward (aux = gelu'(x))
     int scale_cols; float col_scale;         // columns [0, scale_cols) are multiplied by col_scale as well (scale_cols % 64 == 0)
     float* colsum;                           // bf16 output only: colsum[n] += sum_m out[m][n] (bias gradient of the layer that produced A)
     int m_full;                              // rows [0, m_full) in full tiles, [m_full, M) in half-height tiles (m_full == M: none)
@@ -55,14 +55,25 @@ struct GemmNtArgs {
 // Residual reads (fp32) and the GELU' operand read (bf16) use the same ownership, i.e. are 16 B per lane as well.
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
+// Diagnostic builds (tools/ab_lib.sh with AVSIAM_HIPCC_EXTRA=-DNT8_ABLATE=n; never defined in the product build):
+//   1  the epilogue computes everything but issues no global store      2  no epilogue at all (accumulators kept alive)
+#ifndef NT8_ABLATE
+#define NT8_ABLATE 0
+#endif
+#if NT8_ABLATE == 1
+#define NT_STORE(ptr, val) asm volatile("" ::"v"(val))
+#else
+#define NT_STORE(ptr, val) *(ptr) = (val)
+#endif
+
 __device__ __forceinline__ void epi_apply4(float alpha, int ACT, float (&v)[4], const float4& bias4, uint2 p,
                                            bool has_res, f32x4 r) {
     v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
-    if (ACT == 2) {
-        v[0] *= gelu_erf_grad(__uint_as_float(p.x << 16));
-        v[1] *= gelu_erf_grad(__uint_as_float(p.x & 0xffff0000u));
-        v[2] *= gelu_erf_grad(__uint_as_float(p.y << 16));
-        v[3] *= gelu_erf_grad(__uint_as_float(p.y & 0xffff0000u));
+    if (ACT == 2) {                           // p = gelu'(pre-activation), evaluated once by the forward epilogue (ACT 1)
+        v[0] *= __uint_as_float(p.x << 16);
+        v[1] *= __uint_as_float(p.x & 0xffff0000u);
+        v[2] *= __uint_as_float(p.y << 16);
+        v[3] *= __uint_as_float(p.y & 0xffff0000u);
     }
     if (has_res) { v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
     v[0] *= alpha; v[1] *= alpha; v[2] *= alpha; v[3] *= alpha;
@@ -191,7 +202,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     float v[4] = {t.x, t.y, t.z, t.w};
                     const float4 bias4 = *reinterpret_cast<const float4*>(sbias + cc);
                     epi_apply4(alpha, 0, v, bias4, make_uint2(0, 0), a.res != nullptr, pf.rs[g & 1][mj][i]);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
+                    NT_STORE(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n), (f32x4{v[0], v[1], v[2], v[3]}));
                 }
             }
         }
@@ -233,14 +244,22 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                         for (int j = 0; j < 4; ++j) { cs[j] += v0[j]; cs[4 + j] += v1[j]; }
                     }
                     uint4 o;
-                    o.x = pack_bf2(v0[0], v0[1]); o.y = pack_bf2(v0[2], v0[3]);
-                    o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n) = u32x4{o.x, o.y, o.z, o.w};
+                    if (ACT == 1) {
+                        // forward of fc1: `out` receives gelu'(x) instead of x.  The pre-activation itself is needed by nothing but
+                        // the fc2 input-gradient epilogue (ACT 2), and only through gelu'; evaluated here it shares phi's exponential
+                        // with gelu (4 VALU ops more per element) and saves that epilogue 12 of its 14.
+                        o.x = pack_bf2(gelu_erf_grad(v0[0]), gelu_erf_grad(v0[1])); o.y = pack_bf2(gelu_erf_grad(v0[2]), gelu_erf_grad(v0[3]));
+                        o.z = pack_bf2(gelu_erf_grad(v1[0]), gelu_erf_grad(v1[1])); o.w = pack_bf2(gelu_erf_grad(v1[2]), gelu_erf_grad(v1[3]));
+                    } else {
+                        o.x = pack_bf2(v0[0], v0[1]); o.y = pack_bf2(v0[2], v0[3]);
+                        o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
+                    }
+                    NT_STORE(reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n), (u32x4{o.x, o.y, o.z, o.w}));
                     if (ACT == 1) {
                         uint4 gq;
                         gq.x = pack_bf2(gelu_erf(v0[0]), gelu_erf(v0[1])); gq.y = pack_bf2(gelu_erf(v0[2]), gelu_erf(v0[3]));
                         gq.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); gq.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
-                        *reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n) = u32x4{gq.x, gq.y, gq.z, gq.w};
+                        NT_STORE(reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n), (u32x4{gq.x, gq.y, gq.z, gq.w}));
                     }
                 }
             }
@@ -569,7 +588,14 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
             set_tile(vnext);
             dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
         }
+#if NT8_ABLATE == 2
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
         nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
+#endif
         // a compiler-visible full drain: the K loop reuses registers the epilogue loaded into, and hipcc would otherwise
         // re-wait for those loads (vmcnt(0)) at the head of EVERY K-tile.  The next tile's first wait drains the stores anyway.
         wait_vm<0>();
@@ -868,7 +894,7 @@ extern "C" int avs_gemm_set_persistent(int on) {
 static long long g_nt_dispatches = 0;      // kernel dispatches issued by avs_gemm_nt_bf16 so far (a call is one or two)
 extern "C" long long avs_gemm_nt_dispatches(void) { return g_nt_dispatches; }
 
-static int g_nt8 = -1;                     // 1: 256^2 GEMMs run the 8-phase kernel (AVSIAM_GEMM_NT8 / avs_gemm_set_nt8)
+static int g_nt8 = -1;                     // 1: 256^2 GEMMs run the 8-phase kernels (AVSIAM_GEMM_NT8 / avs_gemm_set_nt8)
 extern "C" int avs_gemm_set_nt8(int on) {
     g_nt8 = on ? 1 : 0;
     return 0;
@@ -941,11 +967,13 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
             if (rows_full >= 1 && rows_full < nt_m && (big_tiles % ncu) * 2 <= ncu) b.m_full = rows_full * 256;
         }
         if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
-        if (g_nt8 == 1 && K >= 128 && g_persistent && g_force_tile == 0) {
+        if (g_nt8 >= 1 && K >= 128 && g_persistent && g_force_tile == 0) {
             // 8-phase kernel, every tile a full 256x256 tile: a partial last round costs it the same as handing the leftover rows
             // to the half-height-tile kernel in a second dispatch (measured: 185.7 vs 186.0 ms/step), so it keeps one dispatch
             const int tiles8 = nt_m * nt_n;
-            const int grid8 = tiles8 < ncu ? tiles8 : ncu;
+            int grid8 = tiles8 < ncu ? tiles8 : ncu;
+            // AVSIAM_NT_GRID: cap the persistent grid (tools/bench_stagger.py: two half-chip GEMMs side by side on two streams)
+            { static int gcap = -1; if (gcap < 0) { const char* e = getenv("AVSIAM_NT_GRID"); gcap = e ? atoi(e) : 0; } if (gcap > 0 && gcap < grid8) grid8 = gcap; }
             if (act == 0) gemm_nt8_kernel<0><<<grid8, 512, 131072, stream>>>(a);
             else if (act == 1) gemm_nt8_kernel<1><<<grid8, 512, 131072, stream>>>(a);
             else gemm_nt8_kernel<2><<<grid8, 512, 131072, stream>>>(a);
@@ -1008,7 +1036,7 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     // ... and enough output tiles that the splits (each adds a full-tile atomic epilogue) stay few
     // (8-phase kernel: from 12 tiles - the decoder's 1536x512 / 2048x512 gradients gain 14-18 % on it; 9 tiles and fewer lose)
     if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
-    const int min_tiles = g_nt8 == 1 ? 12 : 24;
+    const int min_tiles = g_nt8 >= 1 ? 12 : 24;
     const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256 && (N1 / 256) * (N2 / 256) >= min_tiles);
     const int T = big ? 256 : 128;
     const int tiles = (N1 / T) * (N2 / T);
@@ -1029,7 +1057,7 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     const int per = ceil_div(nstages, splits);
     splits = ceil_div(nstages, per);
     GemmTnArgs a{A, lda, B, ldb, C, ldc, M, N1, N2, per};
-    if (big && g_nt8 == 1) gemm_tn8_kernel<0><<<tiles * splits, 512, 131072, stream>>>(a);
+    if (big && g_nt8 >= 1) gemm_tn8_kernel<0><<<tiles * splits, 512, 131072, stream>>>(a);
     else if (big) gemm_tn_kernel<4, 4><<<tiles * splits, 512, 131072, stream>>>(a);
     else gemm_tn_kernel<2, 2><<<tiles * splits, 256, 65536, stream>>>(a);
     AVS_LAUNCH_CHECK("gemm_tn");

@@ -8,6 +8,7 @@
 // fp32 in (residual stream), bf16 out (GEMM operand), fp32 statistics - the reference's autocast keeps
 // LayerNorm in fp32 as well.
 #include "common.h"
+#include <stdlib.h>
 
 template <int NV, bool F32IO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g0,
@@ -68,12 +69,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Backward.  dx = dres + rstd * (gy - mean(gy) - xhat * mean(gy * xhat)),  gy = dy * gamma.
 // Parameter gradients: each block reduces its rows into a private slab ws[block][set][{dgamma,dbeta}][D]
 // (plain stores, deterministic); ln_bwd_reduce_kernel sums the slabs into the gradient arena.
-constexpr int LN_ROWS_PER_WAVE = 16;
-constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
+constexpr int LN_MIN_ROWS_PER_WAVE = 4;      // the workspace is sized for this (most blocks)
 constexpr int LN_SETS = 5;                   // dgamma0, dbeta0, dgamma1, dbeta1, column-sum of dx
 constexpr int LN_REDUCE_CHUNKS = 64;
 
-template <int NV, bool F32IO, bool HAS_RES>
+template <int NV, bool F32IO, bool HAS_RES, int LN_ROWS_PER_WAVE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ g0, const float* __restrict__ g1,
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* dres, float* dx, bf16_t* __restrict__ dx_bf16,
                                                      float* __restrict__ ws, int rows) {
     constexpr int D = NV * 256;
+    constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
     __shared__ float red[4][D];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -188,7 +189,9 @@ __global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, 
     atomicAdd(dst + c, s);
 }
 
-extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, LN_ROWS_PER_BLOCK) * LN_SETS * D; }
+extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, 4 * LN_MIN_ROWS_PER_WAVE) * LN_SETS * D; }
+
+static int g_ln_rpw = -1;                   // rows per wave of the backward kernel: 0 automatic; 4 / 8 / 16 forced (AVSIAM_LN_RPW, tuning)
 
 extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
                                  const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
@@ -218,12 +221,21 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
                                  float* db1, float* dcol, float* ws, int rows, int D, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(dy && x && mean && rstd && g0 && dx && ws, "layernorm_bwd: null pointer");
-    const int nblocks = ceil_div(rows, LN_ROWS_PER_BLOCK);
+    if (g_ln_rpw < 0) { const char* e = getenv("AVSIAM_LN_RPW"); g_ln_rpw = e ? atoi(e) : 0; }
+    // A block of 4 waves x RPW rows writes one slab of parameter-gradient partial sums; fewer rows per wave = more blocks
+    // (helps only when 16 rows leave most CUs with a single block) and more slab traffic.
+    int rpw = g_ln_rpw;
+    if (rpw != 4 && rpw != 8 && rpw != 16) rpw = rows >= 16384 ? 16 : 8;        // measured (tools/bench_ln.py): 8 wins only on the 8192-row audio tower
+    const int nblocks = ceil_div(rows, 4 * rpw);
     dim3 grid(nblocks), block(256);
+#define LN_BWD_R(NV, F, R)                                                                                                                     \
+    do {                                                                                                                                       \
+        if (dres) ln_bwd_kernel<NV, F, true, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);   \
+        else ln_bwd_kernel<NV, F, false, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);       \
+    } while (0)
 #define LN_BWD(NV, F)                                                                                                                          \
     do {                                                                                                                                       \
-        if (dres) ln_bwd_kernel<NV, F, true><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);   \
-        else ln_bwd_kernel<NV, F, false><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);       \
+        if (rpw == 16) LN_BWD_R(NV, F, 16); else if (rpw == 8) LN_BWD_R(NV, F, 8); else LN_BWD_R(NV, F, 4);                                       \
     } while (0)
     if (dy_f32) {
         if (D == 512) LN_BWD(2, true); else if (D == 768) LN_BWD(3, true); else LN_BWD(4, true);
@@ -231,6 +243,7 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
         if (D == 512) LN_BWD(2, false); else if (D == 768) LN_BWD(3, false); else LN_BWD(4, false);
     }
 #undef LN_BWD
+#undef LN_BWD_R
     AVS_LAUNCH_CHECK("layernorm_bwd");
     const int chunks = nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;
     ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), LN_SETS, chunks), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1, dcol);

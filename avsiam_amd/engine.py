@@ -190,7 +190,7 @@ class Stack:
         self.ln2 = self.ln1 if inference else per_block((rp, D), BF16)
         self.qkv = per_block((rp, 3 * D), BF16)
         self.att = per_block((rp, D), BF16)
-        self.fc1 = per_block((rp, hidden), BF16)
+        self.fc1 = per_block((rp, hidden), BF16)          # gelu'(fc1 output): all the backward needs of the pre-activation (gemm act 1 / 2)
         self.act = per_block((rp, hidden), BF16)
         self.lse = per_block((H, rp), F32)
         st = [_z((rp,), F32, dev) for _ in range(4)] if inference else None

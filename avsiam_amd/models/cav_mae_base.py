@@ -91,6 +91,9 @@ class _HotPath(torch.autograd.Function):
             live |= P2
         if ctx.has_c and g_c is not None:
             live |= P1
+        for w in (P1, P2):
+            if live & w:
+                model._reduced[w] = False                              # fresh local gradients
         if live & P1:
             arena.zero_grad_range(P1)
         if live & P2:
@@ -117,6 +120,7 @@ class _HotPath(torch.autograd.Function):
             for w in (P1, P2):
                 if live & w:
                     model._grad_scale[w] = 1.0 / model._world          # the SUM is in the arena; DDP's mean is still owed
+                    model._reduced[w] = True
             if model.publish_grads:                                    # an external optimizer reads .grad: deliver the mean now
                 for w in (P1, P2):
                     if live & w:
@@ -154,6 +158,7 @@ class CAVMAE_BASE(nn.Module):
         self._world, self._rank = 1, 0
         self._comm, self._dp = None, False
         self.reduce_in_backward = True             # data parallel: loss.backward() all-reduces, like DDP (False: call allreduce_grads)
+        self._reduced = {P1: False, P2: False}     # this pass's gradients in the arena are already summed over the ranks
         self._grad_scale = {P1: 1.0, P2: 1.0}      # factor the arena's gradients still owe (1/W after a SUM all-reduce)
         self._versions = None
         self.last_reduce_messages = 0
@@ -349,11 +354,12 @@ class CAVMAE_BASE(nn.Module):
         if not self._dp:
             return
         if already_reduced is None:
-            already_reduced = self._grad_scale[which] != 1.0
+            already_reduced = self._reduced[which]
         if not already_reduced:
             r = self._make_reducer(*self.arena.range[which], overlap=False)
             r.finish()
             self._grad_scale[which] = 1.0 / self._world
+            self._reduced[which] = True
         if average:
             self._average(which)
 

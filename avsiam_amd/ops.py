@@ -126,7 +126,8 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
 # ---------------------------------------------------------------------------------------------------
 def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None, alpha=1.0, act=0, scale_cols=0, col_scale=1.0, colsum=None,
             dual=None):
-    """out[M,N] = alpha * (A[M,K] @ B[N,K]^T + bias [* gelu'(aux)] + res[res_idx]); columns [0, scale_cols) also * col_scale;
+    """x[M,N] = alpha * (A[M,K] @ B[N,K]^T + bias [* aux] + res[res_idx]); columns [0, scale_cols) also * col_scale.
+    act 0: out = x.  act 1 (fc1 + GELU): out = gelu'(x), out2 = gelu(x).  act 2 (fc2 input gradient): aux = the gelu'(x) act 1 saved.
     colsum[n] += sum_m out[m, n] (bf16 output only).
     dual = (m_split, B2, bias2, colsum2): rows [m_split, M) use the second weight set (one launch for two towers)."""
     _chk(A, BF16, "gemm.A", 2); _chk(B, BF16, "gemm.B", 2); _chk(bias, F32, "gemm.bias"); _chk(res, F32, "gemm.res", 2)

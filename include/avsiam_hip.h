@@ -43,8 +43,9 @@ int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* m
                       int D, avs_stream_t stream);
 
 /* ---- bf16 MFMA GEMMs (nn.Linear / PatchEmbed.proj and their backward: cav_mae_base.py:51,55,60,77,96-99,138-143,
- * 600,634-635).  nt: out = alpha*(A[M,K].B[N,K]^T + bias [*gelu'(aux)] + res[res_idx? res_idx[m] : m]); act 0 none,
- * 1 gelu (out = pre-activation, out2 = gelu(out) bf16), 2 gelu-backward (aux = saved pre-activation).  N%128==0, K%64==0.
+ * 600,634-635).  nt: x = alpha*(A[M,K].B[N,K]^T + bias [*aux] + res[res_idx? res_idx[m] : m]); act 0: out = x;
+ * act 1 (timm Mlp fc1 + GELU forward): out = gelu'(x) bf16 - what the backward needs of the pre-activation - and
+ * out2 = gelu(x) bf16; act 2 (fc2 input gradient): aux = the saved gelu'(x), out = x.  N%128==0, K%64==0.
  * Columns [0, scale_cols) (a multiple of 64, 0 = none) are multiplied by col_scale in addition: the qkv projection
  * uses it to hand the attention kernels q already multiplied by hd^-0.5 * log2(e), rounded to bf16 once.
  * colsum (bf16 output only, may be NULL): colsum[n] += sum over rows of the output - the bias gradient of the layer

@@ -14,7 +14,7 @@ import torch
 from avsiam_amd.config import AVSiamConfig
 from avsiam_amd.param_spec import P1, P2
 from avsiam_amd.weights import synth_inputs, synth_state
-from tests.helpers import ROOT, golden_grads, golden_plan, load_golden, record_margin, sample_positions
+from tests.helpers import ROOT, golden_plan, gpu_grads_vs_golden, load_golden, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -47,21 +47,9 @@ def test_combined_forward_matches_reference_golden():
     record_margin("combined_golden", loss_rel=float(np.max(np.abs(got[:5] - d["out_scalars"][:5]) / np.abs(d["out_scalars"][:5]))))
     assert out[5] is None and out[6] is None                     # the mixed encoder's None masks win (cav_mae_base.py:722)
     assert abs(got[0] - (got[1] + got[4])) < 1e-6                # loss = loss_c + loss_mae (:739), loss_mae NOT weighted
-    np.testing.assert_allclose(m._engine("contrastive", B).total.cpu().numpy(), d["logits"], atol=0.25)
+    np.testing.assert_allclose(m._engine("contrastive", B).total.cpu().numpy(), d["logits"], atol=0.01)
     out[0].backward()
-    names, none, gsum, gl2, gsamp = golden_grads(d)
-    worst = 0.0
-    for i, n in enumerate(names):
-        g = m._params[n].grad
-        assert g is not None, n
-        g = g.double().reshape(-1).cpu()
-        rel = abs(float(g.norm()) - gl2[i]) / max(gl2[i], 1e-12)
-        assert rel <= 0.05, (n, float(g.norm()), gl2[i])
-        worst = max(worst, rel)
-    for n in none:
-        g = m._params[n].grad
-        assert g is None or float(g.abs().max()) == 0.0, n
-    record_margin("combined_golden", grad_l2_rel=worst)
+    gpu_grads_vs_golden(d, lambda n: m._params[n].grad, "combined_golden", l2_rel=0.01, samp_rel=0.3, sum_rel=2.0)
 
 
 def test_combined_forward_matches_oracle():
@@ -85,8 +73,7 @@ def test_combined_forward_matches_oracle():
     ref[0].backward()
     for i in (0, 1, 2, 3, 4):
         assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
-    worst = _compare_grads(m, {k: p.grad for k, p in P.items()})
-    record_margin("combined_oracle", worst_cos=worst[0], worst_tensor=worst[1])
+    _compare_grads(m, {k: p.grad for k, p in P.items()}, tag="combined_oracle")
 
 
 def _args(tmp, **kw):
@@ -219,7 +206,7 @@ def test_external_torch_optimizer_without_mark_weights_changed():
     out[0].backward()
     opt.step()
     l1 = m(a.cuda(), v.cuda(), mae_loss_weight=1, contrast_loss_weight=0, mask_plan=plan)[0].item()
-    assert l1 < l0 - 1e-3, (l0, l1)                                # the step was seen by the kernels
+    assert abs(l1 - l0) > 1e-3, (l0, l1)                           # the step was seen by the kernels (the oracle check below says: correctly)
     torch.set_num_threads(16)
     P = {k: p.detach().cpu().clone() for k, p in m._params.items() if m.arena.info[k].live}
     with torch.no_grad():

@@ -38,11 +38,11 @@ def _worker(rank, world, port, q):
         out = m(a.cuda(), v.cuda(), mae_loss_weight=0, contrast_loss_weight=1, mask_plan=golden_plan(d))
         out[0].backward()
         got = np.array([out[i].item() for i in (0, 4)])
-        np.testing.assert_allclose(got, d["out_scalars"][[0, 4]], rtol=2e-2)
+        np.testing.assert_allclose(got, d["out_scalars"][[0, 4]], rtol=2e-3)
         eng = m._engine("contrastive", B)
-        np.testing.assert_allclose(eng.total.cpu().numpy(), d["logits"], atol=0.25)
+        np.testing.assert_allclose(eng.total.cpu().numpy(), d["logits"], atol=0.01)
         from tests.helpers import gpu_grads_vs_golden
-        gpu_grads_vs_golden(d, lambda n: m._params[n].grad, f"golden_c_w2_b3_r{rank}", l2_rel=0.08, samp_rel=1.0, sum_rel=1.0)
+        gpu_grads_vs_golden(d, lambda n: m._params[n].grad, f"golden_c_w2_b3_r{rank}", l2_rel=0.01, samp_rel=0.3, sum_rel=0.25)
         # c1: one all-reduce over the live range, then 1/W -> both ranks hold the same mean gradient
         m.allreduce_grads(P1, average=True)
         lo, hi = m.arena.range[P1]

@@ -113,27 +113,30 @@ def test_gemm_nt_epilogues(M, N, K):
     assert rel_err(outf, want) < 1e-5
     o.gemm_nt(A, W, out, M, bias=bias, scale_cols=sc, col_scale=0.25)
     assert rel_err(out, want) < 4e-3
-    # gelu dual output
-    pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    # gelu forward epilogue: out = gelu'(x) (what the backward needs of the pre-activation), out2 = gelu(x)
+    dact = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
     act = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
-    o.gemm_nt(A, W, pre, M, bias=bias, out2=act, act=1)
-    assert rel_err(pre, ref + bias.double()) < 4e-3
-    assert rel_err(act, F.gelu(ref + bias.double())) < 5e-3
-    # gelu backward epilogue
+    o.gemm_nt(A, W, dact, M, bias=bias, out2=act, act=1)
+    p = (ref + bias.double()).requires_grad_(True)
+    F.gelu(p).sum().backward()
+    assert rel_err(dact, p.grad) < 4e-3
+    assert float((dact.double() - p.grad).abs().max()) < 8e-3     # gelu' in [-0.13, 1.13]: bf16 rounding + the 5e-5 fit error
+    assert rel_err(act, F.gelu(p.detach())) < 5e-3
+    # gelu backward epilogue: out = (A W^T) * aux with aux = the saved gelu'(x)
     dpre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
     csum = torch.ones(N, device=DEV)
-    o.gemm_nt(A, W, dpre, M, aux=pre, act=2, colsum=csum)
-    p = pre.double().requires_grad_(True)
-    F.gelu(p).backward(ref)
-    assert rel_err(dpre, p.grad) < 5e-3
-    assert rel_err(csum, 1 + p.grad.sum(0)) < 2e-3               # fused column sum (bias gradient), accumulated
+    o.gemm_nt(A, W, dpre, M, aux=dact, act=2, colsum=csum)
+    want = ref * dact.double()
+    assert rel_err(dpre, want) < 5e-3
+    assert rel_err(csum, 1 + want.sum(0)) < 2e-3                  # fused column sum (bias gradient), accumulated
 
 
-@pytest.mark.parametrize("M,N,K", [(33000, 768, 256), (70001, 512, 2048), (95630, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(33000, 768, 256), (70001, 512, 2048), (95630, 768, 768), (66000, 256, 128), (40001, 512, 192),
+                                   (158208, 2048, 512)])
 def test_gemm_nt_8phase_matches_two_buffer_kernel(M, N, K):
-    """The 8-phase kernel accumulates in the same order as the two-buffer kernel, so every epilogue variant must agree
-    BITWISE (several tiles per workgroup, ragged last row tile, leftover rows): a stale or early-read staging granule
-    shows up here as a differing tile."""
+    """The 8-phase kernel accumulates in the same order as the two-buffer kernel and applies the same per-element arithmetic,
+    so every epilogue variant must agree BITWISE (several tiles per workgroup, ragged last row tile, 2 / 3 / many K-tiles per
+    tile): a stale or early-read staging granule or a mis-counted wait shows up here as a differing tile."""
     from avsiam_amd import _lib
     o = ops()
     lib = _lib.load()
@@ -157,11 +160,13 @@ def test_gemm_nt_8phase_matches_two_buffer_kernel(M, N, K):
     try:
         lib.avs_gemm_set_nt8(0)
         want = run()
-        lib.avs_gemm_set_nt8(1)
-        for rep in range(3):
-            got = run()
-            for name, g, w in zip(("bf16", "f32+res", "pre", "gelu", "gelu'"), got, want):
-                assert torch.equal(g, w), (name, rep, float((g.float() - w.float()).abs().max()))
+        for mode in (1,):
+            lib.avs_gemm_set_nt8(mode)
+            for rep in range(3):
+                got = run()
+                for name, g, w in zip(("bf16", "f32+res", "pre", "gelu", "gelu'"), got, want):
+                    assert torch.equal(g, w), (mode, name, rep, float((g.float() - w.float()).abs().max()),
+                                               torch.nonzero((g != w).any(1))[:4].flatten().tolist(), torch.nonzero((g != w).any(0))[:8].flatten().tolist())
     finally:
         lib.avs_gemm_set_nt8(1)
     ref = A.double() @ W.double().t() + bias.double()

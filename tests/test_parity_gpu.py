@@ -3,8 +3,14 @@ the C ABI) against the CPU oracle on identical weights, inputs and mask plan, an
 the unmodified reference produced (tests/golden).
 
 Tolerances (bf16 GEMM/attention operands with fp32 accumulation vs an fp32 reference; north_star asks for a
-stated tolerance):  losses rel 2e-2; contrastive logits abs 0.25 (tau = 0.05 amplifies 20x); per-tensor
-gradient cosine >= 0.99 and norm ratio within 5 % for every live parameter; dead parameters get no gradient."""
+stated tolerance).  They are set at about 3x the worst error MEASURED on an MI355X and logged by these tests into
+profiles/r02/parity_margins.json (tests.helpers.record_margin):
+  losses            rel 2e-3 (measured <= 5e-4; the constant-input golden case 1.8e-3 -> 6e-3)
+  contrastive logits abs 0.01 (measured 1.7e-3 at tau = 0.05)
+  gradients, every live tensor: cosine >= 0.9998 (measured >= 0.99993), norm ratio within 1 % (measured <= 0.32 %; ViT-L 0.66 % -> 2 %)
+  reference goldens, every live tensor: L2 norm within 1 % (0.29 %), the 8 sampled elements within 0.3 rms (0.10), the
+  element sum within 2.0 / 0.25 norms (MAE / contrastive; 0.62 / 0.075 - the sum is a cancelling statistic, kept as a weak check)
+  dead parameters get no gradient; masks are bit-exact."""
 import numpy as np
 import pytest
 import torch
@@ -20,8 +26,9 @@ pytestmark = pytest.mark.gpu
 
 # Tolerances of the reference-golden gradient checks (normalised as tests.helpers.gpu_grads_vs_golden says), first run with the
 # round-1 bounds; tightened to ~3x the measured worst case once profiles/r02/parity_margins.json exists.
-GOLD_L2, GOLD_SAMP, GOLD_SUM = 0.05, 1.0, 1.0
-GOLD_L2_C, GOLD_SAMP_C, GOLD_SUM_C = 0.08, 1.0, 1.0
+GOLD_L2, GOLD_SAMP, GOLD_SUM = 0.01, 0.3, 2.0
+GOLD_L2_C, GOLD_SAMP_C, GOLD_SUM_C = 0.01, 0.3, 0.25
+LOSS_RTOL, LOSS_RTOL_GOLD, LOGITS_ATOL, COS_MIN, RATIO_TOL = 2e-3, 6e-3, 0.01, 0.9998, 0.01
 
 
 def _model(cfg, seed=1234, mode="random"):
@@ -40,7 +47,7 @@ def _oracle(cfg, a, v, plan, mae, seed=1234, mode="random"):
     return out, extras, {k: p.grad for k, p in P.items()}
 
 
-def _compare_grads(model, ref_grads, cos_min=0.99, ratio_tol=0.05, tag=None):
+def _compare_grads(model, ref_grads, cos_min=0.9998, ratio_tol=0.01, tag=None):
     worst = (1.0, None)
     worst_ratio = (0.0, None)
     for info in build_spec(model.cfg):
@@ -80,7 +87,7 @@ def test_mae_pass_matches_reference_golden(name):
     out = m(a.cuda(), v.cuda(), mae_loss_weight=1, contrast_loss_weight=0, mask_plan=plan)
     out[0].backward()
     got = np.array([out[i].item() for i in (0, 1, 2, 3, 4, 7)])
-    np.testing.assert_allclose(got, d["out_scalars"], rtol=2e-2, atol=1e-6)
+    np.testing.assert_allclose(got, d["out_scalars"], rtol=LOSS_RTOL_GOLD, atol=1e-6)
     np.testing.assert_array_equal(out[5].cpu().numpy(), d["mask_a"])
     np.testing.assert_array_equal(out[6].cpu().numpy(), d["mask_v"])
     record_margin("golden_" + name, loss_rel=float(np.max(np.abs(got[:4] - d["out_scalars"][:4]) / np.abs(d["out_scalars"][:4]))))
@@ -96,10 +103,10 @@ def test_contrastive_pass_matches_reference_golden():
     out = m(a.cuda(), v.cuda(), mae_loss_weight=0, contrast_loss_weight=1, mask_plan=plan)
     out[0].backward()
     got = np.array([out[i].item() for i in (0, 1, 2, 3, 4, 7)])
-    np.testing.assert_allclose(got[[0, 4]], d["out_scalars"][[0, 4]], rtol=2e-2)
+    np.testing.assert_allclose(got[[0, 4]], d["out_scalars"][[0, 4]], rtol=LOSS_RTOL)
     assert out[5] is None and out[6] is None
     eng = m._engine("contrastive", 4)
-    np.testing.assert_allclose(eng.total.cpu().numpy(), d["logits"], atol=0.25)
+    np.testing.assert_allclose(eng.total.cpu().numpy(), d["logits"], atol=LOGITS_ATOL)
     record_margin("golden_c_w1_b4", loss_rel=float(abs(got[0] - d["out_scalars"][0]) / abs(d["out_scalars"][0])),
                   logits_abs=float(np.abs(eng.total.cpu().numpy() - d["logits"]).max()))
     gpu_grads_vs_golden(d, lambda n: m._params[n].grad, "golden_c_w1_b4", l2_rel=GOLD_L2_C, samp_rel=GOLD_SAMP_C, sum_rel=GOLD_SUM_C)
@@ -120,17 +127,21 @@ def test_pass_matches_oracle_full_gradients(which, B, T, La):
     out[0].backward()
     ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 4321)
     for i in (0, 1, 2, 3, 4):
-        assert abs(out[i].item() - ref[i].item()) <= 2e-2 * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+        assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
     if mae:
         assert torch.equal(out[5].cpu(), ref[5]) and torch.equal(out[6].cpu(), ref[6])
         eng = m._engine("mae", B)
         pa = eng.p_a[:eng.na_rows].cpu().reshape(extras["pred_a"].shape)
         pv = eng.p_v[:eng.nv_rows].cpu().reshape(extras["pred_v"].shape)
-        assert float((pa - extras["pred_a"]).norm() / extras["pred_a"].norm()) < 2e-2
-        assert float((pv - extras["pred_v"]).norm() / extras["pred_v"].norm()) < 2e-2
+        ea = float((pa - extras["pred_a"].detach()).norm() / extras["pred_a"].detach().norm())
+        ev = float((pv - extras["pred_v"].detach()).norm() / extras["pred_v"].detach().norm())
+        record_margin(f"oracle_{which}_B{B}_T{T}_La{La}", pred_a_rel_l2=ea, pred_v_rel_l2=ev)
+        assert ea < 2e-2 and ev < 2e-2, (ea, ev)
     else:
         eng = m._engine("contrastive", B)
-        assert float((eng.total.cpu() - extras["logits"]).abs().max()) < 0.25
+        el = float((eng.total.cpu() - extras["logits"].detach()).abs().max())
+        record_margin(f"oracle_{which}_B{B}_T{T}_La{La}", logits_abs=el)
+        assert el < LOGITS_ATOL, el
         assert abs(out[7].item() - ref[7].item()) <= 1.0 / B + 1e-6
     record_margin(f"oracle_{which}_B{B}_T{T}_La{La}", loss_rel=max(abs(out[i].item() - ref[i].item()) / max(abs(ref[i].item()), 1e-12) for i in (0, 1, 2, 3, 4)
                                                                    if ref[i].item() != 0))
@@ -162,7 +173,7 @@ def test_device_drawn_plan_matches_oracle(which, B, T, La):
     plan = m.last_plans(B)[which]
     ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 77)
     for i in (0, 1, 2, 3, 4):
-        assert abs(out[i].item() - ref[i].item()) <= 2e-2 * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+        assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
     if mae:
         assert torch.equal(out[5].cpu(), ref[5]) and torch.equal(out[6].cpu(), ref[6])
     _compare_grads(m, rgrads, tag=f"devplan_{which}")
@@ -193,5 +204,5 @@ def test_vit_large_matches_oracle(which):
     out[0].backward()
     ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 99)
     for i in (0, 1, 2, 3, 4):
-        assert abs(out[i].item() - ref[i].item()) <= 2e-2 * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
-    _compare_grads(m, rgrads, cos_min=0.985, tag=f"vit_large_{which}")
+        assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+    _compare_grads(m, rgrads, cos_min=0.9998, ratio_tol=0.02, tag=f"vit_large_{which}")
