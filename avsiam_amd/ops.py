@@ -211,7 +211,7 @@ def attn_fwd(qkv, tiles, H, out, lse):
     assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64)
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row
     assert lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    _launch("attn_fwd", 4.0 * tiles.sum_sq * D, "avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, out.stride(0),
+    _launch("attn_fwd_hd%d" % (D // H), 4.0 * tiles.sum_sq * D, "avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, out.stride(0),
             lse, lse.shape[1], _stream())
 
 
@@ -221,7 +221,7 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
     D = qkv.shape[1] // 3
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    _launch("attn_bwd", 10.0 * tiles.sum_sq * D, "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
+    _launch("attn_bwd_hd%d" % (D // H), 10.0 * tiles.sum_sq * D, "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
             out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
 
 

@@ -23,24 +23,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_HBM_GBS = 8000.0          # HBM3E peak, same table (6.3 TB/s is what a float4 copy achieves)
 
 
-def cpu_baseline(cfg, seconds_budget=30.0):
-    """The oracle (oracle/ref_cpu.py, a validated CPU restatement of the reference) timed on this node's host
-    cores on a bounded sample of the same workload: one full step (both passes fwd+bwd + both Adam updates) at B=2."""
+def cpu_baseline(cfg, batch=2, warmup=1, steps=3):
+    """the oracle (oracle/ref_cpu.py, the CPU restatement of the reference validated against it) timed on THIS
+    node's host cores in the same run, on a bounded sample of the same workload: `warmup` + `steps` full reference steps (both
+    passes forward + backward + both Adam updates) at a small batch of the same configuration, fp32 torch, all the cores the
+    process may use.  A reported baseline, never a target."""
+    import platform
     from avsiam_amd.flops import gflop_per_sample
     from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
     from avsiam_amd.weights import synth_inputs, synth_state
     from oracle import ref_cpu
     import random
-    cores = os.cpu_count() or 1
+    cores, cores_note = usable_cores()
+    torch.set_num_threads(cores)
+    cpu_model = platform.processor() or "unknown"
     try:
-        cores = len(os.sched_getaffinity(0))
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
     except Exception:
         pass
-    cores = min(cores, int(os.environ.get("AVSIAM_CPU_THREADS", 16)))     # a 1-GPU box's CPU share is 16 cores
-    torch.set_num_threads(cores)
-    B = 2
+    B = batch
     P = {k: t.clone().requires_grad_(True) for k, t in synth_state(cfg, 0, "init", include_dead=False).items()}
     a, v = synth_inputs(cfg, B, 87)
     gen = torch.Generator().manual_seed(0)
@@ -48,27 +56,86 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     params = list(P.values())
     opt1 = torch.optim.Adam(params, 2e-4, weight_decay=5e-7, betas=(0.95, 0.999))
     opt2 = torch.optim.Adam(params, 2e-4, weight_decay=5e-7, betas=(0.95, 0.999))
-    t0 = time.time()
-    out = ref_cpu.forward(P, cfg, a, v, pc, mae_loss_weight=0, contrast_loss_weight=1)
-    opt1.zero_grad(); out[0].backward(); opt1.step()
-    out = ref_cpu.forward(P, cfg, a, v, pm, mae_loss_weight=1, contrast_loss_weight=0)
-    opt2.zero_grad(); out[0].backward(); opt2.step()
-    dt = time.time() - t0
-    return {"value": B / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 full step (contrastive + MAE fwd/bwd, 2x Adam) at batch {B} of the same config, fp32 torch CPU, {dt:.1f} s",
+
+    def step():
+        out = ref_cpu.forward(P, cfg, a, v, pc, mae_loss_weight=0, contrast_loss_weight=1)
+        opt1.zero_grad(); out[0].backward(); opt1.step()
+        out = ref_cpu.forward(P, cfg, a, v, pm, mae_loss_weight=1, contrast_loss_weight=0)
+        opt2.zero_grad(); out[0].backward(); opt2.step()
+
+    for i in range(warmup):
+        t0 = time.time()
+        step()
+        log(f"cpu baseline: warm-up step {i} took {time.time() - t0:.1f} s ({cores} threads)")
+    times = []
+    for i in range(steps):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+        log(f"cpu baseline: timed step {i} took {times[-1]:.1f} s")
+    dt = sum(times) / len(times)
+    return {"value": B / dt, "unit": "samples/s", "cores": cores, "cores_note": cores_note, "kind": "port", "cpu_model": cpu_model, "torch": torch.__version__,
+            "batch": B, "warmup_steps": warmup, "timed_steps": steps, "step_seconds": [round(t, 3) for t in times],
+            "sample": f"{warmup} warm-up + {steps} timed full steps (contrastive + MAE fwd/bwd, 2x Adam) at batch {B} of the same config "
+                      f"({cfg.frames} frames x{cfg.video_tokens} + {cfg.audio_tokens} audio tokens), fp32 torch CPU, {cores} threads, mean {dt:.2f} s/step",
             "gflops": B * gflop_per_sample(cfg, B) / dt}
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel, measured OFFLINE with rocprofv3 PMC passes of this same command
-    (FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md) and stored under profiles/;
-    null when the stored measurement is for a different workload."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic_gemm_nt.json")
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, cut down to the cgroup CPU quota when there is one (a one-GPU box
+    exposes every hardware thread of the host in the mask but grants a 16-CPU share: 256 threads against that quota thrash)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    note = f"affinity mask {n}"
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    if quota is not None and quota < n:
+        n = max(1, int(quota))
+        note += f", cgroup quota {quota:.1f} CPUs"
+    env = os.environ.get("AVSIAM_CPU_THREADS")
+    if env:
+        n = max(1, min(n, int(env)))
+        note += f", AVSIAM_CPU_THREADS={env}"
+    elif quota is None and n > 32:
+        # no quota visible: stay within the documented CPU share of a one-GPU box rather than oversubscribe a shared host
+        n = 16
+        note += ", no cgroup quota visible: limited to the 16-CPU share of a one-GPU box"
+    return n, note
+
+
+def _sha1(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha1(f.read()).hexdigest()
+
+
+def pmc_traffic(args, kernel_file="gemm.hip", key="gemm_nt"):
+    """HBM bytes per launch of a kernel family, measured OFFLINE with rocprofv3 PMC passes of this same command (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md) and stored in profiles/r02/traffic.json together with the
+    SHA-1 of the kernel source it was measured on.  null when the stored figure is for another workload or another kernel source."""
+    path = os.path.join(ROOT, "profiles", "r02", "traffic.json")
     if not os.path.exists(path) or args.batch != 64 or args.frames != 10 or args.audio_tokens != 512 or args.model != "vit_base":
         return None
     try:
         with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
+            d = json.load(f)
+        if d["source_sha1"].get(kernel_file) != _sha1(os.path.join(ROOT, "avsiam_amd", "csrc", kernel_file)):
+            return None
+        return float(d["kernels"][key]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -90,6 +157,7 @@ def main():
                     help="vit_base = BASELINE.json's metric (configs[1]); vit_large = configs[3]'s shape, an extra data point")
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=2, help="steps of the separate single-stream pass that times the other kernel families")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="HIP-event timing of every kernel family (default: the dominant kernel, gemm_nt, only - each timed "
@@ -156,6 +224,22 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
     prof, ops.prof = ops.prof, None
+    # The other kernels that matter: weight-gradient GEMM, decoder attention (hd 32), LayerNorm backward.  In the timed
+    # region the weight gradients run on a second stream beside attention / LayerNorm backward, so a launch-to-end time there
+    # includes waiting for CUs.  Their rooflines are therefore taken in a short SEPARATE pass after the timed region, with
+    # everything on one stream (engine.WGRAD_STREAM_MODE "0") and HIP events around every launch of those families.
+    prof2 = None
+    if not args.no_kernel_events and world == 1 and args.roofline_steps > 0:
+        from avsiam_amd import engine as _eng
+        mode, _eng.WGRAD_STREAM_MODE = _eng.WGRAD_STREAM_MODE, "0"
+        train_step(model, a, v, args.lr)
+        torch.cuda.synchronize()
+        ops.prof = ops.KernelProfiler(("gemm_tn", "attn_", "layernorm_"))
+        for _ in range(args.roofline_steps):
+            train_step(model, a, v, args.lr)
+        torch.cuda.synchronize()
+        prof2, ops.prof = ops.prof, None
+        _eng.WGRAD_STREAM_MODE = mode
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -190,6 +274,40 @@ def main():
                                 "sampling": "all launches" if args.all_kernel_events else "every 5th launch of the timed region"}
             line["kernels"] = {k: {"launches": x["launches"], "total_ms": round(x["total_ms"], 3), "avg_us": round(x["avg_us"], 2),
                                    "rate_T_per_s": round(x["rate"] / 1e12, 3)} for k, x in sorted(s.items())}
+        if prof2 is not None:
+            s2 = prof2.summary()
+
+            def fam(keys, bound, peak, unit, kernel, note=None, traffic=None):
+                ks = [k for k in s2 if k in keys]
+                if not ks:
+                    return None
+                work = sum(s2[k]["work"] for k in ks)
+                ms = sum(s2[k]["total_ms"] for k in ks)
+                n = sum(s2[k]["launches"] for k in ks)
+                ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+                d = {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
+                     "launches": n, "avg_launch_us": 1e3 * ms / n, "work_per_launch": work / n, "ms_per_step": ms / args.roofline_steps}
+                if note:
+                    d["note"] = note
+                return d
+
+            more = [
+                fam(("gemm_tn",), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s", "gemm_tn8_kernel / gemm_tn_kernel (weight-gradient bf16 MFMA GEMMs, 2*M*N1*N2 FLOP per launch)",
+                    traffic=pmc_traffic(args, "gemm.hip", "gemm_tn")),
+                fam(("attn_fwd_hd32", "attn_bwd_hd32"), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s",
+                    "attn_fwd / attn_bwd_dq / attn_bwd_dkv <32> (decoder attention, hd 32; 4 / 10 * sum L^2 * D FLOP per launch)",
+                    note="VALU-bound beside the matrix pipe: one v_exp_f32 (8 issue cycles per wave) per score against 128 FLOP of MFMA work at hd 32 "
+                         "caps these kernels near 0.5 of the MFMA peak before any other VALU work", traffic=pmc_traffic(args, "attention.hip", "attn_hd32")),
+                fam(("attn_fwd_hd64", "attn_bwd_hd64"), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s", "attn_* <64> (encoder attention, hd 64)",
+                    traffic=pmc_traffic(args, "attention.hip", "attn_hd64")),
+                fam(("layernorm_bwd",), "hbm", PEAK_HBM_GBS, "GB/s", "ln_bwd_kernel (LayerNorm backward + residual-gradient add + bf16 copy + column sums; "
+                    "rows*D*(2+4+4+4+2) algorithmic bytes per launch)", traffic=pmc_traffic(args, "layernorm.hip", "ln_bwd")),
+                fam(("layernorm_fwd",), "hbm", PEAK_HBM_GBS, "GB/s", "ln_fwd_kernel (rows*D*(4+2) algorithmic bytes per launch)",
+                    traffic=pmc_traffic(args, "layernorm.hip", "ln_fwd")),
+            ]
+            line["roofline_more"] = {"pass": f"{args.roofline_steps} extra steps after the timed region, single stream (AVSIAM_WGRAD_STREAM=0 schedule), HIP events on every "
+                                             "launch of these families; the headline `value` and `roofline` come from the timed region",
+                                     "kernels": [m for m in more if m]}
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline (oracle) on the host cores")
             try:

@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch of the dominant kernel from two rocprofv3 PMC passes of the same bench command.
+"""HBM bytes per launch of the kernel families bench.py puts on the roofline, from two rocprofv3 PMC passes of the same bench
+command (tools/pmc_traffic.sh):
 
-    cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d out/pmc_write -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events
-    python tools/pmc_summary.py out/pmc_fetch/f_counter_collection.csv out/pmc_write/w_counter_collection.csv [CALLS] > profiles/rNN/traffic_gemm_nt.json
+    python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN/traffic.json
 
-CALLS = number of avs_gemm_nt_bf16(_dual) calls in the profiled run (282 per step; a call is one dispatch, or two when the
-two-buffer kernels hand leftover rows to a second launch), so that the figure is per launch as bench.py counts launches.
-
-FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads and is doubled
-(MI355X_MICROARCH.md, HBM / rocprofv3 section).  Also prints a per-kernel table (sum over all dispatches) to stderr.
+FETCH_SIZE / WRITE_SIZE count KiB at the L2 -> fabric boundary (Infinity-Cache hits included); on gfx950 FETCH_SIZE reports
+half the bytes of wide coalesced reads and is doubled (MI355X_MICROARCH.md, HBM / rocprofv3 section).  A "launch" is one call
+of the C ABI: one dispatch for the GEMMs, dq + dkv kernels for the attention backward, ln_bwd + its slab reduction for the
+LayerNorm backward.  The SHA-1 of every kernel source is stored beside the numbers: bench.py reports a figure only while
+the source it was measured on is unchanged.  A per-kernel table goes to stderr.
 """
 import csv
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(path, counter):
@@ -30,23 +32,48 @@ def load(path, counter):
     return tot, n
 
 
+# family -> (substrings of the kernel names that belong to it, substring of the kernel whose dispatches count the launches)
+FAMILIES = {
+    "gemm_nt": (("gemm_nt",), "gemm_nt"),
+    "gemm_tn": (("gemm_tn",), "gemm_tn"),
+    "attn_hd32": (("attn_fwd_kernel<32", "attn_bwd_dq_kernel<32", "attn_bwd_dkv_kernel<32"), None),
+    "attn_hd64": (("attn_fwd_kernel<64", "attn_bwd_dq_kernel<64", "attn_bwd_dkv_kernel<64"), None),
+    "ln_bwd": (("ln_bwd_kernel", "ln_bwd_reduce_kernel"), "ln_bwd_kernel"),
+    "ln_fwd": (("ln_fwd_kernel",), "ln_fwd_kernel"),
+}
+
+
 def main():
     fetch, nf = load(sys.argv[1], "FETCH_SIZE")
     write, nw = load(sys.argv[2], "WRITE_SIZE")
     rows = []
     for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + write.get(k, 0))):
         rows.append((k, nf.get(k, 0), 2 * fetch.get(k, 0) * 1024, write.get(k, 0) * 1024))
-    for k, n, fb, wb in rows[:25]:
+    for k, n, fb, wb in rows[:30]:
         print(f"{k[:60]:60s} x{n:5d}  read {fb / 1e9:8.2f} GB  write {wb / 1e9:8.2f} GB", file=sys.stderr)
     print(f"all kernels: read {sum(r[2] for r in rows) / 1e9:.1f} GB, write {sum(r[3] for r in rows) / 1e9:.1f} GB", file=sys.stderr)
-    mm = [r for r in rows if "gemm_nt" in r[0]]
-    n = int(sys.argv[3]) if len(sys.argv) > 3 else sum(r[1] for r in mm)
-    fb, wb = sum(r[2] for r in mm), sum(r[3] for r in mm)
-    print(json.dumps({"kernel": "gemm_nt8_kernel + gemm_nt_kernel (all instantiations)", "launches": n, "dispatches": sum(r[1] for r in mm), "fetch_bytes_per_launch_raw": fb / 2 / n,
-                      "fetch_bytes_per_launch_corrected": fb / n, "write_bytes_per_launch": wb / n, "hbm_bytes_per_launch": (fb + wb) / n,
-                      "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 1`; "
-                                "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); values in KiB"},
-                     indent=1))
+    out = {}
+    for fam, (subs, count_sub) in FAMILIES.items():
+        mm = [r for r in rows if any(s in r[0] for s in subs)]
+        if not mm:
+            continue
+        if count_sub is None:          # attention: forward launches + backward launches (dq and dkv are one call)
+            n = sum(r[1] for r in mm if "attn_fwd" in r[0]) + sum(r[1] for r in mm if "attn_bwd_dkv" in r[0])
+        else:
+            n = sum(r[1] for r in mm if count_sub in r[0] and "reduce" not in r[0])
+        fb, wb = sum(r[2] for r in mm), sum(r[3] for r in mm)
+        out[fam] = {"launches": n, "dispatches": sum(r[1] for r in mm), "fetch_bytes_per_launch_corrected": fb / n, "write_bytes_per_launch": wb / n,
+                    "hbm_bytes_per_launch": (fb + wb) / n}
+    sha = {}
+    csrc = os.path.join(ROOT, "avsiam_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                sha[f] = hashlib.sha1(fh.read()).hexdigest()
+    print(json.dumps({"kernels": out, "source_sha1": sha,
+                      "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 1 --no-cpu-baseline "
+                                "--no-kernel-events`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); "
+                                "values in KiB; totals over the run divided by the launches of the run"}, indent=1))
 
 
 if __name__ == "__main__":

@@ -1,6 +1,7 @@
 #!/bin/bash
-# HBM traffic of the dominant kernel for bench.py's roofline.traffic: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE - separate
-# runs, counters only) of the bench command, summarised per launch.  usage (GPU box, repo root): bash tools/pmc_traffic.sh <tag>
+# HBM traffic of the roofline kernels for bench.py's `traffic` fields: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE - separate
+# runs, counters only) of the bench command, summarised per launch and stamped with the kernel sources' SHA-1.
+# usage (GPU box, repo root): bash tools/pmc_traffic.sh <tag>   ->  gpurun_out/<tag>/traffic.json  (commit as profiles/rNN/traffic.json)
 set -e
 TAG=${1:-pmc}
 REPO=$PWD
@@ -14,6 +15,6 @@ echo "write pass done"
 cd $REPO
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
-python3 tools/pmc_summary.py $F $W > $OUT/traffic_gemm_nt.json 2> $OUT/traffic_by_kernel.txt
+python3 tools/pmc_summary.py $F $W > $OUT/traffic.json 2> $OUT/traffic_by_kernel.txt
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
-cat $OUT/traffic_gemm_nt.json; head -12 $OUT/traffic_by_kernel.txt
+head -40 $OUT/traffic.json; head -14 $OUT/traffic_by_kernel.txt
