@@ -14,6 +14,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 extern "C" void avs_set_error(const char* fmt, ...);
 
+// host-side descriptor of a raw input (the C ABI's `avs_input_xf`, include/avsiam_hip.h)
+typedef struct avs_input_xf_t {
+    int kind;                        // 0 none | 1 un-normalised fp32 fbank | 2 uint8 frames
+    float mean[3], std[3];           // kind 1: [0] only (dataset mean / std); kind 2: per channel
+    const int* shift;                // kind 1, device, per sample, may be NULL: time roll (dataloader.py:513)
+    const float* amp;                // kind 1, device, per sample, may be NULL: noise amplitude (:512)
+    unsigned long long seed;         // Philox key of the noise
+} avs_input_xf_t;
+
 #define AVS_CHECK_ARG(cond, ...)                 \
     do {                                         \
         if (!(cond)) {                           \
@@ -97,3 +106,51 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- raw inputs: the arithmetic of the reference's dataset (/root/reference/src/dataloader.py:505-513
+// audio, :461-462 + :152-155 frames) applied WHERE THE INPUT IS READ - the patch gather of the embedding and the target gather of
+// the reconstruction loss - instead of in a pass of its own.  Mirrors `avs_input_xf` of include/avsiam_hip.h.
+//   kind 0  the tensor is already normalised fp32 (the reference's forward() contract)
+//   kind 1  audio: un-normalised fp32 fbank; value(b, t, f) = (in[b, (t - shift_b) mod T, f] - mean0) * inv_std0 + amp_b * U(b, ts, f)
+//           (shift / amp: per-sample arrays or NULL; U: Philox4x32-10 keyed by `seed`, counter (ts * F + f, b) - the same stream
+//           avs_normalize_audio draws, so the fused and the two-pass paths agree bit for bit)
+//   kind 2  frames: uint8; value(n, c, y, x) = (in / 255 - mean_c) * inv_std_c
+struct InXf {
+    int kind;
+    float mean[3], inv_std[3];
+    const int* shift;
+    const float* amp;
+    uint32_t seed_lo, seed_hi;
+};
+
+__device__ __forceinline__ uint32_t xf_philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
+    uint32_t c2 = 0, c3 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// audio element (sample b, time frame t, mel bin f) of a [B, T, F] spectrogram as the model sees it
+__device__ __forceinline__ float xf_audio(const float* __restrict__ a, const InXf& x, int b, int t, int f, int T, int F) {
+    if (x.kind == 0) return a[((size_t)b * T + t) * F + f];
+    int sh = x.shift ? x.shift[b] % T : 0;
+    if (sh < 0) sh += T;
+    int ts = t - sh;
+    if (ts < 0) ts += T;
+    float v = (a[((size_t)b * T + ts) * F + f] - x.mean[0]) * x.inv_std[0];
+    const float amp = x.amp ? x.amp[b] : 0.f;
+    if (amp != 0.f) v += amp * ((float)(xf_philox((uint32_t)(ts * F + f), (uint32_t)b, x.seed_lo, x.seed_hi) >> 8) * (1.0f / 16777216.0f));
+    return v;
+}
+
+// frame element at flat index i of channel c (fp32 normalised, or uint8 raw)
+__device__ __forceinline__ float xf_video(const void* __restrict__ v, const InXf& x, size_t i, int c) {
+    if (x.kind == 0) return reinterpret_cast<const float*>(v)[i];
+    return ((float)reinterpret_cast<const uint8_t*>(v)[i] * (1.0f / 255.0f) - x.mean[c]) * x.inv_std[c];
+}

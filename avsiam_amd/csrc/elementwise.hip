@@ -11,26 +11,35 @@
 //        out[r, p*16+q] = a[b, t*16+q, f*16+p]
 __global__ void im2col_audio_kernel(const float* __restrict__ a, const int* __restrict__ row_b,
                                     const int* __restrict__ row_tok, bf16_t* __restrict__ out, int rows, int tlen,
-                                    int mel, int tP) {
+                                    int mel, int tP, InXf xf) {
     const int r = blockIdx.x;
     const int q = threadIdx.x >> 4, p = threadIdx.x & 15;      // consecutive threads read consecutive mel bins
     const int b = row_b[r], tok = row_tok[r];
     const int f = tok / tP, t = tok - f * tP;
-    const float v = a[((size_t)b * tlen + t * 16 + q) * mel + f * 16 + p];
+    const float v = xf_audio(a, xf, b, t * 16 + q, f * 16 + p, tlen, mel);
     out[(size_t)r * 256 + p * 16 + q] = f2bf(v);
 }
 
 // video: v [NF, C, H, W] fp32; token = gy*G + gx; out[r, c*256 + p*16 + q] = v[img, c, gy*16+p, gx*16+q]
-__global__ void im2col_video_kernel(const float* __restrict__ v, const int* __restrict__ row_img,
+__global__ void im2col_video_kernel(const void* __restrict__ vin, const int* __restrict__ row_img,
                                     const int* __restrict__ row_tok, bf16_t* __restrict__ out, int rows, int C, int H,
-                                    int W, int G) {
+                                    int W, int G, InXf xf) {
     const int r = blockIdx.x;
     const int img = row_img[r], tok = row_tok[r];
     const int gy = tok / G, gx = tok - gy * G;
     const int K = C * 256;
     for (int e = threadIdx.x * 4; e < K; e += blockDim.x * 4) {
         const int c = e >> 8, p = (e >> 4) & 15, q = e & 15;
-        const float4 x = *reinterpret_cast<const float4*>(v + (((size_t)img * C + c) * H + gy * 16 + p) * W + gx * 16 + q);
+        const size_t i = (((size_t)img * C + c) * H + gy * 16 + p) * W + gx * 16 + q;
+        float4 x;
+        if (xf.kind == 0) {
+            x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(vin) + i);
+        } else {                                               // four uint8 pixels in one 4-byte load
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(vin) + i);
+            const float m = xf.mean[c], is = xf.inv_std[c];
+            x = make_float4(((float)(w & 0xff) * (1.0f / 255.0f) - m) * is, ((float)((w >> 8) & 0xff) * (1.0f / 255.0f) - m) * is,
+                            ((float)((w >> 16) & 0xff) * (1.0f / 255.0f) - m) * is, ((float)(w >> 24) * (1.0f / 255.0f) - m) * is);
+        }
         uint2 o;
         o.x = pack_bf2(x.x, x.y);
         o.y = pack_bf2(x.z, x.w);
@@ -273,20 +282,53 @@ static inline int grid_1d(size_t n, int block) {
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
+// host-side check + copy of the caller's descriptor (include/avsiam_hip.h: avs_input_xf) into the kernel argument
+int avs_make_xf(const avs_input_xf_t* x, int want_kind, InXf* out, const char* who) {
+    InXf r{};
+    if (x && x->kind != 0) {
+        if (x->kind != want_kind) { avs_set_error("%s: input transform kind %d does not fit this input (want %d)", who, x->kind, want_kind); return -2; }
+        r.kind = x->kind;
+        for (int c = 0; c < 3; ++c) {
+            if (x->std[c] == 0.f && (c == 0 || want_kind == 2)) { avs_set_error("%s: zero std in the input transform", who); return -2; }
+            r.mean[c] = x->mean[c];
+            r.inv_std[c] = x->std[c] != 0.f ? 1.0f / x->std[c] : 0.f;
+        }
+        r.shift = x->shift; r.amp = x->amp;
+        r.seed_lo = (uint32_t)x->seed; r.seed_hi = (uint32_t)(x->seed >> 32);
+    }
+    *out = r;
+    return 0;
+}
+
+extern "C" int avs_im2col_audio_xf(const float* a, const int* row_b, const int* row_tok, bf16_t* out, int rows, int tlen,
+                                   int mel, int t_patches, const avs_input_xf_t* xf, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && a && row_b && row_tok && out, "im2col_audio: bad args");
+    InXf x;
+    if (int rc = avs_make_xf(xf, 1, &x, "im2col_audio")) return rc;
+    im2col_audio_kernel<<<rows, 256, 0, stream>>>(a, row_b, row_tok, out, rows, tlen, mel, t_patches, x);
+    AVS_LAUNCH_CHECK("im2col_audio");
+    return 0;
+}
+
 extern "C" int avs_im2col_audio(const float* a, const int* row_b, const int* row_tok, bf16_t* out, int rows, int tlen,
                                 int mel, int t_patches, hipStream_t stream) {
-    AVS_CHECK_ARG(rows > 0 && a && row_b && row_tok && out, "im2col_audio: bad args");
-    im2col_audio_kernel<<<rows, 256, 0, stream>>>(a, row_b, row_tok, out, rows, tlen, mel, t_patches);
-    AVS_LAUNCH_CHECK("im2col_audio");
+    return avs_im2col_audio_xf(a, row_b, row_tok, out, rows, tlen, mel, t_patches, nullptr, stream);
+}
+
+extern "C" int avs_im2col_video_xf(const void* v, const int* row_img, const int* row_tok, bf16_t* out, int rows, int C, int H,
+                                   int W, const avs_input_xf_t* xf, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && v && row_img && row_tok && out && (W % 16) == 0 && (H % 16) == 0, "im2col_video: bad args");
+    InXf x;
+    if (int rc = avs_make_xf(xf, 2, &x, "im2col_video")) return rc;
+    AVS_CHECK_ARG(x.kind == 0 || C == 3, "im2col_video: uint8 frames need 3 channels");
+    im2col_video_kernel<<<rows, 192, 0, stream>>>(v, row_img, row_tok, out, rows, C, H, W, W / 16, x);
+    AVS_LAUNCH_CHECK("im2col_video");
     return 0;
 }
 
 extern "C" int avs_im2col_video(const float* v, const int* row_img, const int* row_tok, bf16_t* out, int rows, int C, int H,
                                 int W, hipStream_t stream) {
-    AVS_CHECK_ARG(rows > 0 && v && row_img && row_tok && out && (W % 16) == 0 && (H % 16) == 0, "im2col_video: bad args");
-    im2col_video_kernel<<<rows, 192, 0, stream>>>(v, row_img, row_tok, out, rows, C, H, W, W / 16);
-    AVS_LAUNCH_CHECK("im2col_video");
-    return 0;
+    return avs_im2col_video_xf(v, row_img, row_tok, out, rows, C, H, W, nullptr, stream);
 }
 
 extern "C" int avs_cast_scale_bf16(const float* x, bf16_t* y, long long n, float alpha, hipStream_t stream) {

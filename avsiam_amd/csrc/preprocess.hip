@@ -11,19 +11,6 @@
 // be reproduced bit-for-bit on a device, its DISTRIBUTION (uniform [0,1) scaled by amp) is what is kept.
 #include "common.h"
 
-__device__ __forceinline__ uint32_t pp_philox(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
-    uint32_t c2 = 0, c3 = 0;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
-
 // out[b, t, :] = (in[b, (t - shift_b) mod T, :] - mean) / std + amp_b * U[b, (t - shift_b) mod T, :]
 // grid (B, ceil(T*F/4 / 256)); F % 4 == 0
 __global__ __launch_bounds__(256) void normalize_audio_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int F,
@@ -42,10 +29,10 @@ __global__ __launch_bounds__(256) void normalize_audio_kernel(const float* __res
     const float a = amp ? amp[b] : 0.f;
     if (a != 0.f) {                                             // sample-uniform
         const uint32_t e = (uint32_t)(ts * F + f);
-        o.x += a * ((float)(pp_philox(e + 0, (uint32_t)b, seed_lo, seed_hi) >> 8) * (1.0f / 16777216.0f));
-        o.y += a * ((float)(pp_philox(e + 1, (uint32_t)b, seed_lo, seed_hi) >> 8) * (1.0f / 16777216.0f));
-        o.z += a * ((float)(pp_philox(e + 2, (uint32_t)b, seed_lo, seed_hi) >> 8) * (1.0f / 16777216.0f));
-        o.w += a * ((float)(pp_philox(e + 3, (uint32_t)b, seed_lo, seed_hi) >> 8) * (1.0f / 16777216.0f));
+        o.x += a * ((float)(xf_philox(e + 0, (uint32_t)b, seed_lo, seed_hi) >> 8) * (1.0f / 16777216.0f));
+        o.y += a * ((float)(xf_philox(e + 1, (uint32_t)b, seed_lo, seed_hi) >> 8) * (1.0f / 16777216.0f));
+        o.z += a * ((float)(xf_philox(e + 2, (uint32_t)b, seed_lo, seed_hi) >> 8) * (1.0f / 16777216.0f));
+        o.w += a * ((float)(xf_philox(e + 3, (uint32_t)b, seed_lo, seed_hi) >> 8) * (1.0f / 16777216.0f));
     }
     *reinterpret_cast<float4*>(out + ((size_t)b * T + t) * F + f) = o;
 }

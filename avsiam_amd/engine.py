@@ -347,12 +347,13 @@ class PatchEmbedder:
     def rows_updated(self):
         torch.add(self.row_tok, 0 if self.audio else 1, out=self.row_pos)
 
-    def forward(self, inp, out):
-        """inp: audio [B,time,mel] / video [NF,3,H,W] fp32; out: fp32 [rows(+pad), D] slice of the residual stream."""
+    def forward(self, inp, out, xf=None):
+        """inp: audio [B,time,mel] / video [NF,3,H,W] fp32 - or the raw input (un-normalised fbank / uint8 frames) with its
+        transform `xf` (ops.InputXf); out: fp32 [rows(+pad), D] slice of the residual stream."""
         if self.audio:
-            ops.im2col_audio(inp, self.row_src, self.row_tok, self.cols, self.rows, self.cfg.audio_t)
+            ops.im2col_audio(inp, self.row_src, self.row_tok, self.cols, self.rows, self.cfg.audio_t, xf)
         else:
-            ops.im2col_video(inp, self.row_src, self.row_tok, self.cols, self.rows)
+            ops.im2col_video(inp, self.row_src, self.row_tok, self.cols, self.rows, xf)
         ops.gemm_nt(self.cols, self.lin.w, out, self.rows, bias=self.lin.b, res=self.pos, res_idx=self.row_pos, alpha=2.0)
 
     def backward(self, dx):
@@ -525,15 +526,16 @@ class ContrastivePass:
             v_keep[int(perm_v[sl])] = [ids[base + t * Lv: base + t * Lv + self.keep_v[g]].clone() for t in range(T)]
         return ContrastivePlan(a_group, v_group, a_keep, v_keep)
 
-    def forward(self, audio, imgs, plan, weight=1.0):
+    def forward(self, audio, imgs, plan, weight=1.0, xf=(None, None)):
         """-> (weight * nce [1] device tensor, c_acc [1] device tensor); leaves everything backward needs in place.
-        plan: a ContrastivePlan to inject, or None when draw_device() already filled the index arrays."""
+        plan: a ContrastivePlan to inject, or None when draw_device() already filled the index arrays.
+        xf: (audio, frames) input transforms when the inputs are raw (ops.InputXf), else None."""
         cfg, st = self.cfg, self.stack
         if plan is not None:
             self._set_plan(plan)
         x0 = st.x[0]
-        self.emb_a.forward(audio, x0[:self.rows_a])
-        self.emb_v.forward(_fold_frames(imgs, cfg.frames), x0[self.rows_a:])
+        self.emb_a.forward(audio, x0[:self.rows_a], xf[0])
+        self.emb_v.forward(_fold_frames(imgs, cfg.frames), x0[self.rows_a:], xf[1])
         st.forward(self.blocks)
         _ln_fwd(st.out, self.final, self.yf, self.fstat[0], self.fstat[1], self.rows, LN_EPS_FINAL, st.row_mod)
         ops.segment_mean_fwd(self.yf, self.seg_start, self.reps_slot, 2 * self.B)
@@ -706,23 +708,24 @@ class MaePass:
         sv = ids[B * La:].view(B, T, Lv)
         return MaePlan(sa[:, :ka].contiguous(), torch.argsort(sa, dim=1), sv[..., :kv].contiguous(), torch.argsort(sv, dim=-1))
 
-    def forward(self, audio, imgs, plan):
-        """plan: a MaePlan to inject, or None when draw_device() already filled the index arrays."""
+    def forward(self, audio, imgs, plan, xf=(None, None)):
+        """plan: a MaePlan to inject, or None when draw_device() already filled the index arrays.
+        xf: (audio, frames) input transforms when the inputs are raw (ops.InputXf), else None."""
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         La, Lv = cfg.audio_tokens, cfg.video_tokens
         if plan is not None:
             self._set_plan(plan)
-        self.audio, self.imgs = audio, _fold_frames(imgs, T)
+        self.audio, self.imgs, self.xf = audio, _fold_frames(imgs, T), xf
         ra = self.rows_a
         if self.grouped:
             st = self.st_t
-            self.emb_a.forward(audio, st.x[0][:ra])
-            self.emb_v.forward(self.imgs, st.x[0][ra:])
+            self.emb_a.forward(audio, st.x[0][:ra], xf[0])
+            self.emb_v.forward(self.imgs, st.x[0][ra:], xf[1])
             st.forward(self.blk_a, self.blk_v, ra)
             out_a, out_v = st.out[:ra], st.out[ra:]
         else:
-            self.emb_a.forward(audio, self.st_a.x[0])
-            self.emb_v.forward(self.imgs, self.st_v.x[0])
+            self.emb_a.forward(audio, self.st_a.x[0], xf[0])
+            self.emb_v.forward(self.imgs, self.st_v.x[0], xf[1])
             self.st_a.forward(self.blk_a)
             self.st_v.forward(self.blk_v)
             out_a, out_v = self.st_a.out, self.st_v.out
@@ -742,16 +745,16 @@ class MaePass:
         ops.gemm_nt(self.dn[:self.v_off], self.pred_a.w, self.p_a, self.na_rows, bias=self.pred_a.b)       # :634
         ops.gemm_nt(self.dn[self.v_off:], self.pred_v.w, self.p_v, self.nv_rows, bias=self.pred_v.b)       # :635
         ops.mae_loss_fwd(self.p_a, audio, self.mask_a.view(-1), self.rl_a, self.losses[0:1], True, La, self.nmask_a,
-                         total=self.losses[2:3], total_init=True)
+                         total=self.losses[2:3], total_init=True, xf=xf[0])
         ops.mae_loss_fwd(self.p_v, self.imgs, self.mask_v.view(-1), self.rl_v, self.losses[1:2], False, Lv, self.nmask_v,
-                         total=self.losses[2:3], total_init=False)                                          # loss_mae = a + v (:707)
+                         total=self.losses[2:3], total_init=False, xf=xf[1])                                # loss_mae = a + v (:707)
         return self.losses[2:3], self.losses[0:1], self.losses[1:2], self.mask_a, self.mask_v
 
     def backward(self, gout, reducer=None):
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         La, Lv, D, Dd = cfg.audio_tokens, cfg.video_tokens, cfg.embed_dim, cfg.dec_dim
-        ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a)
-        ops.mae_loss_bwd(self.p_v, self.imgs, self.mask_v.view(-1), gout, self.dp_v, False, Lv, self.nmask_v)
+        ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a, xf=self.xf[0])
+        ops.mae_loss_bwd(self.p_v, self.imgs, self.mask_v.view(-1), gout, self.dp_v, False, Lv, self.nmask_v, xf=self.xf[1])
         # prediction heads
         ops.gemm_nt(self.dp_a, self.pred_a.wt, self.ddn[:self.v_off], self.na_rows)
         ops.gemm_tn(self.dp_a, self.dn[:self.v_off], self.pred_a.gw, self.na_rows)

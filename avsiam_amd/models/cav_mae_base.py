@@ -50,8 +50,9 @@ class _HotPath(torch.autograd.Function):
     """One node for a whole pass: forward launches the kernel schedule, backward the hand-written reverse."""
 
     @staticmethod
-    def forward(ctx, anchor, model, audio, imgs, plan_m, plan_c, contrast_w):
-        """plan_*: False = branch off, None = draw on the device, else an explicit MaePlan / ContrastivePlan."""
+    def forward(ctx, anchor, model, audio, imgs, plan_m, plan_c, contrast_w, xf=(None, None)):
+        """plan_*: False = branch off, None = draw on the device, else an explicit MaePlan / ContrastivePlan.
+        xf: (audio, frames) transforms of RAW inputs (ops.InputXf) or (None, None)."""
         ctx.set_materialize_grads(False)
         ctx.model, ctx.contrast_w = model, contrast_w
         ctx.has_m, ctx.has_c = plan_m is not False, plan_c is not False
@@ -63,7 +64,7 @@ class _HotPath(torch.autograd.Function):
             eng = model._engine("mae", B)
             if plan_m is None:
                 eng.draw_device(model._next_seed(), model._np_rng())
-            lm, la, lv, ma, mv = eng.forward(audio, imgs, plan_m)
+            lm, la, lv, ma, mv = eng.forward(audio, imgs, plan_m, xf)
             out.update(loss_mae=lm.clone(), la=la.clone(), lv=lv.clone(), mask_a=ma.clone(), mask_v=mv.clone())
         else:
             out.update(loss_mae=zero.clone(), la=zero.clone(), lv=zero.clone(), mask_a=None, mask_v=None)
@@ -71,7 +72,7 @@ class _HotPath(torch.autograd.Function):
             eng = model._engine("contrastive", B)
             if plan_c is None:
                 eng.draw_device(model._next_seed(), model._np_rng())
-            lc, acc = eng.forward(audio, imgs, plan_c, contrast_w)        # lc = contrast_loss_weight * nce (:735), from the kernel
+            lc, acc = eng.forward(audio, imgs, plan_c, contrast_w, xf)    # lc = contrast_loss_weight * nce (:735), from the kernel
             out.update(loss_c=lc.clone(), c_acc=acc.clone())
         else:
             out.update(loss_c=zero.clone(), c_acc=zero.clone())
@@ -127,7 +128,7 @@ class _HotPath(torch.autograd.Function):
                         model._average(w, live)
         if model.publish_grads:
             model._publish(live)
-        return (None,) * 7
+        return (None,) * 8
 
 
 class CAVMAE_BASE(nn.Module):
@@ -304,10 +305,13 @@ class CAVMAE_BASE(nn.Module):
 
     # ---- forward (reference signature, :685) --------------------------------------------------------------------
     def forward(self, audio, imgs, mask_ratio_a=0.75, mask_ratio_v=0.75, mae_loss_weight=1., contrast_loss_weight=0.01,
-                mask_mode='unstructured', *, mask_plan=None):
+                mask_mode='unstructured', *, mask_plan=None, input_xf=None):
         """Returns (loss, loss_mae, loss_mae_a, loss_mae_v, loss_c, mask_a, mask_v, c_acc) like the reference (:741).
         As in the reference, mask_ratio_* and mask_mode are ignored (ratios are fixed at :696 / :546-549) and
-        mae_loss_weight only switches the MAE branch on (:694,739)."""
+        mae_loss_weight only switches the MAE branch on (:694,739).
+        input_xf (extension): (ops.InputXf.audio(...), ops.InputXf.frames(...)) - `audio` is then the
+        UN-normalised fbank and `imgs` the uint8 frames as the reference's dataset holds them before its own arithmetic
+        (dataloader.py:505-513, 461-462); the kernels that read the inputs apply it on the fly (either entry may be None)."""
         self._require_gpu()
         cfg = self.cfg
         B = audio.shape[0]
@@ -317,8 +321,14 @@ class CAVMAE_BASE(nn.Module):
             (B, cfg.frames, cfg.in_chans, cfg.img_size, cfg.img_size)
         if tuple(imgs.shape) != want_v or (imgs.dim() == 4 and cfg.frames != 1):
             raise ValueError(f"imgs must be {want_v} for frames={cfg.frames}, got {tuple(imgs.shape)}")
+        xf = tuple(input_xf) if input_xf is not None else (None, None)
         audio = audio.to(self.arena.p.device, torch.float32).contiguous()
-        imgs = imgs.to(self.arena.p.device, torch.float32).contiguous()
+        if xf[1] is not None:
+            if imgs.dtype != torch.uint8:
+                raise ValueError("input_xf for the frames expects uint8 images")
+            imgs = imgs.to(self.arena.p.device).contiguous()
+        else:
+            imgs = imgs.to(self.arena.p.device, torch.float32).contiguous()
         do_m, do_c = mae_loss_weight != 0, contrast_loss_weight != 0
         plan_m = plan_c = None
         if isinstance(mask_plan, dict):
@@ -334,9 +344,9 @@ class CAVMAE_BASE(nn.Module):
         self._sync_shadows()
         anchor = self._params["vit_base.norm.weight"]
         if torch.is_grad_enabled():
-            res = _HotPath.apply(anchor, self, audio, imgs, plan_m, plan_c, float(contrast_loss_weight))
+            res = _HotPath.apply(anchor, self, audio, imgs, plan_m, plan_c, float(contrast_loss_weight), xf)
         else:
-            res = _HotPath.forward(_NoCtx(), anchor, self, audio, imgs, plan_m, plan_c, float(contrast_loss_weight))
+            res = _HotPath.forward(_NoCtx(), anchor, self, audio, imgs, plan_m, plan_c, float(contrast_loss_weight), xf)
         loss_mae, loss_c, la, lv, c_acc = (r.reshape(()) for r in res[:5])
         masks = res[5:]
         mask_a, mask_v = (masks[0], masks[1]) if (do_m and not do_c) else (None, None)     # :594 - the mixed encoder returns None

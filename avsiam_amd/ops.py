@@ -3,6 +3,8 @@ stream.  Every function here runs ONLY on the HIP kernels; there is no eager fal
 
 Shapes are validated on the host before any launch: a hand-written kernel that faults can reset the GPU.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -226,18 +228,49 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
 
 
 # ---------------------------------------------------------------------------------------------------
-def im2col_audio(a, row_b, row_tok, out, rows, t_patches):
+class InputXf(ctypes.Structure):
+    """include/avsiam_hip.h: avs_input_xf - how a raw input becomes the tensor the model sees (read on the host at call time)."""
+    _fields_ = [("kind", ctypes.c_int), ("mean", ctypes.c_float * 3), ("std", ctypes.c_float * 3), ("shift", ctypes.c_void_p),
+                ("amp", ctypes.c_void_p), ("seed", ctypes.c_ulonglong)]
+
+    @classmethod
+    def audio(cls, mean, std, shift=None, amp=None, seed=0):
+        """un-normalised fp32 fbank: (x - mean) / std [+ amp_b * U, rolled by shift_b] (dataloader.py:505-513)"""
+        x = cls(1, (ctypes.c_float * 3)(float(mean), 0, 0), (ctypes.c_float * 3)(float(std), 1, 1), None, None, int(seed) & 0xFFFFFFFFFFFFFFFF)
+        if shift is not None:
+            _chk(shift, I32, "xf.shift"); _chk(amp, F32, "xf.amp")
+            x.shift, x.amp = shift.data_ptr(), amp.data_ptr()
+            x._keep = (shift, amp)
+        return x
+
+    @classmethod
+    def frames(cls, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """uint8 frames: (x / 255 - mean_c) / std_c (dataloader.py:461-462, 152-155)"""
+        return cls(2, (ctypes.c_float * 3)(*[float(m) for m in mean]), (ctypes.c_float * 3)(*[float(v) for v in std]), None, None, 0)
+
+
+def _xf_arg(xf, kind, per_sample=None):
+    if xf is None:
+        return None
+    if not isinstance(xf, InputXf) or xf.kind != kind:
+        raise _lib.AvsiamHipError(f"input transform of kind {kind} expected")
+    if per_sample is not None and xf.shift:
+        assert xf._keep[0].numel() >= per_sample and xf._keep[1].numel() >= per_sample
+    return ctypes.addressof(xf)
+
+
+def im2col_audio(a, row_b, row_tok, out, rows, t_patches, xf=None):
     _chk(a, F32, "im2col.a", 3); _chk(row_b, I32, "im2col.row_b"); _chk(row_tok, I32, "im2col.row_tok"); _chk(out, BF16, "im2col.out", 2)
     assert out.shape[1] == 256 and out.shape[0] >= rows and row_b.numel() >= rows and row_tok.numel() >= rows
     assert a.shape[1] == t_patches * 16 and a.shape[2] % 16 == 0
-    _lib.call("avs_im2col_audio", a, row_b, row_tok, out, rows, a.shape[1], a.shape[2], t_patches, _stream())
+    _lib.call("avs_im2col_audio_xf", a, row_b, row_tok, out, rows, a.shape[1], a.shape[2], t_patches, _xf_arg(xf, 1, a.shape[0]), _stream())
 
 
-def im2col_video(v, row_img, row_tok, out, rows):
-    _chk(v, F32, "im2col.v", 4); _chk(row_img, I32, "im2col.row_img"); _chk(row_tok, I32, "im2col.row_tok"); _chk(out, BF16, "im2col.out", 2)
+def im2col_video(v, row_img, row_tok, out, rows, xf=None):
+    _chk(v, U8 if xf is not None else F32, "im2col.v", 4); _chk(row_img, I32, "im2col.row_img"); _chk(row_tok, I32, "im2col.row_tok"); _chk(out, BF16, "im2col.out", 2)
     NF, C, H, W = v.shape
-    assert out.shape[1] == C * 256 and out.shape[0] >= rows and row_img.numel() >= rows and row_tok.numel() >= rows
-    _lib.call("avs_im2col_video", v, row_img, row_tok, out, rows, C, H, W, _stream())
+    assert out.shape[1] == C * 256 and out.shape[0] >= rows and row_img.numel() >= rows and row_tok.numel() >= rows and W % 16 == 0
+    _lib.call("avs_im2col_video_xf", v, row_img, row_tok, out, rows, C, H, W, _xf_arg(xf, 2), _stream())
 
 
 PLAN_FIELDS = 12      # int32 per sequence descriptor of avs_mask_plan
@@ -323,8 +356,8 @@ def segment_mean_bwd(dreps, seg_start, dy, nseg, scale=1.0):
     _lib.call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], float(scale), _stream())
 
 
-def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, total_init=True):
-    _chk(pred, F32, "mae.pred", 2); _chk(inp, F32, "mae.inp"); _chk(mask, F32, "mae.mask"); _chk(row_loss, F32, "mae.row_loss"); _chk(loss, F32, "mae.loss")
+def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, total_init=True, xf=None):
+    _chk(pred, F32, "mae.pred", 2); _chk(inp, U8 if (xf is not None and not audio) else F32, "mae.inp"); _chk(mask, F32, "mae.mask"); _chk(row_loss, F32, "mae.row_loss"); _chk(loss, F32, "mae.loss")
     _chk(total, F32, "mae.total")
     rows = mask.numel()
     if audio:
@@ -334,19 +367,20 @@ def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, t
         C, H, W = inp.shape[-3:]
         assert rows == inp.numel() // (C * H * W) * L and pred.shape[1] == 256 * C and (H // 16) * (W // 16) == L
     assert pred.shape[0] >= rows and row_loss.numel() >= rows
-    _lib.call("avs_mae_loss_fwd", pred, inp, mask, row_loss, loss, total, int(bool(total_init)), rows, int(audio), L, C, H, W,
-              float(nmask), _stream())
+    _lib.call("avs_mae_loss_fwd_xf", pred, inp, mask, row_loss, loss, total, int(bool(total_init)), rows, int(audio), L, C, H, W,
+              float(nmask), _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), _stream())
 
 
-def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask):
-    _chk(pred, F32, "maeb.pred", 2); _chk(inp, F32, "maeb.inp"); _chk(mask, F32, "maeb.mask"); _chk(gout, F32, "maeb.gout"); _chk(dpred, BF16, "maeb.dpred", 2)
+def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask, xf=None):
+    _chk(pred, F32, "maeb.pred", 2); _chk(inp, U8 if (xf is not None and not audio) else F32, "maeb.inp"); _chk(mask, F32, "maeb.mask"); _chk(gout, F32, "maeb.gout"); _chk(dpred, BF16, "maeb.dpred", 2)
     rows = mask.numel()
     if audio:
         C, H, W = 1, inp.shape[1], inp.shape[2]
     else:
         C, H, W = inp.shape[-3:]
     assert pred.shape[0] >= rows and dpred.shape[0] >= rows and dpred.shape[1] == pred.shape[1] == 256 * C
-    _lib.call("avs_mae_loss_bwd", pred, inp, mask, gout, dpred, rows, int(audio), L, C, H, W, float(nmask), _stream())
+    _lib.call("avs_mae_loss_bwd_xf", pred, inp, mask, gout, dpred, rows, int(audio), L, C, H, W, float(nmask),
+              _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), _stream())
 
 
 def l2norm_fwd(x, xn, norm):

@@ -12,17 +12,18 @@ IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
 
 
-def normalize_fbank(fbank, norm_mean, norm_std, noise=False, seed=0, rng=None):
+def normalize_fbank(fbank, norm_mean, norm_std, noise=False, seed=0, rng=None, shift=None, amp=None):
     """fbank [B, T, F] fp32 (GPU) -> (fbank - norm_mean) / norm_std (dataloader.py:505-506).  ``noise=True`` adds the
     reference's training augmentation (:510-513): + U[0,1) * amp with amp = rand()/10 per sample, then a roll along time
-    by a per-sample shift in [-T, T); amp and shift come from ``rng`` (a numpy Generator, default seeded by ``seed``),
-    the per-element noise from a device Philox stream keyed by ``seed``."""
+    by a per-sample shift in [-T, T); amp and shift come from ``rng`` (a numpy Generator, default seeded by ``seed``) unless
+    given explicitly (int32 / fp32 device tensors), the per-element noise from a device Philox stream keyed by ``seed``.
+    (The training path does not call this: forward(..., input_xf=) applies the same arithmetic inside the kernels that read
+    the input; this two-pass form is what tests compare it with.)"""
     if not (fbank.is_cuda and fbank.dtype == torch.float32 and fbank.dim() == 3 and fbank.is_contiguous()):
         raise _lib.AvsiamHipError("normalize_fbank: need a contiguous fp32 [B, T, F] GPU tensor")
     B, T, F = fbank.shape
     out = torch.empty_like(fbank)
-    shift = amp = None
-    if noise:
+    if noise and shift is None:
         rng = rng if rng is not None else np.random.default_rng(seed)
         amp = torch.from_numpy((rng.random(B) / 10).astype(np.float32)).to(fbank.device)
         shift = torch.from_numpy(rng.integers(-T, T, B).astype(np.int32)).to(fbank.device)

@@ -9,7 +9,8 @@ batches are used - the sqlite/wav/mp4 input pipeline (src/dataloader.py) is out 
 'synthetic' adds a synthetic validation loader so validate() and the best-model bookkeeping run.
 Extensions: --frames (T frames per sample), --steps-per-epoch / --val-steps (synthetic epoch lengths), --raw-input (the
 loader hands over what the reference's dataset holds BEFORE normalisation - un-normalised fbank, uint8 frames - and the
-dataloader's arithmetic, incl. --noise, runs on the device: avsiam_amd/preprocess.py).
+dataloader's arithmetic, incl. --noise, is applied by the kernels that read the inputs: the patch gather of the embedding
+and the target gather of the reconstruction loss).
 """
 import argparse
 import ast
@@ -73,21 +74,26 @@ def build_parser():
     return parser
 
 
-def make_preprocess(args):
-    """The reference dataset's per-sample arithmetic as a device-side hook (a_raw, v_raw, train) -> (a, v):
-    (fbank - dataset_mean) / dataset_std, + noise and time roll in training when --noise (dataloader.py:505-513);
-    uint8 frames -> (x / 255 - mean_c) / std_c (:461-462, 152-155)."""
+def make_input_xf(args, device):
+    """The reference dataset's per-sample arithmetic as per-batch transform descriptors (ops.InputXf) that the input-reading
+    kernels apply on the fly: (fbank - dataset_mean) / dataset_std, + noise and time roll in training when --noise
+    (dataloader.py:505-513: amp = rand() / 10 and shift = randint(-T, T) per sample); uint8 frames -> (x / 255 - mean_c) / std_c
+    (:461-462, 152-155).  Returns f(batch, train) -> (audio transform, frame transform)."""
     import numpy as np
-    from . import preprocess
+    import torch
+    from .ops import InputXf
     rng = np.random.default_rng(87 + getattr(args, "local_rank", 0))
-    step = [0]
+    count = [0]
+    frames = InputXf.frames()
 
-    def prep(a_raw, v_raw, train=True):
-        step[0] += 1
-        a = preprocess.normalize_fbank(a_raw.contiguous(), args.dataset_mean, args.dataset_std, noise=bool(args.noise) and train,
-                                       seed=step[0], rng=rng)
-        return a, preprocess.normalize_frames(v_raw.contiguous())
-    return prep
+    def make(batch, train=True):
+        count[0] += 1
+        if bool(args.noise) and train:
+            amp = torch.from_numpy((rng.random(batch) / 10).astype(np.float32)).to(device)
+            shift = torch.from_numpy(rng.integers(-args.target_length, args.target_length, batch).astype(np.int32)).to(device)
+            return InputXf.audio(args.dataset_mean, args.dataset_std, shift, amp, seed=(87 << 32) | count[0]), frames
+        return InputXf.audio(args.dataset_mean, args.dataset_std), frames
+    return make
 
 
 def main(argv=None):
@@ -130,10 +136,10 @@ def _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train):
         val_loader = SyntheticAVLoader(cfg, args.batch_size, args.val_steps, torch.device("cuda", args.gpu), 1087 + args.rank,
                                        raw=args.raw_input)
     if args.raw_input:
-        args._preprocess = make_preprocess(args)
+        args._input_xf = make_input_xf(args, torch.device("cuda", args.gpu))
     print('Now starting training for {:d} epochs.'.format(args.n_epochs))
     train(audio_model, None, [val_loader, None], [None, None], None, args, None)                                  # :212
-    args.__dict__.pop("_preprocess", None)
+    args.__dict__.pop("_input_xf", None)
     return audio_model
 
 

@@ -19,16 +19,17 @@ from .param_spec import P1, P2
 from .utils import AverageMeter
 
 
-def train_step(model, a_input, v_input, lr, plans=None):
+def train_step(model, a_input, v_input, lr, plans=None, input_xf=None):
     """One reference step on one batch.  Returns the device scalars the reference logs (no host sync here):
-    (loss_pass2, loss_mae_a, loss_mae_v, loss_c, c_acc)."""
+    (loss_pass2, loss_mae_a, loss_mae_v, loss_c, c_acc).  input_xf: the batch's raw-input transforms (both passes see the SAME
+    augmented batch, as with the reference's loader)."""
     pm, pc = plans if plans is not None else (None, None)     # None: masks are drawn on the device
-    out = model(a_input, v_input, mae_loss_weight=0, contrast_loss_weight=1, mask_plan=pc)        # :132
+    out = model(a_input, v_input, mae_loss_weight=0, contrast_loss_weight=1, mask_plan=pc, input_xf=input_xf)        # :132
     loss_c, c_acc = out[4], out[7]
     out[0].backward()                                                                             # :138 (+ DDP's all-reduce)
     model.allreduce_grads(P1, average=False)                  # no-op when backward reduced; the 1/W rides in the Adam kernel
     model.adam_step(P1, lr)                                                                       # :139
-    out = model(a_input, v_input, mae_loss_weight=1, contrast_loss_weight=0, mask_plan=pm)        # :147
+    out = model(a_input, v_input, mae_loss_weight=1, contrast_loss_weight=0, mask_plan=pm, input_xf=input_xf)        # :147
     out[0].backward()                                                                             # :150
     model.allreduce_grads(P2, average=False)
     model.adam_step(P2, lr)                                                                       # :151
@@ -64,17 +65,16 @@ def validate(audio_model, val_loader, val_sampler, args):
     Returns (loss, loss_mae, loss_mae_a, loss_mae_v, loss_c, c_acc).  Masks stay random, as in the reference."""
     device = audio_model.arena.p.device
     rank = getattr(args, "rank", 0)
-    prep = getattr(args, "_preprocess", None)
+    raw = getattr(args, "_input_xf", None)
     acc = [[] for _ in range(6)]
     with torch.no_grad():
         for i, (a_input, v_input, _) in enumerate(val_loader):
             a_input, v_input = a_input.to(device), v_input.to(device)
-            if prep is not None:
-                a_input, v_input = prep(a_input, v_input, train=False)
             if rank == 0 and i % 50 == 0:
                 print("Val index: {}/{}".format(i, len(val_loader)))
             out = audio_model(a_input, v_input, args.masking_ratio, args.masking_ratio, mae_loss_weight=args.mae_loss_weight,
-                              contrast_loss_weight=args.contrast_loss_weight, mask_mode=args.mask_mode)
+                              contrast_loss_weight=args.contrast_loss_weight, mask_mode=args.mask_mode,
+                              input_xf=raw(a_input.size(0), train=False) if raw is not None else None)
             for lst, j in zip(acc, (0, 1, 2, 3, 4, 7)):
                 lst.append(out[j].detach())
     if not acc[0]:
@@ -114,7 +114,7 @@ def train(audio_model, train_sampler, test_loader, test_sampler, train_loader_li
                                          raw=getattr(args, "raw_input", False))
     else:
         train_loader = train_sampler
-    prep = getattr(args, "_preprocess", None)
+    raw = getattr(args, "_input_xf", None)                  # raw inputs (--raw-input): per-batch transforms, applied inside the kernels
     test_loader = test_loader[0] if isinstance(test_loader, (list, tuple)) else test_loader
     val_sampler = test_sampler[0] if isinstance(test_sampler, (list, tuple)) else test_sampler
     # The reference updates its loss meters every step with four .item() host syncs (:160-163).  Here the four losses are
@@ -147,9 +147,8 @@ def train(audio_model, train_sampler, test_loader, test_sampler, train_loader_li
             a_input = a_input.to(device, non_blocking=True)
             v_input = v_input.to(device, non_blocking=True)
             dnn_start_time = time.time()
-            if prep is not None:
-                a_input, v_input = prep(a_input, v_input, train=True)
-            loss, la, lv, lc, c_acc = train_step(audio_model, a_input, v_input, lr)
+            loss, la, lv, lc, c_acc = train_step(audio_model, a_input, v_input, lr,
+                                                 input_xf=raw(B, train=True) if raw is not None else None)
             step_vals = torch.stack([loss.detach(), la.detach(), lv.detach(), lc.detach()]).float()
             dsum += step_vals
             dcount += 1

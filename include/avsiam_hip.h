@@ -103,12 +103,32 @@ int avs_normalize_audio(const float* in, float* out, int B, int T, int F, float 
 int avs_normalize_frames_u8(const uint8_t* in, float* out, int n_images, int plane, const float* mean3, const float* std3,
                             avs_stream_t stream);
 
+/* ---- raw inputs, fused.  The same dataset arithmetic as avs_normalize_* above, applied where the input
+ * is READ - the patch gather of the embedding and the target gather of the reconstruction loss - so un-normalised fbank
+ * and uint8 frames go straight from the loader's buffers into the model: one read of the raw tensor per consumer instead of
+ * read + write + read.  kind 0 / NULL: the tensor is the normalised fp32 tensor of the reference's forward() contract.
+ * kind 1 (audio [B, T, F] fp32): value(b,t,f) = (in[b, (t - shift_b) mod T, f] - mean[0]) / std[0] + amp_b * U(b, ts, f); shift / amp
+ * are DEVICE arrays per sample or NULL (dataloader.py:510-513: the `noise` augmentation), U is the Philox stream of
+ * avs_normalize_audio for the same seed, so both paths agree bit for bit.  kind 2 (frames [n, 3, H, W] uint8):
+ * value = (in / 255 - mean[c]) / std[c] (:461-462, 152-155).  The struct itself is read on the HOST at call time. */
+typedef struct avs_input_xf {
+    int kind;
+    float mean[3], std[3];
+    const int* shift;
+    const float* amp;
+    unsigned long long seed;
+} avs_input_xf;
+
 /* ---- patch gather of the kept tokens (PatchEmbed input side + random_masking gather: cav_mae_base.py:96-99,
- * 382,431,444-455) */
+ * 382,431,444-455); the _xf forms take a raw input and its transform */
 int avs_im2col_audio(const float* a, const int* row_b, const int* row_tok, avs_bf16* out, int rows, int tlen, int mel,
                      int t_patches, avs_stream_t stream);
 int avs_im2col_video(const float* v, const int* row_img, const int* row_tok, avs_bf16* out, int rows, int C, int H, int W,
                      avs_stream_t stream);
+int avs_im2col_audio_xf(const float* a, const int* row_b, const int* row_tok, avs_bf16* out, int rows, int tlen, int mel,
+                        int t_patches, const avs_input_xf* xf, avs_stream_t stream);
+int avs_im2col_video_xf(const void* v, const int* row_img, const int* row_tok, avs_bf16* out, int rows, int C, int H, int W,
+                        const avs_input_xf* xf, avs_stream_t stream);
 /* random masking on the device (random_masking_unstructured / _structured + the gather index build,
  * cav_mae_base.py:365-439): one workgroup per sequence; seqs = nseq x 12 int32 {L, keep, row_off, src_id, dec_off, enc_base,
  * t_patches, ids_off, mask_off, 0, 0, 0}; L <= 1024.  tmask_lo/hi, fmask (per sequence bit masks of the time columns /
@@ -139,6 +159,12 @@ int avs_mae_loss_fwd(const float* pred, const float* inp, const float* mask, flo
                      int total_init, int rows, int audio, int L, int C, int H, int W, float nmask, avs_stream_t stream);
 int avs_mae_loss_bwd(const float* pred, const float* inp, const float* mask, const float* gout, avs_bf16* dpred, int rows,
                      int audio, int L, int C, int H, int W, float nmask, avs_stream_t stream);
+/* the same with the target read from a raw input (see avs_input_xf) */
+int avs_mae_loss_fwd_xf(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss, float* total,
+                        int total_init, int rows, int audio, int L, int C, int H, int W, float nmask, const avs_input_xf* xf,
+                        avs_stream_t stream);
+int avs_mae_loss_bwd_xf(const float* pred, const void* inp, const float* mask, const float* gout, avs_bf16* dpred, int rows,
+                        int audio, int L, int C, int H, int W, float nmask, const avs_input_xf* xf, avs_stream_t stream);
 
 /* ---- bidirectional InfoNCE (forward_contrastive, cav_mae_base.py:641-661) */
 int avs_l2norm_fwd(const float* x, float* xn, float* norm, int rows, int D, avs_stream_t stream);

@@ -257,3 +257,54 @@ def test_torchrun_entry_forms_the_rccl_group_and_runs(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "engine path on rccl ok" in r.stdout, r.stdout[-1500:]
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_raw_inputs_fused_into_the_input_reads(noise):
+    """un-normalised fbank + uint8 frames handed to forward() with their transforms (input_xf): the patch
+    gather and the loss-target gather apply the dataset arithmetic (/root/reference/src/dataloader.py:505-513, 461-462, 152-155)
+    on the fly.  Must equal (a) the two-pass path - normalise on the device first (avsiam_amd.preprocess), then the plain
+    forward - exactly (same arithmetic, same Philox stream), and (b) without the noise, the oracle fed with inputs normalised
+    on the CPU by the dataloader's formulas."""
+    import random
+    from avsiam_amd import preprocess
+    from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
+    from avsiam_amd.ops import InputXf
+    from oracle import ref_cpu
+    cfg = AVSiamConfig(audio_tokens=128, frames=2)
+    B, mean, std = 3, -5.081, 4.4849
+    g = torch.Generator().manual_seed(5)
+    a_raw = torch.randn(B, cfg.audio_len, cfg.n_mels, generator=g) * std + mean
+    v_u8 = torch.randint(0, 256, (B, cfg.frames, 3, cfg.img_size, cfg.img_size), generator=g, dtype=torch.uint8)
+    gen = torch.Generator().manual_seed(2)
+    pm, pc = make_mae_plan(cfg, B, gen), make_contrastive_plan(cfg, B, gen, random.Random(2))
+    shift = amp = None
+    if noise:
+        shift = torch.tensor([5, -300, 0], dtype=torch.int32, device="cuda")
+        amp = torch.tensor([0.05, 0.0, 0.09], dtype=torch.float32, device="cuda")
+    xf = (InputXf.audio(mean, std, shift, amp, seed=77), InputXf.frames())
+    a_dev = preprocess.normalize_fbank(a_raw.cuda(), mean, std, shift=shift, amp=amp, seed=77)
+    v_dev = preprocess.normalize_frames(v_u8.cuda())
+    m = _model(cfg, 41)
+    for mae, plan in ((True, pm), (False, pc)):
+        kw = dict(mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
+        two = m(a_dev, v_dev, **kw)
+        two[0].backward()
+        g_two = m.arena.g.clone()
+        one = m(a_raw.cuda(), v_u8.cuda(), input_xf=xf, **kw)
+        one[0].backward()
+        for i in (0, 1, 2, 3, 4):
+            assert one[i].item() == two[i].item(), (mae, i, one[i].item(), two[i].item())
+        lo, hi = m.arena.range[P2 if mae else P1]
+        ga, gb = m.arena.g[lo:hi].double(), g_two[lo:hi].double()
+        assert float(torch.dot(ga, gb) / (ga.norm() * gb.norm())) > 0.999999      # the same kernels on the same operands (fp32 atomics order)
+        if not noise:
+            torch.set_num_threads(16)
+            an = (a_raw - mean) / std
+            vn = (v_u8.float() / 255 - torch.tensor(preprocess.IMAGENET_DEFAULT_MEAN).view(1, 1, 3, 1, 1)) / torch.tensor(preprocess.IMAGENET_DEFAULT_STD).view(1, 1, 3, 1, 1)
+            P = {k: t.clone() for k, t in synth_state(cfg, 41, "random", include_dead=False).items()}
+            with torch.no_grad():
+                ref = ref_cpu.forward(P, cfg, an, vn, plan, mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1)
+            assert abs(one[0].item() - ref[0].item()) <= LOSS_RTOL * abs(ref[0].item()), (mae, one[0].item(), ref[0].item())
+    with pytest.raises(ValueError):
+        m(a_raw.cuda(), v_u8.cuda().float(), input_xf=xf, mae_loss_weight=1, contrast_loss_weight=0, mask_plan=pm)
