@@ -2,6 +2,7 @@
 
     python -m avsiam_amd.build            # incremental
     python -m avsiam_amd.build --force
+    AVSIAM_HIPCC_EXTRA=-DNT8_ABLATE=2 python -m avsiam_amd.build --out avsiam_amd/csrc/ab_x.so     # diagnostic build (tools/ab_lib.sh)
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting .so travels
 to the GPU box with the source snapshot (it is git-ignored, not gpurun-ignored).
@@ -27,30 +28,36 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    extra = os.environ.get("AVSIAM_HIPCC_EXTRA", "").split()       # diagnostic builds (tools/ab_lib.sh); forces a rebuild
-    if extra:
+def build(force=False, verbose=True, out=None):
+    """The product library (`out` None): incremental, never with extra flags.  A diagnostic build (`out` given; extra hipcc flags from
+    AVSIAM_HIPCC_EXTRA) compiles everything afresh into its own object directory and writes `out` - it never touches
+    libavsiam_hip.so, so a timing build cannot be left behind as the product."""
+    extra = os.environ.get("AVSIAM_HIPCC_EXTRA", "").split()
+    if extra and out is None:
+        raise SystemExit("AVSIAM_HIPCC_EXTRA is for diagnostic builds: pass --out <file.so> (tools/ab_lib.sh does)")
+    obj_dir, lib = (OBJ, LIB) if out is None else (OBJ + "_diag", os.path.abspath(out))
+    if out is not None:
         force = True
-    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
             cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, out=sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None)

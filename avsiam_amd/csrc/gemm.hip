@@ -57,6 +57,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // Diagnostic builds (tools/ab_lib.sh with AVSIAM_HIPCC_EXTRA=-DNT8_ABLATE=n; never defined in the product build):
 //   1  the epilogue computes everything but issues no global store      2  no epilogue at all (accumulators kept alive)
+//   3  as 2, and every tile streams the operands of tile 0 (all operand loads hit the L2: main loop without the memory system)
+//   4  as 2, with the phase's 16 MFMAs of 16x16x32 replaced by 8 of 32x32x16 on the same registers (timing only, wrong results)
 #ifndef NT8_ABLATE
 #define NT8_ABLATE 0
 #endif
@@ -458,7 +460,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
     const bf16_t* sB[2][2];
     int m0 = 0, n0 = 0;
     auto set_tile = [&](int v) {
+#if NT8_ABLATE == 3
+        const int wg = 0 * v;                                 // every tile streams tile 0's operands: all loads hit the L2
+#else
         const int wg = xcd_remap(v, ntiles);
+#endif
         m0 = (wg / nt_n) * TBM;
         n0 = (wg % nt_n) * TBN;
 #pragma unroll
@@ -502,6 +508,13 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if NT8_ABLATE == 4
+        f32x16 acc16[2][2][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc16[i >> 2][(i >> 1) & 1][i & 1][r] = 0.f;
+#endif
         // K-tile 0 (8 DMAs per thread, issued before the previous epilogue) must land; after the barrier every wave has
         // left that epilogue, so buffer 1 (its LDS patches) may take B0(1), A0(1)
         wait_vm<0>();
@@ -530,6 +543,14 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this phase's fragment reads (issued before the barrier)
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
+#if NT8_ABLATE == 4
+                // timing only (results are meaningless): the same fragments and flops through 8 MFMAs of 32x32x16
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+                        acc16[bh][ah][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[bh][kq >> 1][kq & 1], xf[mb * 2 + (kq >> 1)][kq & 1], acc16[bh][ah][mb], 0, 0, 0);
+#else
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -538,6 +559,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
                         for (int ni = 0; ni < 2; ++ni)
                             acc[bh * 2 + ni][ah * 4 + mi] =
                                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[bh][ni][kk], xf[mi][kk], acc[bh * 2 + ni][ah * 4 + mi], 0, 0, 0);
+#endif
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -588,11 +610,15 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
             set_tile(vnext);
             dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
         }
-#if NT8_ABLATE == 2
+#if NT8_ABLATE >= 2
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
+#if NT8_ABLATE == 4
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc16[i >> 2][(i >> 1) & 1][i & 1]));
+#endif
 #else
         nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
 #endif

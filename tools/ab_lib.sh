@@ -4,6 +4,6 @@
 #   gpurun -- 'for v in old new old new; do AVSIAM_HIP_LIB=$PWD/avsiam_amd/csrc/ab_$v.so python tools/bench_epilogue.py; done'
 set -e
 cd "$(dirname "$0")/.."
-python -m avsiam_amd.build > /dev/null
-cp avsiam_amd/csrc/libavsiam_hip.so "avsiam_amd/csrc/ab_$1.so"
+# (a build of its own: the product library is not touched; AVSIAM_HIPCC_EXTRA adds flags, e.g. -DNT8_ABLATE=2)
+python -m avsiam_amd.build --out "avsiam_amd/csrc/ab_$1.so" > /dev/null
 echo "avsiam_amd/csrc/ab_$1.so"
