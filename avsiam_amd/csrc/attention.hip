@@ -20,8 +20,9 @@
 //     32 MFMA cycles per 32x32x16 tile), so the per-score arithmetic is pushed into the MFMA's C operand: q arrives
 //     PRE-MULTIPLIED by hd^-0.5 * log2(e) (epilogue of the qkv GEMM, one bf16 rounding as before), the score
 //     accumulators start from -running_max (forward) / -lse (backward) and the dP accumulators from -delta, so the
-//     matrix core delivers exp2's argument and (dP - delta) directly.  Forward keeps a stale running max and only
-//     rescales when a tile exceeds it by 2^8 (exact: the final division and the saved lse use the same max).
+//     matrix core delivers exp2's argument and (dP - delta) directly.  Forward takes its reference point from the first
+//     key tile and moves it only when a later tile's row sum says so (no per-tile max; exact: the final division and
+//     the saved lse use the same reference).
 // Head dims 64 (encoder, 12 heads) and 32 (decoder, 16 heads).
 #include "common.h"
 #include <type_traits>
@@ -148,9 +149,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    // scores are in log2 units (q is pre-scaled).  m_run is the reference point the accumulators start from; it trails
-    // the true running max by at most LAZY, so p = exp2(s - m_run) <= 2^LAZY and nothing is rescaled on most tiles.
-    constexpr float LAZY = 8.0f;
+    // scores are in log2 units (q is pre-scaled).  m_run is the reference point the accumulators start from: the first tile's
+    // row max, moved only when a later tile's row sum of p = exp2(s - m_run) reaches LAZY_SUM = 2^40 (far from fp32 overflow:
+    // 2472 keys x 2^40 x |v| stays below 2^60) - the final division and the saved lse use the same reference, so the result
+    // is the softmax whatever the reference is.
+    constexpr float LAZY_SUM = 1099511627776.0f;
     float m_run = 0.f, l_run = 0.f;
     f32x16 negm = splat16(0.f);
 
@@ -185,40 +188,74 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r)
                     if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[kb][r] = -INFINITY;
         }
-        float t = -INFINITY;                                   // tile max relative to m_run
+        if (k0 == 0) {
+            // the first tile fixes the reference point at its row max
+            float t = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t = fmaxf(t, s[kb][r]);
-        t = fmaxf(t, __shfl_xor(t, 32, 64));
-        if (k0 == 0 || __any(t > LAZY)) {
-            // wave-uniform and rare after the first tile: move the reference point to the new max
+                for (int r = 0; r < 16; ++r) t = fmaxf(t, s[kb][r]);
+            t = fmaxf(t, __shfl_xor(t, 32, 64));
+            m_run = t;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= t;
+            negm = splat16(-m_run);
+        }
+        float psum;
+        float p[2][16];
+        auto exp_tile = [&]() {
+            // pairs are summed with v_pk_add_f32 (two scores per VALU slot)
+            f32x2 ps = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    p[kb][r] = fast_exp2(s[kb][r]);
+                    p[kb][r + 1] = fast_exp2(s[kb][r + 1]);
+                    ps += f32x2{p[kb][r], p[kb][r + 1]};
+                }
+            psum = ps[0] + ps[1];
+        };
+        exp_tile();
+        if (k0 != 0 && __any(!(psum < LAZY_SUM))) {
+            // wave-uniform and rare: some score of this tile lies more than ~2^LAZY above the reference point (or the sum overflowed).
+            // Recompute the tile's scores (K is still in LDS), move the reference point to the new max and rescale what has been
+            // accumulated - exactly the online-softmax step, taken only when it is needed.  No per-tile max otherwise: the row sum
+            // the tile needs anyway is the detector.
             asm volatile("; softmax: new reference max" ::: "memory");
-            const float d = k0 == 0 ? t : fmaxf(t, 0.f);
-            if (k0 != 0) {
-                const float alpha = fast_exp2(-d);
-                l_run *= alpha;
 #pragma unroll
-                for (int dd = 0; dd < NDB; ++dd)
+            for (int kb = 0; kb < 2; ++kb) {
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, 0, lane), qf[0], negm, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+                for (int kk = 1; kk < NKK; ++kk)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sK, kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
             }
+            float t = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (k0 + 64 > L && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[kb][r] = -INFINITY;
+                    t = fmaxf(t, s[kb][r]);
+                }
+            t = fmaxf(t, __shfl_xor(t, 32, 64));
+            const float d = fmaxf(t, 0.f);
+            const float alpha = fast_exp2(-d);
+            l_run *= alpha;
+#pragma unroll
+            for (int dd = 0; dd < NDB; ++dd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
             m_run += d;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] -= d;
             negm = splat16(-m_run);
+            exp_tile();
         }
-        float psum = 0.f;
-        float p[2][16];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[kb][r] = fast_exp2(s[kb][r]);
-                psum += p[kb][r];
-            }
         l_run += psum;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)

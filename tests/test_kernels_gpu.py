@@ -280,14 +280,17 @@ def test_attention_fwd_bwd(H, hd, lens, tile_rows):
     assert dqkv[rows:].abs().max().item() == 0
 
 
-def test_attention_spiked_scores():
-    """Large score spread: forces online-softmax rescaling across key tiles (max grows late)."""
+@pytest.mark.parametrize("H,hd,L,spike", [(2, 64, 200, 8.0), (2, 64, 200, 2.5), (4, 32, 300, 40.0), (4, 32, 300, 4.0)])
+def test_attention_spiked_scores(H, hd, L, spike):
+    """Large score spread: the forward keeps the first key tile's row max as its reference and moves it only when a later
+    tile's row sum reaches 2^40 (or overflows) - spikes below that threshold (large p, no rescale), above it, and beyond
+    fp32's exp2 range (inf in the first attempt) must all give the softmax."""
     o = ops()
-    H, hd, L = 2, 64, 200
     D = H * hd
     rp = o.pad_rows(L)
     x = torch.randn(L, 3 * D, device=DEV)
-    x[150, D:2 * D] *= 8.0          # one late key dominates
+    x[150, D:2 * D] *= spike        # one late key dominates
+    x[L - 3, D:2 * D] *= spike      # and one in the partial last key tile (masking + moved reference together)
     x[10, :D] *= 6.0
     x[60:70, :D] *= -4.0            # rows whose first key tile is far BELOW the later maximum and far above others
     x[:, :D] *= o.attn_q_scale(hd)
