@@ -14,7 +14,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libavsiam_hip.so")
-SOURCES = ["api.cpp", "layernorm.hip", "elementwise.hip", "losses.hip", "gemm.hip", "attention.hip", "maskplan.hip", "preprocess.hip"]
+SOURCES = ["api.cpp", "comm.cpp", "layernorm.hip", "elementwise.hip", "losses.hip", "gemm.hip", "attention.hip", "maskplan.hip", "preprocess.hip"]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), so the softmax VALU work of
 # the attention kernels reads them directly instead of through v_accvgpr_read/write copies.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
@@ -52,7 +52,7 @@ def build(force=False, verbose=True, out=None):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _stale(lib, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -58,9 +58,76 @@ class TorchDistComm:
         self.dist.all_reduce(t, group=self.group)
 
 
+class RcclComm:
+    """The same collectives through the C ABI's own RCCL wrappers (avs_comm_* / avs_allreduce / avs_allgather of
+    include/avsiam_hip.h): one communicator with a stream of its own and event hand-off - no torch.distributed call on the
+    data path.  torch.distributed (any backend, or none at world size 1) is used once, to hand rank 0's 128-byte
+    rendezvous id to the other ranks.  Select with ``set_distributed(..., comm=RcclComm(...))`` or AVSIAM_COMM=rccl."""
+
+    def __init__(self, rank=None, world=None, group=None, always=False):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        import torch.distributed as dist
+        have = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank(group) if have else 0)
+        self.world = world if world is not None else (dist.get_world_size(group) if have else 1)
+        self.active = self.world > 1 or always
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.call("avs_comm_unique_id", ctypes.cast(uid, ctypes.c_void_p))
+        if self.world > 1:
+            if not have:
+                raise _lib.AvsiamHipError("RcclComm: world size > 1 needs an initialised torch.distributed group to exchange the rendezvous id")
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = ctypes.create_string_buffer(box[0], 128)
+        handle = ctypes.c_void_p()
+        _lib.call("avs_comm_init", ctypes.cast(uid, ctypes.c_void_p), self.rank, self.world, ctypes.byref(handle))
+        self._h = handle
+
+    def _dtype(self, t):
+        if t.dtype == torch.float32:
+            return 0
+        if t.dtype == torch.bfloat16:
+            return 1
+        raise self._lib.AvsiamHipError(f"RcclComm: unsupported dtype {t.dtype}")
+
+    def all_gather(self, out, inp):
+        assert out.is_contiguous() and inp.is_contiguous() and out.numel() == self.world * inp.numel()
+        st = self._lib.current_stream()
+        self._lib.call("avs_allgather", self._h, inp, out, inp.numel(), self._dtype(inp), st)
+        self._lib.call("avs_comm_wait", self._h, st)
+
+    def all_reduce_async(self, t):
+        assert t.is_contiguous()
+        self._lib.call("avs_allreduce", self._h, t, t.numel(), self._dtype(t), self._lib.current_stream())
+        return self
+
+    def wait(self):
+        self._lib.call("avs_comm_wait", self._h, self._lib.current_stream())
+
+    def all_reduce(self, t):
+        self.all_reduce_async(t).wait()
+
+    def close(self):
+        if self._h is not None:
+            self._lib.call("avs_comm_destroy", self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def default_comm(world):
+    """AVSIAM_COMM=rccl: the C ABI's own RCCL communicator instead of torch.distributed's."""
     if world <= 1:
         return LocalComm()
+    if os.environ.get("AVSIAM_COMM", "torch") == "rccl":
+        return RcclComm()
     return TorchDistComm()
 
 

@@ -187,6 +187,27 @@ int avs_cast_bf16(const float* x, avs_bf16* y, long long n, avs_stream_t stream)
 int avs_adam(float* p, const float* g, float* m, float* v, avs_bf16* p_bf16, long long n, float lr, float beta1,
              float beta2, float eps, float weight_decay, int step, float grad_scale, avs_stream_t stream);
 
+/* ---- Collectives of the data-parallel path: thin wrappers over RCCL on a stream of the communicator's own, with event hand-off
+ * (SURVEY.md 8(b)).  Replace, on the data path, torch.distributed's all_gather / all_reduce in GatherLayer
+ * (src/models/gather_layer.py:21-37) and DistributedDataParallel's bucketed gradient all-reduce
+ * (src/traintest_cavmae_base.py:58-59).  RCCL is resolved at run time (the copy PyTorch loaded, else the system's).
+ *  avs_comm_unique_id  rank 0: the 128-byte rendezvous id, to be handed to the other ranks over any host channel
+ *  avs_comm_init       collective over all ranks (returns when every rank has called it); uses the current device
+ *  avs_allreduce       buf[count] <- SUM over ranks, in place          dtype 0 = fp32, 1 = bf16
+ *  avs_allgather       out[world * count] <- every rank's in[count], rank-major
+ *  avs_reducescatter   out[count] <- SUM over ranks of their in[rank * count ...]
+ *     each is ordered behind the work already queued on `after`, runs on the communicator's stream and returns at once
+ *  avs_comm_wait       `stream` waits on the device for every collective issued so far */
+int avs_comm_unique_id(void* id128);
+int avs_comm_init(const void* id128, int rank, int world, void** comm);
+int avs_comm_destroy(void* comm);
+int avs_comm_rank(void* comm);
+int avs_comm_world(void* comm);
+int avs_allreduce(void* comm, void* buf, unsigned long long count, int dtype, avs_stream_t after);
+int avs_allgather(void* comm, const void* in, void* out, unsigned long long count, int dtype, avs_stream_t after);
+int avs_reducescatter(void* comm, const void* in, void* out, unsigned long long count, int dtype, avs_stream_t after);
+int avs_comm_wait(void* comm, avs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -243,8 +243,8 @@ def test_torchrun_entry_forms_the_rccl_group_and_runs(tmp_path):
     """The way the reference is launched (torchrun, one process per GPU): utils.init_distributed_mode reads RANK / WORLD_SIZE /
     LOCAL_RANK, forms the "nccl" (= RCCL) process group - at world size 1 too, like the reference (utils.py:288) - and the
     entry point trains.  A second child process then runs the data-parallel code path itself on a one-rank RCCL group: the
-    embedding all-gather and the chunked gradient all-reduce are ISSUED (comm.TorchDistComm(always=True)) and must leave
-    losses and gradients unchanged."""
+    embedding all-gather and the chunked gradient all-reduce are ISSUED - through torch.distributed (comm.TorchDistComm(always=True))
+    and through the C ABI's own RCCL communicator (comm.RcclComm) - and must leave losses and gradients unchanged."""
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29577", "-m", "avsiam_amd.run_cavmae_pretrain_base", "--target_length", "256", "--batch-size", "4",
@@ -256,6 +256,7 @@ def test_torchrun_entry_forms_the_rccl_group_and_runs(tmp_path):
            "--master-port", "29579", os.path.join(ROOT, "tools", "rccl_selfcheck.py"), "--engine"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "native communicator ok" in r.stdout, r.stdout[-1500:]          # avs_comm_* / avs_allreduce / avs_allgather / avs_reducescatter
     assert "engine path on rccl ok" in r.stdout, r.stdout[-1500:]
 
 

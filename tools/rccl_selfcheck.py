@@ -34,9 +34,38 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     print(f"rank {rank}/{world}: rccl collectives ok (backend {dist.get_backend()})", flush=True)
+    native_comm(rank, world, dev)
     if "--engine" in sys.argv:
         engine_path(rank, world, dev)
     dist.destroy_process_group()
+
+
+def native_comm(rank, world, dev):
+    """The C ABI's own communicator (avs_comm_* / avs_allreduce / avs_allgather / avs_reducescatter): fp32 and bf16, ordering against
+    the caller's stream in both directions."""
+    from avsiam_amd import _lib
+    from avsiam_amd.comm import RcclComm
+    c = RcclComm(always=True)
+    assert (c.rank, c.world) == (rank, world)
+    assert _lib.load().avs_comm_rank(c._h) == rank and _lib.load().avs_comm_world(c._h) == world
+    st = _lib.current_stream()
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.arange(1 << 20, device=dev, dtype=torch.float32).remainder(251).to(dt)
+        y = x * 2                                               # queued on the caller's stream: the collective must see it
+        h = c.all_reduce_async(y)
+        h.wait()
+        assert torch.equal(y, x * 2 * world)
+        out = torch.zeros(world * x.numel(), device=dev, dtype=dt)
+        c.all_gather(out, x)
+        assert torch.equal(out.view(world, -1)[rank], x)
+        rs = torch.zeros(x.numel() // world, device=dev, dtype=dt)
+        _lib.call("avs_reducescatter", c._h, x, rs, rs.numel(), 0 if dt == torch.float32 else 1, st)
+        _lib.call("avs_comm_wait", c._h, st)
+        n = rs.numel()
+        assert torch.equal(rs, x[rank * n:(rank + 1) * n] * world)
+    torch.cuda.synchronize()
+    c.close()
+    print(f"rank {rank}/{world}: native communicator ok", flush=True)
 
 
 def engine_path(rank, world, dev):
@@ -44,7 +73,7 @@ def engine_path(rank, world, dev):
     all-gather (engine.ContrastivePass.forward) and the chunked asynchronous gradient all-reduce (comm.GradReducer, issued from
     engine.Stack.backward) run on RCCL even at world size 1, where they must change nothing."""
     import random
-    from avsiam_amd.comm import TorchDistComm
+    from avsiam_amd.comm import RcclComm, TorchDistComm
     from avsiam_amd.config import AVSiamConfig
     from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
     from avsiam_amd.models import CAVMAE_BASE
@@ -57,9 +86,9 @@ def engine_path(rank, world, dev):
     gen = torch.Generator().manual_seed(1)
     pm, pc = make_mae_plan(cfg, B, gen), make_contrastive_plan(cfg, B, gen, random.Random(1))
     res = []
-    for use_rccl in (False, True):
+    for comm in (None, TorchDistComm(always=True), RcclComm(always=True)):      # no collectives / torch.distributed / the C ABI's communicator
         m = CAVMAE_BASE(cfg=cfg, init_seed=5, init_mode="random", verbose=False).to(dev)
-        m.set_distributed(world, rank, TorchDistComm(always=True) if use_rccl else None)
+        m.set_distributed(world, rank, comm)
         m.publish_grads = False
         outs = []
         for mae, plan, which in ((False, pc, P1), (True, pm, P2)):
@@ -69,10 +98,11 @@ def engine_path(rank, world, dev):
             outs.append((out[0].item(), m.arena.g[lo:hi].double().norm().item(), m.last_reduce_messages))
         res.append(outs)
     torch.cuda.synchronize()
-    for (l0, g0, _), (l1, g1, msgs) in zip(*res):
-        assert l0 == l1 and abs(g0 - g1) <= 1e-5 * g0, (l0, l1, g0, g1)
-        assert world > 1 or msgs >= 2, msgs                 # the chunked reducer really issued several all-reduces
-    print(f"rank {rank}/{world}: engine path on rccl ok (messages per pass: {[r[2] for r in res[1]]})", flush=True)
+    for other in res[1:]:
+        for (l0, g0, _), (l1, g1, msgs) in zip(res[0], other):
+            assert l0 == l1 and abs(g0 - g1) <= 1e-5 * g0, (l0, l1, g0, g1)
+            assert world > 1 or msgs >= 2, msgs             # the chunked reducer really issued several all-reduces
+    print(f"rank {rank}/{world}: engine path on rccl ok (messages per pass: {[r[2] for r in res[1]]}; native communicator: {[r[2] for r in res[2]]})", flush=True)
 
 
 if __name__ == "__main__":
