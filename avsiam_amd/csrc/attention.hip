@@ -16,8 +16,9 @@
 //     tile's rows;
 //   * backward recomputes P from the saved log-sum-exp (no N x N tensor), in two kernels: dQ (query-major, same
 //     shape as forward) and dK/dV (key-major), so no atomics and bitwise-reproducible gradients.
-//   * the softmax is VALU-bound at these head dims (per score: v_exp 8 issue cycles + 4 per plain VALU op, against
-//     32 MFMA cycles per 32x32x16 tile), so the per-score arithmetic is pushed into the MFMA's C operand: q arrives
+//   * the softmax is VALU-bound at these head dims (measured, tools/valu_rate.py: v_exp_f32 8 SIMD cycles per wave64
+//     instruction, v_max3 / v_cvt_pk_bf16 / packed fp32 ops 4, plain fp32 mul / add / fma 2 - against 32 MFMA cycles per
+//     32x32x16 product, i.e. at hd 32 each 32-key block costs 128 cycles of v_exp alone beside 128 of MFMA), so the per-score arithmetic is pushed into the MFMA's C operand: q arrives
 //     PRE-MULTIPLIED by hd^-0.5 * log2(e) (epilogue of the qkv GEMM, one bf16 rounding as before), the score
 //     accumulators start from -running_max (forward) / -lse (backward) and the dP accumulators from -delta, so the
 //     matrix core delivers exp2's argument and (dP - delta) directly.  Forward takes its reference point from the first
