@@ -171,7 +171,13 @@ class Stack:
         self.inference = inference
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
-        self.tiles = ops.AttnTiles(seq_lens, dev)
+        # rows per attention workgroup (4 or 2 waves of 32 queries / keys), by the mean sequence length of the stack - measured on the
+        # step's mixes (tools/bench_attn.py --step): the backward of the contrastive pass (39-196 video, 102-512 audio tokens) is 12 %
+        # faster with 64-row workgroups, its forward 11 % slower; 49/128-token towers: forward 10 % faster; 618 and 2472 tokens: 128
+        mean_len = rows / max(1, len(seq_lens))
+        force = int(os.environ.get("AVSIAM_ATTN_TILE", "0"))                 # A/B switch: 64 | 128 for every stack and direction
+        self.tiles = ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_len < 64 else 128))
+        self.tiles_bwd = self.tiles if inference else ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_len < 256 else 128))
         self.q_scale = ops.attn_q_scale(D // H)          # q leaves the qkv GEMM ready for the attention kernels
 
         def per_block(shape, dtype):
@@ -299,7 +305,7 @@ class Stack:
             else:
                 wgrads(i, "dbm", (dbm, self.att[i], "proj"))
                 side.before_write("dqkv")
-            ops.attn_bwd(self.qkv[i], self.tiles, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
+            ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
             # qkv
             if excl:
                 side.join()

@@ -50,7 +50,9 @@ class KernelProfiler:
         return (self.seen - 1) % self.stride == 0
 
     def add(self, kind, e0, e1, work, dispatches=1):
-        self.rec.setdefault(kind, []).append((e0, e1, work, dispatches))
+        """work: FLOP (or bytes) of the launch, or a pair (FLOP, algorithmic HBM bytes) for kernels priced against both roofs"""
+        w, b = work if isinstance(work, tuple) else (work, 0.0)
+        self.rec.setdefault(kind, []).append((e0, e1, w, dispatches, b))
 
     def summary(self):
         out = {}
@@ -58,7 +60,7 @@ class KernelProfiler:
             ms = sum(r[0].elapsed_time(r[1]) for r in lst)
             work = sum(r[2] for r in lst)
             out[kind] = {"launches": len(lst), "dispatches": sum(r[3] for r in lst), "total_ms": ms, "avg_us": 1e3 * ms / len(lst), "work": work,
-                         "rate": work / (ms * 1e-3) if ms > 0 else 0.0}
+                         "rate": work / (ms * 1e-3) if ms > 0 else 0.0, "bytes": sum(r[4] for r in lst)}
         return out
 
 
@@ -213,7 +215,8 @@ def attn_fwd(qkv, tiles, H, out, lse):
     assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64)
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row
     assert lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    _launch("attn_fwd_hd%d" % (D // H), 4.0 * tiles.sum_sq * D, "avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, out.stride(0),
+    # algorithmic HBM bytes: q, k, v read and o written once per row (bf16), lse written per head and row
+    _launch("attn_fwd_hd%d" % (D // H), (4.0 * tiles.sum_sq * D, tiles.rows * (8.0 * D + 4.0 * H)), "avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, out.stride(0),
             lse, lse.shape[1], _stream())
 
 
@@ -223,7 +226,8 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
     D = qkv.shape[1] // 3
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    _launch("attn_bwd_hd%d" % (D // H), 10.0 * tiles.sum_sq * D, "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
+    # algorithmic HBM bytes of the two kernels: dQ reads q, k, v, o, dO and writes dq (+ delta); dK/dV reads q, k, v, dO and writes dk, dv
+    _launch("attn_bwd_hd%d" % (D // H), (10.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
             out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
 
 

@@ -277,11 +277,11 @@ def main():
         if prof2 is not None:
             s2 = prof2.summary()
 
-            def fam(keys, bound, peak, unit, kernel, note=None, traffic=None):
+            def fam(keys, bound, peak, unit, kernel, note=None, traffic=None, use_bytes=False):
                 ks = [k for k in s2 if k in keys]
                 if not ks:
                     return None
-                work = sum(s2[k]["work"] for k in ks)
+                work = sum(s2[k]["bytes" if use_bytes else "work"] for k in ks)
                 ms = sum(s2[k]["total_ms"] for k in ks)
                 n = sum(s2[k]["launches"] for k in ks)
                 ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
@@ -299,7 +299,11 @@ def main():
                     note="VALU-bound beside the matrix pipe: one v_exp_f32 (8 issue cycles per wave) per score against 128 FLOP of MFMA work at hd 32 "
                          "caps these kernels near 0.5 of the MFMA peak before any other VALU work", traffic=pmc_traffic(args, "attention.hip", "attn_hd32")),
                 fam(("attn_fwd_hd64", "attn_bwd_hd64"), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s", "attn_* <64> (encoder attention, hd 64)",
+                    note="sequences of 39-196 tokens (618 in the two joint layers): the time follows the ROWS, not the FLOP - see the hbm entry of the same launches",
                     traffic=pmc_traffic(args, "attention.hip", "attn_hd64")),
+                fam(("attn_fwd_hd64", "attn_bwd_hd64"), "hbm", PEAK_HBM_GBS, "GB/s", "attn_* <64> against the HBM roof: q, k, v, o (and dO, dq, dk, dv) "
+                    "once per kernel that needs them = rows*D*2*(4 forward | 12 backward: two kernels) algorithmic bytes per launch",
+                    traffic=pmc_traffic(args, "attention.hip", "attn_hd64"), use_bytes=True),
                 fam(("layernorm_bwd",), "hbm", PEAK_HBM_GBS, "GB/s", "ln_bwd_kernel (LayerNorm backward + residual-gradient add + bf16 copy + column sums; "
                     "rows*D*(2+4+4+4+2) algorithmic bytes per launch)", traffic=pmc_traffic(args, "layernorm.hip", "ln_bwd")),
                 fam(("layernorm_fwd",), "hbm", PEAK_HBM_GBS, "GB/s", "ln_fwd_kernel (rows*D*(4+2) algorithmic bytes per launch)",

@@ -19,8 +19,46 @@ def timeit(fn, iters=5):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def run_case(name, H, hd, lens, dev, tile_rows=(128, 64)):
+    D = H * hd
+    rows = sum(lens)
+    rp = ops.pad_rows(rows)
+    qkv = torch.zeros(rp, 3 * D, device=dev, dtype=torch.bfloat16)
+    qkv[:rows] = torch.randn(rows, 3 * D, device=dev).bfloat16()
+    out = torch.zeros(rp, D, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(H, rp, device=dev)
+    dout = torch.zeros(rp, D, device=dev, dtype=torch.bfloat16)
+    dout[:rows] = torch.randn(rows, D, device=dev).bfloat16()
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.zeros_like(lse)
+    fl = 4.0 * sum(L * L for L in lens) * D
+    msg = f"{name:34s} rows={rows:6d}:"
+    for tr in tile_rows:
+        tiles = ops.AttnTiles(lens, dev, tile_rows=tr)
+        tf = timeit(lambda: ops.attn_fwd(qkv, tiles, H, out, lse), 10)
+        tb = timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv), 10)
+        msg += (f"  [tile {tr}] fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF/s {rows*8.0*D/tf/1e9:6.0f} GB/s"
+                f"  bwd {tb*1e6:7.1f} us {2.5*fl/tb/1e12:6.1f} TF/s {rows*24.0*D/tb/1e9:6.0f} GB/s")
+    print(msg, flush=True)
+
+
+def step_mixes(dev):
+    """the sequence mixes of the bench step (batch 64, 10 frames): contrastive pass (five keep ratios), MAE towers, joint layers, decoder"""
+    vid = [196] * 130 + [156] * 130 + [117] * 130 + [78] * 130 + [39] * 120
+    aud = [512] * 13 + [409] * 13 + [307] * 13 + [204] * 13 + [102] * 12
+    run_case("contrastive pass (audio+video)", 12, 64, aud + vid, dev)
+    run_case("contrastive pass, video only", 12, 64, vid, dev)
+    run_case("contrastive pass, audio only", 12, 64, aud, dev)
+    run_case("MAE towers (64x128 + 640x49)", 12, 64, [128] * 64 + [49] * 640, dev)
+    run_case("MAE joint layers (64x618)", 12, 64, [618] * 64, dev)
+    run_case("decoder (64x2472)", 16, 32, [2472] * 64, dev, tile_rows=(128,))
+
+
 def main():
     dev = "cuda"
+    import sys
+    if "--step" in sys.argv:
+        return step_mixes(dev)
     for H, hd, L, rows_target in [(12, 64, 39, 40000), (12, 64, 49, 40000), (12, 64, 78, 40000), (12, 64, 117, 40000), (12, 64, 128, 40000),
                                   (12, 64, 156, 40000), (12, 64, 196, 40000), (12, 64, 307, 40000), (12, 64, 512, 40000), (12, 64, 618, 40000),
                                   (16, 32, 708, 80000), (16, 32, 2472, 160000)]:
