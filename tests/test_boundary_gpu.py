@@ -309,3 +309,40 @@ def test_raw_inputs_fused_into_the_input_reads(noise):
             assert abs(one[0].item() - ref[0].item()) <= LOSS_RTOL * abs(ref[0].item()), (mae, one[0].item(), ref[0].item())
     with pytest.raises(ValueError):
         m(a_raw.cuda(), v_u8.cuda().float(), input_xf=xf, mae_loss_weight=1, contrast_loss_weight=0, mask_plan=pm)
+
+
+def test_library_rebuilds_from_source_on_this_box(tmp_path):
+    """The shipped libavsiam_hip.so is built in the container; here the same sources are compiled afresh ON the GPU box
+    (python -m avsiam_amd.build --out: a build of its own that leaves the product library alone) and the rebuilt library must
+    give bitwise the results of the shipped one."""
+    out = tmp_path / "libavsiam_rebuilt.so"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("AVSIAM_HIPCC_EXTRA", None)
+    r = subprocess.run([sys.executable, "-m", "avsiam_amd.build", "--out", str(out)], env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0 and out.exists(), r.stdout[-1500:] + r.stderr[-1500:]
+    code = ("import torch, hashlib\n"
+            "from avsiam_amd import ops\n"
+            "torch.manual_seed(3)\n"
+            "M, N, K = 1000, 768, 512\n"
+            "A = torch.zeros(ops.pad_rows(M, 256), K, device='cuda', dtype=torch.bfloat16); A[:M] = torch.randn(M, K, device='cuda').bfloat16()\n"
+            "W = (torch.randn(N, K, device='cuda') * 0.05).bfloat16(); b = torch.randn(N, device='cuda')\n"
+            "o = torch.zeros(ops.pad_rows(M, 256), N, device='cuda', dtype=torch.bfloat16); o2 = torch.zeros_like(o)\n"
+            "ops.gemm_nt(A, W, o, M, bias=b, out2=o2, act=1)\n"
+            "x = torch.randn(M, N, device='cuda'); y = torch.zeros(M, N, device='cuda', dtype=torch.bfloat16)\n"
+            "mean, rstd = torch.zeros(M, device='cuda'), torch.zeros(M, device='cuda')\n"
+            "ops.layernorm_fwd(x, b, b, y, mean, rstd, M, 1e-5)\n"
+            "torch.cuda.synchronize()\n"
+            "h = hashlib.sha1()\n"
+            "for t in (o[:M], o2[:M], y, mean, rstd): h.update(t.cpu().view(torch.uint8).numpy().tobytes())\n"
+            "print('DIGEST', h.hexdigest())\n")
+    digests = []
+    for lib in (str(out), None):
+        e = dict(env)
+        if lib:
+            e["AVSIAM_HIP_LIB"] = lib
+        else:
+            e.pop("AVSIAM_HIP_LIB", None)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1], digests
