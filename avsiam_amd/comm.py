@@ -141,19 +141,37 @@ class GradReducer:
     ``min_elems`` are pending, so that xGMI sees few, large messages (ring collectives are per-link bound).
 
     mode (AVSIAM_DP_OVERLAP): "1" (default) chunks as described; "0" one blocking message in finish() - what round 1 did.
+    wire (AVSIAM_DP_WIRE): "fp32" (default) reduces the arena in place; "bf16" halves the bytes on xGMI: each chunk is rounded
+    to bf16 into a staging buffer, summed over the ranks in bf16, and written back over the fp32 gradients when its handle
+    is waited for (the local gradients and everything downstream - Adam moments, master weights - stay fp32).
     """
 
-    def __init__(self, comm, g, lo, hi, min_elems=16 << 20, overlap=None):
+    def __init__(self, comm, g, lo, hi, min_elems=16 << 20, overlap=None, wire=None, staging=None):
         self.comm, self.g, self.lo, self.hi = comm, g, lo, hi
         self.min_elems = min_elems
         if overlap is None:
             overlap = os.environ.get("AVSIAM_DP_OVERLAP", "1") != "0"
         self.active = getattr(comm, "active", comm.world > 1)
         self.overlap = overlap and self.active
+        self.wire = wire or os.environ.get("AVSIAM_DP_WIRE", "fp32")
+        assert self.wire in ("fp32", "bf16"), self.wire
+        # staging: a bf16 buffer of at least hi - lo elements the caller keeps across steps (allocated here if not given)
+        self.staging = staging
+        if self.wire == "bf16" and self.active and (staging is None or staging.numel() < hi - lo):
+            self.staging = torch.empty(hi - lo, dtype=torch.bfloat16, device=g.device)
         self.sent = []            # [a, b) ranges already handed to the collective
         self.pending = []         # declared final, not yet sent
         self.handles = []
         self.messages = 0
+
+    def _send(self, a, b):
+        if self.wire == "bf16":
+            st = self.staging[a - self.lo:b - self.lo]
+            st.copy_(self.g[a:b])                                    # round to nearest even, on the stream the gradients were written on
+            self.handles.append((self.comm.all_reduce_async(st), a, b))
+        else:
+            self.handles.append((self.comm.all_reduce_async(self.g[a:b]), a, b))
+        self.messages += 1
 
     def ready(self, a, b):
         if not self.overlap or b <= a:
@@ -177,8 +195,7 @@ class GradReducer:
 
     def _flush(self):
         for a, b in self._merge(self.pending):
-            self.handles.append(self.comm.all_reduce_async(self.g[a:b]))
-            self.messages += 1
+            self._send(a, b)
             self.sent.append((a, b))
         self.pending = []
 
@@ -189,9 +206,10 @@ class GradReducer:
         cur = self.lo
         for a, b in self._merge(self.sent) + [(self.hi, self.hi)]:
             if a > cur:
-                self.handles.append(self.comm.all_reduce_async(self.g[cur:a]))
-                self.messages += 1
+                self._send(cur, a)
             cur = max(cur, b)
-        for h in self.handles:
+        for h, a, b in self.handles:
             h.wait()
+            if self.wire == "bf16":
+                self.g[a:b].copy_(self.staging[a - self.lo:b - self.lo])
         self.handles, self.sent = [], []

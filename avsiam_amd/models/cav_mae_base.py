@@ -211,7 +211,9 @@ class CAVMAE_BASE(nn.Module):
 
     def _make_reducer(self, lo, hi, overlap=None):
         from ..comm import GradReducer
-        return GradReducer(self._comm, self.arena.ensure_grads(), lo, hi, overlap=overlap)
+        r = GradReducer(self._comm, self.arena.ensure_grads(), lo, hi, overlap=overlap, staging=getattr(self, "_wire_staging", None))
+        self._wire_staging = r.staging               # the bf16 wire buffer (AVSIAM_DP_WIRE=bf16) is kept across steps
+        return r
 
     def _average(self, which, live=None):
         """Apply the factor the gradients of pass `which` still owe (DDP's 1/W).  With both passes live in one backward the

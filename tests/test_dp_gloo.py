@@ -172,6 +172,21 @@ def _reducer_worker(rank, world, port, q):
         blocking.ready(200, 300)
         blocking.finish()
         assert blocking.messages == 1 and float(g2[lo]) == sum(r + 1 for r in range(world)) and float(g2[0]) == rank + 1
+        # bf16 on the wire: the sum of the ranks' bf16-rounded chunks, written back as fp32; outside [lo, hi) untouched
+        gen = torch.Generator().manual_seed(5 + rank)
+        g3 = torch.randn(n, generator=gen)
+        mine = g3.clone()
+        parts = [torch.randn(n, generator=torch.Generator().manual_seed(5 + r)) for r in range(world)]
+        exact = sum(parts)
+        wire = GradReducer(comm, g3, lo, hi, min_elems=1500, overlap=True, wire="bf16")
+        for a, b in ((8000, 8500), (7000, 8000), (4000, 5000)):
+            wire.ready(a, b)
+        wire.finish()
+        assert torch.equal(g3[:lo], mine[:lo]) and torch.equal(g3[hi:], mine[hi:])
+        assert torch.equal(g3[lo:hi], g3[lo:hi].bfloat16().float())                      # what arrived is a bf16 value
+        err = (g3[lo:hi] - exact[lo:hi]).abs().max().item()
+        assert err <= 2.0 ** -7 * world * exact[lo:hi].abs().max().item(), err             # bf16 rounding of inputs and of the partial sums
+        assert torch.dot(g3[lo:hi], exact[lo:hi]) / (g3[lo:hi].norm() * exact[lo:hi].norm()) > 0.99999
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback
