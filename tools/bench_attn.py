@@ -46,6 +46,8 @@ def step_mixes(dev):
     """the sequence mixes of the bench step (batch 64, 10 frames): contrastive pass (five keep ratios), MAE towers, joint layers, decoder"""
     vid = [196] * 130 + [156] * 130 + [117] * 130 + [78] * 130 + [39] * 120
     aud = [512] * 13 + [409] * 13 + [307] * 13 + [204] * 13 + [102] * 12
+    if "--decoder-only" in __import__("sys").argv:            # for counter runs (tools/pmc_attn.sh)
+        return run_case("decoder (64x2472)", 16, 32, [2472] * 64, dev, tile_rows=(128,))
     run_case("contrastive pass (audio+video)", 12, 64, aud + vid, dev)
     run_case("contrastive pass, video only", 12, 64, vid, dev)
     run_case("contrastive pass, audio only", 12, 64, aud, dev)
