@@ -75,3 +75,12 @@ def vit_large(**kw):
     """ViT-L/16 re-parameterisation (BASELINE.json configs[3]); no reference source exists
     for it so parity for this shape is pinned by the oracle only."""
     return AVSiamConfig(embed_dim=1024, depth=24, num_heads=16, **kw)
+
+
+def vit_huge(**kw):
+    """ViT-H width (timm vit_huge: 1280 wide, 32 layers, 16 heads of 80, MLP 5120) on this path's 16 x 16 patch grid - the encoder
+    of BASELINE.json configs[4] in bf16.  Not the /14 patch grid (588 = 14*14*3 is not a multiple of the GEMMs' 64-wide K step) and
+    not fp8; like ViT-L there is no reference source for it, parity is pinned by the oracle only.  ``depth`` may be overridden for
+    small test shapes."""
+    kw.setdefault("depth", 32)
+    return AVSiamConfig(embed_dim=1280, num_heads=16, **kw)

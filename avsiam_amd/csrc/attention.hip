@@ -75,7 +75,8 @@ struct TileRegs {
     f32x4 v[PER];
 };
 
-template <int HD, int NTH>
+// HG: the head dim in memory when it is not a multiple of 32 (80: ViT-H); the LDS image is HD = 96 wide and its columns HG.. are zero
+template <int HD, int NTH, int HG = HD>
 __device__ __forceinline__ void tile_load(TileRegs<HD, NTH>& t, const bf16_t* src, long long ld, int row0, int last_row, int tid) {
     constexpr int NCH = HD / 8;
 #pragma unroll
@@ -83,7 +84,8 @@ __device__ __forceinline__ void tile_load(TileRegs<HD, NTH>& t, const bf16_t* sr
         const int c = i * NTH + tid;
         const int row = c / NCH, ch = c % NCH;
         const int gr = min(row0 + row, last_row);
-        t.v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gr * ld + ch * 8);
+        if (HG == HD || ch < HG / 8) t.v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gr * ld + ch * 8);
+        else t.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -123,10 +125,10 @@ __device__ __forceinline__ f32x16 splat16(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int HD, int NW>
+template <int HD, int NW, int HG = HD>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     constexpr int NTH = 64 * NW;
-    constexpr int NKK = HD / 16, NDB = HD / 32;
+    constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2];
     char* sK = smem;
     char* sV = smem + 64 * HD * 2;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const int qw = a.tile_q0[tix] + 32 * wave;          // first query of this wave
     const bool active = qw < L;
     const int q = min(qw + (lane & 31), L - 1);
-    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
+    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HG;
 
     bf16x8 qf[NKK];
 #pragma unroll
@@ -159,16 +161,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     f32x16 negm = splat16(0.f);
 
     TileRegs<HD, NTH> rk, rv;
-    tile_load<HD, NTH>(rk, base + a.D, a.ld, 0, L - 1, tid);
-    tile_load<HD, NTH>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rk, base + a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
     for (int k0 = 0; k0 < L; k0 += 64) {
         __syncthreads();
         tile_store<HD, NTH>(rk, sK, tid);
         tile_store<HD, NTH>(rv, sV, tid);
         __syncthreads();
         if (k0 + 64 < L) {
-            tile_load<HD, NTH>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
-            tile_load<HD, NTH>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
         }
         if (!active) continue;
         f32x16 s[2];
@@ -273,11 +275,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const float inv = 1.0f / l_tot;
     const int qq = qw + (lane & 31);
     if (qq < L) {
-        bf16_t* orow = a.out + (size_t)(seq0 + qq) * a.ldo + head * HD;
+        bf16_t* orow = a.out + (size_t)(seq0 + qq) * a.ldo + head * HG;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (d * 32 + 8 * t >= HG) continue;                    // columns of the image beyond the real head dim
                 uint2 w;
                 w.x = pack_bf2(o[d][4 * t + 0] * inv, o[d][4 * t + 1] * inv);
                 w.y = pack_bf2(o[d][4 * t + 2] * inv, o[d][4 * t + 3] * inv);
@@ -289,10 +292,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // dQ (query-major).  Also produces delta = rowsum(dO * O), reused by the dK/dV kernel.
-template <int HD, int NW>
+template <int HD, int NW, int HG = HD>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int NTH = 64 * NW;
-    constexpr int NKK = HD / 16, NDB = HD / 32;
+    constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2];
     char* sK = smem;
     char* sV = smem + 64 * HD * 2;
@@ -305,15 +308,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     const int qw = a.tile_q0[tix] + 32 * wave;
     const bool active = qw < L;
     const int q = min(qw + (lane & 31), L - 1);
-    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
+    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HG;
 
     bf16x8 qf[NKK], dof[NKK];
     float dpart = 0.f;
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
         qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * a.ld + (2 * kk + hh) * 8);
-        dof[kk] = *reinterpret_cast<const bf16x8*>(a.dout + (size_t)(seq0 + q) * a.ldo + head * HD + (2 * kk + hh) * 8);
-        const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.out + (size_t)(seq0 + q) * a.ldo + head * HD + (2 * kk + hh) * 8);
+        dof[kk] = *reinterpret_cast<const bf16x8*>(a.dout + (size_t)(seq0 + q) * a.ldo + head * HG + (2 * kk + hh) * 8);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.out + (size_t)(seq0 + q) * a.ldo + head * HG + (2 * kk + hh) * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) dpart += bf2f((bf16_t)dof[kk][j]) * bf2f((bf16_t)of[j]);
     }
@@ -334,16 +337,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
     TileRegs<HD, NTH> rk, rv;
-    tile_load<HD, NTH>(rk, base + a.D, a.ld, 0, L - 1, tid);
-    tile_load<HD, NTH>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rk, base + a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
     for (int k0 = 0; k0 < L; k0 += 64) {
         __syncthreads();
         tile_store<HD, NTH>(rk, sK, tid);
         tile_store<HD, NTH>(rv, sV, tid);
         __syncthreads();
         if (k0 + 64 < L) {
-            tile_load<HD, NTH>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
-            tile_load<HD, NTH>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
         }
         if (!active) continue;
         const bool tail_tile = k0 + 64 > L;                 // block-uniform
@@ -389,11 +392,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
     if (!active) return;
     const int qq = qw + (lane & 31);
     if (qq < L) {
-        bf16_t* drow = a.dqkv + (size_t)(seq0 + qq) * a.ld + head * HD;
+        bf16_t* drow = a.dqkv + (size_t)(seq0 + qq) * a.ld + head * HG;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (d * 32 + 8 * t >= HG) continue;
                 uint2 w;
                 w.x = pack_bf2(dq[d][4 * t + 0] * a.scale, dq[d][4 * t + 1] * a.scale);
                 w.y = pack_bf2(dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale);
@@ -404,10 +408,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // dK, dV (key-major): each wave owns 32 keys (the lane) and walks the query rows of the sequence.
-template <int HD, int NW>
+template <int HD, int NW, int HG = HD>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int NTH = 64 * NW;
-    constexpr int NKK = HD / 16, NDB = HD / 32;
+    constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 2 * 64 * 4];
     char* sQ = smem;
     char* sDO = smem + 64 * HD * 2;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int kw = a.tile_q0[tix] + 32 * wave;          // first key of this wave
     const bool active = kw < L;
     const int key = min(kw + (lane & 31), L - 1);
-    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
+    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HG;
 
     bf16x8 kf[NKK], vf[NKK];
 #pragma unroll
@@ -436,13 +440,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
 
-    const bf16_t* dobase = a.dout + (size_t)seq0 * a.ldo + head * HD;
+    const bf16_t* dobase = a.dout + (size_t)seq0 * a.ldo + head * HG;
     const float* lsebase = a.lse + (size_t)head * a.rows_total + seq0;
     const float* delbase = a.delta + (size_t)head * a.rows_total + seq0;
     TileRegs<HD, NTH> rq, rdo;
     float rl = 0.f, rd = 0.f;
-    tile_load<HD, NTH>(rq, base, a.ld, 0, L - 1, tid);
-    tile_load<HD, NTH>(rdo, dobase, a.ldo, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rq, base, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rdo, dobase, a.ldo, 0, L - 1, tid);
     if (tid < 64) { rl = lsebase[min(tid, L - 1)]; rd = delbase[min(tid, L - 1)]; }
     for (int q0 = 0; q0 < L; q0 += 64) {
         __syncthreads();
@@ -451,8 +455,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (tid < 64) { sLse[tid] = -rl * 1.4426950408889634f; sDel[tid] = -rd; }    // negated: MFMA C operands
         __syncthreads();
         if (q0 + 64 < L) {
-            tile_load<HD, NTH>(rq, base, a.ld, q0 + 64, L - 1, tid);
-            tile_load<HD, NTH>(rdo, dobase, a.ldo, q0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rq, base, a.ld, q0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rdo, dobase, a.ldo, q0 + 64, L - 1, tid);
             if (tid < 64) { rl = lsebase[min(q0 + 64 + tid, L - 1)]; rd = delbase[min(q0 + 64 + tid, L - 1)]; }
         }
         if (!active) continue;
@@ -504,12 +508,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     if (!active) return;
     const int kq = kw + (lane & 31);
     if (kq < L) {
-        bf16_t* krow = a.dqkv + (size_t)(seq0 + kq) * a.ld + a.D + head * HD;
+        bf16_t* krow = a.dqkv + (size_t)(seq0 + kq) * a.ld + a.D + head * HG;
         bf16_t* vrow = krow + a.D;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (d * 32 + 8 * t >= HG) continue;
                 uint2 w;
                 // dK = dS^T . (q * scale) and the staged q is q * scale * log2(e)
                 w.x = pack_bf2(dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2);
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 // ===================================================================================================
 static int check_common(const char* name, const void* qkv, long long ld, int D, int H, int hd, const int* ts, const int* tl,
                         const int* tq, int ntiles) {
-    if (!(qkv && ts && tl && tq && ntiles > 0 && H > 0 && (hd == 32 || hd == 64) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0)) {
+    if (!(qkv && ts && tl && tq && ntiles > 0 && H > 0 && (hd == 32 || hd == 64 || hd == 80) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0)) {
         avs_set_error("%s: bad arguments (D=%d H=%d hd=%d ld=%lld ntiles=%d)", name, D, H, hd, ld, ntiles);
         return -2;
     }
@@ -536,12 +541,15 @@ extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const
                             const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
                             hipStream_t stream) {
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_fwd: tile_rows must be 64 or 128");
+    AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_fwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_fwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && lse && (ldo % 4) == 0, "attn_fwd: null output");
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd)};
     dim3 grid(ntiles * H);
-    if (tile_rows == 128) {
+    // hd 80 (ViT-H: 1280 / 16 heads): a 96-wide LDS image whose last 16 columns are zero, five contraction steps, 128-row tiles only
+    if (hd == 80) attn_fwd_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
+    else if (tile_rows == 128) {
         if (hd == 64) attn_fwd_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
         else attn_fwd_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
     } else {
@@ -556,13 +564,15 @@ extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const
                             const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
                             const float* lse, float* delta, int rows_total, bf16_t* dqkv, hipStream_t stream) {
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_bwd: tile_rows must be 64 or 128");
+    AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_bwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
                dout, delta, dqkv, 1.0f / sqrtf((float)hd)};
     dim3 grid(ntiles * H);
-    if (tile_rows == 128) {
+    if (hd == 80) attn_bwd_dq_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
+    else if (tile_rows == 128) {
         if (hd == 64) attn_bwd_dq_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
         else attn_bwd_dq_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
     } else {
@@ -570,7 +580,8 @@ extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const
         else attn_bwd_dq_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
     }
     AVS_LAUNCH_CHECK("attn_bwd_dq");
-    if (tile_rows == 128) {
+    if (hd == 80) attn_bwd_dkv_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
+    else if (tile_rows == 128) {
         if (hd == 64) attn_bwd_dkv_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
         else attn_bwd_dkv_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
     } else {

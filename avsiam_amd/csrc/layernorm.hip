@@ -197,15 +197,15 @@ extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b
                                  const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
                                  int rows, int D, float eps, hipStream_t stream) {
     // D = 1536: the concatenated audio|video feature of the fusion classification head (forward only)
-    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1536), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
+    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280 || D == 1536), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(x && g0 && b0 && y && mean && rstd, "layernorm_fwd: null pointer");
     AVS_CHECK_ARG(!row_mod || (g1 && b1), "layernorm_fwd: row_mod given without second affine set");
     dim3 grid(ceil_div(rows, 4)), block(256);
 #define LN_FWD(NV, F) ln_fwd_kernel<NV, F><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps)
     if (y_f32) {
-        if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else if (D == 1024) LN_FWD(4, true); else LN_FWD(6, true);
+        if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else if (D == 1024) LN_FWD(4, true); else if (D == 1280) LN_FWD(5, true); else LN_FWD(6, true);
     } else {
-        if (D == 512) LN_FWD(2, false); else if (D == 768) LN_FWD(3, false); else if (D == 1024) LN_FWD(4, false); else LN_FWD(6, false);
+        if (D == 512) LN_FWD(2, false); else if (D == 768) LN_FWD(3, false); else if (D == 1024) LN_FWD(4, false); else if (D == 1280) LN_FWD(5, false); else LN_FWD(6, false);
     }
 #undef LN_FWD
     AVS_LAUNCH_CHECK("layernorm_fwd");
@@ -219,7 +219,7 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
                                  const float* g0, const float* g1, const uint8_t* row_mod, const int* out_map,
                                  const float* dres, float* dx, bf16_t* dx_bf16, float* dg0, float* db0, float* dg1,
                                  float* db1, float* dcol, float* ws, int rows, int D, hipStream_t stream) {
-    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
+    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(dy && x && mean && rstd && g0 && dx && ws, "layernorm_bwd: null pointer");
     if (g_ln_rpw < 0) { const char* e = getenv("AVSIAM_LN_RPW"); g_ln_rpw = e ? atoi(e) : 0; }
     // A block of 4 waves x RPW rows writes one slab of parameter-gradient partial sums; fewer rows per wave = more blocks
@@ -238,9 +238,9 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
         if (rpw == 16) LN_BWD_R(NV, F, 16); else if (rpw == 8) LN_BWD_R(NV, F, 8); else LN_BWD_R(NV, F, 4);                                       \
     } while (0)
     if (dy_f32) {
-        if (D == 512) LN_BWD(2, true); else if (D == 768) LN_BWD(3, true); else LN_BWD(4, true);
+        if (D == 512) LN_BWD(2, true); else if (D == 768) LN_BWD(3, true); else if (D == 1024) LN_BWD(4, true); else LN_BWD(5, true);
     } else {
-        if (D == 512) LN_BWD(2, false); else if (D == 768) LN_BWD(3, false); else LN_BWD(4, false);
+        if (D == 512) LN_BWD(2, false); else if (D == 768) LN_BWD(3, false); else if (D == 1024) LN_BWD(4, false); else LN_BWD(5, false);
     }
 #undef LN_BWD
 #undef LN_BWD_R

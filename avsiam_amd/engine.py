@@ -176,6 +176,8 @@ class Stack:
         # faster with 64-row workgroups, its forward 11 % slower; 49/128-token towers: forward 10 % faster; 618 and 2472 tokens: 128
         mean_len = rows / max(1, len(seq_lens))
         force = int(os.environ.get("AVSIAM_ATTN_TILE", "0"))                 # A/B switch: 64 | 128 for every stack and direction
+        if D // H == 80:
+            force = 128                                                       # the hd-80 instantiation (ViT-H) exists for 128-row workgroups only
         self.tiles = ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_len < 64 else 128))
         self.tiles_bwd = self.tiles if inference else ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_len < 256 else 128))
         self.q_scale = ops.attn_q_scale(D // H)          # q leaves the qkv GEMM ready for the attention kernels

@@ -212,7 +212,7 @@ def attn_q_scale(hd):
 def attn_fwd(qkv, tiles, H, out, lse):
     _chk(qkv, BF16, "attn.qkv", 2); _chk(out, BF16, "attn.out", 2); _chk(lse, F32, "attn.lse", 2)
     D = qkv.shape[1] // 3
-    assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64)
+    assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64, 80)
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row
     assert lse.shape[0] == H and lse.shape[1] >= tiles.max_row
     # algorithmic HBM bytes: q, k, v read and o written once per row (bf16), lse written per head and row
@@ -224,7 +224,7 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
     _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2)
     _chk(lse, F32, "attnb.lse", 2); _chk(delta, F32, "attnb.delta", 2); _chk(dqkv, BF16, "attnb.dqkv", 2)
     D = qkv.shape[1] // 3
-    assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape
+    assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape and D // H in (32, 64, 80)
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
     # algorithmic HBM bytes of the two kernels: dQ reads q, k, v, o, dO and writes dq (+ delta); dK/dV reads q, k, v, dO and writes dk, dv
     _launch("attn_bwd_hd%d" % (D // H), (10.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,

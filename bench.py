@@ -153,8 +153,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--audio-tokens", type=int, default=512)
-    ap.add_argument("--model", choices=("vit_base", "vit_large"), default="vit_base",
-                    help="vit_base = BASELINE.json's metric (configs[1]); vit_large = configs[3]'s shape, an extra data point")
+    ap.add_argument("--model", choices=("vit_base", "vit_large", "vit_huge"), default="vit_base",
+                    help="vit_base = BASELINE.json's metric (configs[1]); vit_large = configs[3]'s shape, vit_huge = configs[4]'s encoder width in bf16 "
+                         "on 16x16 patches (use --batch 32: saved activations of batch 64 x 10 frames exceed 288 GB) - extra data points")
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=2, help="steps of the separate single-stream pass that times the other kernel families")
@@ -189,9 +190,12 @@ def main():
     if args.model == "vit_large":
         from avsiam_amd.config import vit_large
         cfg = vit_large(audio_tokens=args.audio_tokens, frames=args.frames)
+    elif args.model == "vit_huge":
+        from avsiam_amd.config import vit_huge
+        cfg = vit_huge(audio_tokens=args.audio_tokens, frames=args.frames)
     else:
         cfg = AVSiamConfig(audio_tokens=args.audio_tokens, frames=args.frames)
-    mname = "ViT-B/16" if args.model == "vit_base" else "ViT-L/16"
+    mname = {"vit_base": "ViT-B/16", "vit_large": "ViT-L/16", "vit_huge": "ViT-H/16 (1280 wide, 32 layers, 16 heads of 80)"}[args.model]
     torch.manual_seed(87 + rank)
     log(f"building model (frames={args.frames}, batch={args.batch}/GPU, world={world})")
     model = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)

@@ -206,3 +206,25 @@ def test_vit_large_matches_oracle(which):
     for i in (0, 1, 2, 3, 4):
         assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
     _compare_grads(m, rgrads, cos_min=0.9998, ratio_tol=0.02, tag=f"vit_large_{which}")
+
+
+@pytest.mark.parametrize("which", ["mae", "contrastive"])
+def test_vit_huge_width_matches_oracle(which):
+    """BASELINE.json configs[4]'s encoder width in bf16: 1280 wide, 16 heads of 80 (the hd-80 attention instantiation: a 96-wide LDS
+    image, five contraction steps), MLP 5120 - here 4 layers deep at a small shape (2 frames, 128 audio tokens, batch 2) against the
+    oracle.  16 x 16 patches (not /14), no fp8."""
+    from avsiam_amd.config import vit_huge
+    import random
+    cfg = vit_huge(audio_tokens=128, frames=2, depth=4)
+    B = 2
+    a, v = synth_inputs(cfg, B, 19)
+    gen = torch.Generator().manual_seed(4)
+    mae = which == "mae"
+    plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(4))
+    m = _model(cfg, 98)
+    out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
+    out[0].backward()
+    ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 98)
+    for i in (0, 1, 2, 3, 4):
+        assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+    _compare_grads(m, rgrads, cos_min=0.9998, ratio_tol=0.02, tag=f"vit_huge_{which}")
