@@ -31,6 +31,12 @@ BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
 LN_EPS_BLOCK, LN_EPS_FINAL = 1e-5, 1e-6       # nn.LayerNorm default in Block; timm ViT final norm
 
 
+# Per-layer activation recompute (AVSIAM_RECOMPUTE=1 / bench.py --recompute): a Stack keeps only the fp32 input of every block and
+# re-runs the block's forward (without its last GEMM) in front of the block's backward.  For shapes whose saved activations do not fit
+# 288 GB (ViT-H at batch 64 x 10 frames); costs about 8/12 of the forward GEMMs plus the attention forward again.
+RECOMPUTE = os.environ.get("AVSIAM_RECOMPUTE", "0")
+
+
 def _z(shape, dtype, dev):
     return torch.zeros(shape, dtype=dtype, device=dev)
 
@@ -169,6 +175,7 @@ class Stack:
         self.rows, self.D, self.H, self.hidden, self.nblocks = rows, D, H, hidden, nblocks
         self.row_mod = row_mod
         self.inference = inference
+        self.recompute = RECOMPUTE == "1" and not inference
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
         # rows per attention workgroup (4 or 2 waves of 32 queries / keys), by the mean sequence length of the stack - measured on the
@@ -183,7 +190,7 @@ class Stack:
         self.q_scale = ops.attn_q_scale(D // H)          # q leaves the qkv GEMM ready for the attention kernels
 
         def per_block(shape, dtype):
-            if inference:
+            if inference or self.recompute:                   # one buffer for all blocks (recompute: refilled in front of each block's backward)
                 one = _z(shape, dtype, dev)
                 return [one] * nblocks
             return [_z(shape, dtype, dev) for _ in range(nblocks)]
@@ -201,8 +208,9 @@ class Stack:
         self.fc1 = per_block((rp, hidden), BF16)          # gelu'(fc1 output): all the backward needs of the pre-activation (gemm act 1 / 2)
         self.act = per_block((rp, hidden), BF16)
         self.lse = per_block((H, rp), F32)
-        st = [_z((rp,), F32, dev) for _ in range(4)] if inference else None
-        self.stats = [st if inference else [_z((rp,), F32, dev) for _ in range(4)] for _ in range(nblocks)]   # mean1 rstd1 mean2 rstd2
+        shared = inference or self.recompute
+        st = [_z((rp,), F32, dev) for _ in range(4)] if shared else None
+        self.stats = [st if shared else [_z((rp,), F32, dev) for _ in range(4)] for _ in range(nblocks)]   # mean1 rstd1 mean2 rstd2
         if inference:
             return
         # backward scratch (shared by all blocks)
@@ -223,22 +231,27 @@ class Stack:
         """blocks2 / split: rows [split, rows) run through a SECOND set of blocks (the MAE pass's visual tower next to its
         audio tower, cav_mae_base.py:487,489) in the same launches - every GEMM takes both weight sets
         (ops.gemm_nt(dual=...)), the LayerNorm picks the affine per row (row_mod: 0 below split, 1 from it)."""
-        M = self.rows
         for i, bp in enumerate(blocks):
-            x, st = self.x[i], self.stats[i]
-            b2 = blocks2[i] if blocks2 is not None else None
-            n1 = bp.n1 if b2 is None else [bp.n1[0], b2.n1[0]]
-            n2 = bp.n2 if b2 is None else [bp.n2[0], b2.n2[0]]
-            dq = dp = d1 = d2 = None
-            if b2 is not None:
-                dq, dp = (split, b2.qkv.w, b2.qkv.b, None), (split, b2.proj.w, b2.proj.b, None)
-                d1, d2 = (split, b2.fc1.w, b2.fc1.b, None), (split, b2.fc2.w, b2.fc2.b, None)
-            _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
-            ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq)
-            ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i])
-            ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x, dual=dp)
-            _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)
-            ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1)
+            self._block_forward(i, bp, blocks2[i] if blocks2 is not None else None, split)
+
+    def _block_forward(self, i, bp, b2, split, last_gemm=True):
+        """Block i: x[i] -> x[i + 1] and everything its backward reads.  last_gemm=False (recompute in front of the backward): x[i + 1]
+        is not needed again, the fc2 GEMM is skipped."""
+        M = self.rows
+        x, st = self.x[i], self.stats[i]
+        n1 = bp.n1 if b2 is None else [bp.n1[0], b2.n1[0]]
+        n2 = bp.n2 if b2 is None else [bp.n2[0], b2.n2[0]]
+        dq = dp = d1 = d2 = None
+        if b2 is not None:
+            dq, dp = (split, b2.qkv.w, b2.qkv.b, None), (split, b2.proj.w, b2.proj.b, None)
+            d1, d2 = (split, b2.fc1.w, b2.fc1.b, None), (split, b2.fc2.w, b2.fc2.b, None)
+        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
+        ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq)
+        ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i])
+        ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x, dual=dp)
+        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)
+        ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1)
+        if last_gemm:
             ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2)
 
     def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0, reducer=None):
@@ -256,7 +269,9 @@ class Stack:
         dbo, dbm = self.dxb
         ranges = [(0, M, blocks)] if blocks2 is None else [(0, split, blocks), (split, M, blocks2)]
         one = blocks2 is not None                # a row range has ONE affine set; the packed single-tower case selects by row_mod
-        mode = WGRAD_STREAM_MODE
+        # recompute: the blocks share ONE set of activation buffers, refilled in front of every block's backward - weight-gradient GEMMs
+        # still reading them on a second stream would race with the refill, so everything runs on one stream
+        mode = "0" if self.recompute else WGRAD_STREAM_MODE
         side = _side_stream(dxo.device) if mode in ("1", "2") else _Inline()
         excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
 
@@ -278,6 +293,8 @@ class Stack:
         for i in reversed(range(self.nblocks)):
             bp, st = blocks[i], self.stats[i]
             b2 = blocks2[i] if blocks2 is not None else None
+            if self.recompute:
+                self._block_forward(i, bp, b2, split, last_gemm=False)
             # fc2: d(gelu out) fused with GELU' -> d(fc1 pre-activation)
             if excl:
                 side.join()

@@ -157,6 +157,8 @@ def main():
                     help="vit_base = BASELINE.json's metric (configs[1]); vit_large = configs[3]'s shape, vit_huge = configs[4]'s encoder width in bf16 "
                          "on 16x16 patches (use --batch 32: saved activations of batch 64 x 10 frames exceed 288 GB) - extra data points")
     ap.add_argument("--lr", type=float, default=2e-4)
+    ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved "
+                    "activations do not fit the GPU, e.g. --model vit_huge at batch 64; never for the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=2, help="steps of the separate single-stream pass that times the other kernel families")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -198,6 +200,9 @@ def main():
     mname = {"vit_base": "ViT-B/16", "vit_large": "ViT-L/16", "vit_huge": "ViT-H/16 (1280 wide, 32 layers, 16 heads of 80)"}[args.model]
     torch.manual_seed(87 + rank)
     log(f"building model (frames={args.frames}, batch={args.batch}/GPU, world={world})")
+    if args.recompute:
+        from avsiam_amd import engine as _engine
+        _engine.RECOMPUTE = "1"
     model = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
     model.set_distributed(world, rank)
     model.publish_grads = False
@@ -259,7 +264,7 @@ def main():
             "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x196 + "
                                    f"{args.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": args.audio_tokens,
-                       "parallelism": f"dp{world}", "gflop_per_sample": gf},
+                       "parallelism": f"dp{world}", "gflop_per_sample": gf, **({"activation_recompute": True} if args.recompute else {})},
             "model_tflops": sps * gf / 1e3, "mfu_vs_dense_bf16_peak": sps * gf / 1e3 / (world * PEAK_BF16_TFLOPS),
             "final_losses": {"loss_mae": losses[0], "loss_mae_a": losses[1], "loss_mae_v": losses[2], "loss_c": losses[3], "c_acc": losses[4]},
         }

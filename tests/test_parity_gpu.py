@@ -228,3 +228,37 @@ def test_vit_huge_width_matches_oracle(which):
     for i in (0, 1, 2, 3, 4):
         assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
     _compare_grads(m, rgrads, cos_min=0.9998, ratio_tol=0.02, tag=f"vit_huge_{which}")
+
+
+@pytest.mark.parametrize("which", ["mae", "contrastive"])
+def test_recompute_matches_saved_activations(which):
+    """engine.RECOMPUTE: every Stack keeps only its blocks' fp32 inputs and re-runs a block's forward in front of its backward.  The
+    kernels are deterministic, so the loss is bitwise the same and the gradients differ only by the order of the fp32 atomics of the
+    weight-gradient GEMMs."""
+    import random
+    from avsiam_amd import engine
+    cfg = AVSiamConfig(audio_tokens=128, frames=2)
+    B = 3
+    a, v = synth_inputs(cfg, B, 23)
+    gen = torch.Generator().manual_seed(6)
+    mae = which == "mae"
+    plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(6))
+    res = []
+    try:
+        for rec in ("0", "1"):
+            engine.RECOMPUTE = rec
+            m = _model(cfg, 97)
+            out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
+            out[0].backward()
+            torch.cuda.synchronize()
+            res.append((out[0].item(), {k: p.grad.detach().double().cpu() for k, p in m._params.items() if p.grad is not None}))
+    finally:
+        engine.RECOMPUTE = "0"
+    assert res[0][0] == res[1][0]
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 100
+    worst = 0.0
+    for k, g0 in res[0][1].items():
+        g1 = res[1][1][k]
+        if float(g0.norm()) > 0:
+            worst = max(worst, float((g1 - g0).norm() / g0.norm()))
+    assert worst < 1e-5, worst
