@@ -346,6 +346,59 @@ extern "C" int avs_scatter_add_rows(const bf16_t* src, const int* idx, float* ds
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) operand preparation for avs_gemm_nt_fp8: |x| maximum of a tensor (the host derives the per-tensor scale 448 / amax
+// from it - delayed scaling reads it a step later, calibration reads it at once) and y = e4m3(clamp(x * scale, +-448)).
+__global__ void absmax_kernel(const void* __restrict__ x, int is_f32, size_t n8, size_t n, float* out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t e = i * 8 + j;
+            if (e < n) m = fmaxf(m, fabsf(is_f32 ? reinterpret_cast<const float*>(x)[e] : bf2f(reinterpret_cast<const bf16_t*>(x)[e])));
+        }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));      // non-negative floats order like their bit patterns
+}
+
+__global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint8_t* __restrict__ y, size_t n4, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float v[4];
+        if (is_f32) {
+            const float4 f = reinterpret_cast<const float4*>(x)[i];
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+            const uint2 u = reinterpret_cast<const uint2*>(x)[i];
+            v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+            v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * scale, -448.0f, 448.0f);
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+        reinterpret_cast<int*>(y)[i] = w;
+    }
+}
+
+extern "C" int avs_absmax(const void* x, int is_f32, long long n, float* out, hipStream_t stream) {
+    AVS_CHECK_ARG(x && out && n > 0, "absmax: bad args");
+    const size_t n8 = ((size_t)n + 7) / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+    absmax_kernel<<<blocks, 256, 0, stream>>>(x, is_f32, n8, (size_t)n, out);
+    AVS_LAUNCH_CHECK("absmax");
+    return 0;
+}
+
+extern "C" int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, hipStream_t stream) {
+    AVS_CHECK_ARG(x && y && n > 0 && (n % 4) == 0, "quantize_fp8: n must be a multiple of 4");
+    const size_t n4 = (size_t)n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    quantize_fp8_kernel<<<blocks, 256, 0, stream>>>(x, is_f32, y, n4, scale);
+    AVS_LAUNCH_CHECK("quantize_fp8");
+    return 0;
+}
+
 extern "C" int avs_colsum_bf16(const bf16_t* x, float* out, int rows, int C, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && (C % 64) == 0 && x && out, "colsum: C must be a multiple of 64");
     dim3 grid(C / 64, ceil_div(rows, COLSUM_ROWS));

@@ -438,7 +438,12 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("" ::: "memory");
 }
 
-template <int ACT>
+// FP8 = 1 (avs_gemm_nt_fp8): the operands are OCP fp8 (e4m3) instead of bf16.  Byte for byte the kernel is the same - an fp8
+// matrix [M, K8] with leading dimension lda8 is handed over as the bf16 matrix [M, K8 / 2] / lda8 / 2 it aliases, so tiles, DMA
+// granules, waits and the epilogue do not change; a 128-byte K-tile row then holds 128 contraction values instead of 64, each
+// lane's two 16-byte fragment chunks are the ADJACENT chunks 2g, 2g + 1 of its row (lane group g: 32 consecutive values) instead of
+// chunks g and 4 + g, and a phase issues 8 v_mfma_f32_16x16x128_f8f6f4 (32 cycles each) instead of 16 v_mfma_f32_16x16x32_bf16.
+template <int ACT, int FP8 = 0>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
     constexpr int NT = 512, TBM = 256, TBN = 256, MI = 8;
     constexpr int A_BYTES = TBM * 128, BUF_BYTES = 2 * A_BYTES, GR = 16384;     // per K-tile buffer: [A 32 KiB | B 32 KiB]
@@ -449,8 +454,8 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
     const int nt_n = a.N / TBN;
     const int ntiles = ((a.M + TBM - 1) / TBM) * nt_n;
     const int fr = lane & 15, fq = lane >> 4;
-    const int off_k0 = fr * 128 + (((0 + fq) ^ (lane & 7)) << 4);
-    const int off_k1 = fr * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    const int off_k0 = fr * 128 + (((FP8 ? 2 * fq : 0 + fq) ^ (lane & 7)) << 4);
+    const int off_k1 = fr * 128 + (((FP8 ? 2 * fq + 1 : 4 + fq) ^ (lane & 7)) << 4);
     const int nk = a.K / BK;
     const unsigned lds_base = (unsigned)(size_t)(LDS_AS const char*)smem;
 
@@ -551,14 +556,31 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
                     for (int mb = 0; mb < 2; ++mb)
                         acc16[bh][ah][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[bh][kq >> 1][kq & 1], xf[mb * 2 + (kq >> 1)][kq & 1], acc16[bh][ah][mb], 0, 0, 0);
 #else
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                if (FP8) {
+                    typedef __attribute__((ext_vector_type(8))) int i32x8;
+                    typedef __attribute__((ext_vector_type(4))) int i32x4;
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const i32x4 w0 = __builtin_bit_cast(i32x4, wb[bh][ni][0]), w1 = __builtin_bit_cast(i32x4, wb[bh][ni][1]);
+                            const i32x4 x0 = __builtin_bit_cast(i32x4, xf[mi][0]), x1 = __builtin_bit_cast(i32x4, xf[mi][1]);
+                            const i32x8 wv = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                            const i32x8 xv = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                            // cbsz = blgp = 0: both operands e4m3; scale selectors 0 = the unscaled instruction
                             acc[bh * 2 + ni][ah * 4 + mi] =
-                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[bh][ni][kk], xf[mi][kk], acc[bh * 2 + ni][ah * 4 + mi], 0, 0, 0);
+                                __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv, acc[bh * 2 + ni][ah * 4 + mi], 0, 0, 0, 0, 0, 0);
+                        }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni)
+                                acc[bh * 2 + ni][ah * 4 + mi] =
+                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[bh][ni][kk], xf[mi][kk], acc[bh * 2 + ni][ah * 4 + mi], 0, 0, 0);
+                }
 #endif
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -620,7 +642,18 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
         for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(acc16[i >> 2][(i >> 1) & 1][i & 1]));
 #endif
 #else
-        nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
+        if (FP8) {
+            // the de-quantisation factor belongs to the product alone (the shared epilogue's alpha also scales bias and residual)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) acc[i][j] *= a.alpha;
+            GemmNtArgs e = a;
+            e.alpha = 1.0f;
+            nt_epilogue<ACT, MI>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
+        } else {
+            nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
+        }
 #endif
         // a compiler-visible full drain: the K loop reuses registers the epilogue loaded into, and hipcc would otherwise
         // re-wait for those loads (vmcnt(0)) at the head of EVERY K-tile.  The next tile's first wait drains the stores anyway.
@@ -1026,6 +1059,37 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
                                 float alpha, int act, int scale_cols, float col_scale, float* colsum, hipStream_t stream) {
     return gemm_nt_launch(A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols,
                           col_scale, colsum, 0x7fffffff, nullptr, nullptr, nullptr, stream);
+}
+
+// fp8 (OCP e4m3) operands, fp32 accumulation, the act-0 epilogue of the bf16 GEMM (alpha, bias, fp32 residual, bf16 or fp32 output).
+// out = alpha * (A8 . B8^T) + bias (+ res); alpha carries the product of the two de-quantisation scales.
+extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long ldb, int M, int N, int K, const float* bias,
+                               const float* res, long long ldr, void* out, long long ldo, int out_f32, float alpha, hipStream_t stream) {
+    AVS_CHECK_ARG(M > 0 && N > 0 && K >= 256 && (N % 256) == 0 && (K % 128) == 0, "gemm_nt_fp8: need N%%256==0, K%%128==0, K>=256 (M=%d N=%d K=%d)", M, N, K);
+    AVS_CHECK_ARG(A && B && out && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && (ldo % (out_f32 ? 4 : 8)) == 0,
+                  "gemm_nt_fp8: operands must keep 16-byte alignment");
+    AVS_CHECK_ARG(!res || out_f32, "gemm_nt_fp8: the residual add is implemented for fp32 output");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt8_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) {
+            avs_set_error("gemm_nt_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return -1;
+        }
+        attr_done = true;
+    }
+    // the fp8 matrices as the bf16 matrices they alias (see gemm_nt8_kernel): half the columns, half the leading dimension
+    GemmNtArgs a{reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, M, N, K / 2, bias, res, ldr, nullptr, nullptr, 0,
+                 out, ldo, out_f32, nullptr, 0, alpha, 0, 0, 1.0f, nullptr, M, 0x7fffffff, nullptr, nullptr, nullptr};
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    const int tiles = ceil_div(M, 256) * (N / 256);
+    gemm_nt8_kernel<0, 1><<<tiles < ncu ? tiles : ncu, 512, 131072, stream>>>(a);
+    AVS_LAUNCH_CHECK("gemm_nt_fp8");
+    return 0;
 }
 
 extern "C" int avs_gemm_nt_bf16_dual(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,

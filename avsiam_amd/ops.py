@@ -170,6 +170,36 @@ def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None
         _launch("gemm_nt_act%d" % act, 2.0 * M * N * K, "avs_gemm_nt_bf16_dual", *args, int(m_split), B2, bias2, colsum2, _stream())
 
 
+FP8_MAX = 448.0          # largest finite OCP e4m3 value
+
+
+def absmax(x):
+    """max |x| of a fp32 / bf16 GPU tensor, as a python float (synchronises: calibration / tests; a training loop would keep it on the device)"""
+    assert x.is_cuda and x.is_contiguous() and x.dtype in (F32, BF16)
+    out = torch.zeros(1, device=x.device)
+    _lib.call("avs_absmax", x, 1 if x.dtype == F32 else 0, x.numel(), out, _stream())
+    return float(out.item())
+
+
+def quantize_fp8(x, scale, out=None):
+    """x (fp32 / bf16, contiguous) -> uint8 tensor holding OCP e4m3 of clamp(x * scale, +-448)"""
+    assert x.is_cuda and x.is_contiguous() and x.dtype in (F32, BF16) and x.numel() % 4 == 0
+    y = out if out is not None else torch.empty(x.shape, dtype=U8, device=x.device)
+    assert y.dtype == U8 and y.numel() == x.numel() and y.is_contiguous()
+    _lib.call("avs_quantize_fp8", x, 1 if x.dtype == F32 else 0, y, x.numel(), float(scale), _stream())
+    return y
+
+
+def gemm_nt_fp8(A8, B8, out, M, alpha, bias=None, res=None):
+    """out[M, N] = alpha * (A8[M, K] @ B8[N, K]^T) + bias (+ res); A8 / B8 uint8 tensors of e4m3 values (quantize_fp8), alpha = 1 / (scale_A * scale_B)"""
+    _chk(A8, U8, "gemm8.A", 2); _chk(B8, U8, "gemm8.B", 2); _chk(bias, F32, "gemm8.bias"); _chk(res, F32, "gemm8.res", 2)
+    assert out.dtype in (BF16, F32) and out.dim() == 2 and out.is_contiguous()
+    N, K = B8.shape
+    assert A8.shape[1] == K and A8.shape[0] >= M and out.shape[0] >= M and out.shape[1] == N
+    _launch("gemm_nt_fp8", 2.0 * M * N * K, "avs_gemm_nt_fp8", A8, A8.stride(0), B8, B8.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
+            out, out.stride(0), 1 if out.dtype == F32 else 0, float(alpha), _stream())
+
+
 def gemm_tn(A, B, C, M, splits=0):
     """C[N1,N2] += A[M,N1]^T @ B[M,N2]; A/B zero-padded to a multiple of 64 rows."""
     _chk(A, BF16, "wgrad.A", 2); _chk(B, BF16, "wgrad.B", 2); _chk(C, F32, "wgrad.C")

@@ -574,3 +574,34 @@ def test_input_normalisation_matches_dataloader_formulas():
     mean = torch.tensor(pp.IMAGENET_DEFAULT_MEAN, device=DEV).view(1, 1, 3, 1, 1)
     std = torch.tensor(pp.IMAGENET_DEFAULT_STD, device=DEV).view(1, 1, 3, 1, 1)
     assert torch.allclose(got, (fr.float() / 255 - mean) / std, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,f32out", [(256, 256, 256, True), (1000, 768, 768, False), (4099, 1280, 5120, True), (70000, 768, 3072, False)])
+def test_gemm_nt_fp8(M, N, K, f32out):
+    """The fp8 (OCP e4m3) variant of the 8-phase GEMM (BASELINE configs[4]'s fp8 MFMA path).  (1) Layout / arithmetic: against an fp64
+    product of the DE-quantised operands the result is exact up to fp32 accumulation.  (2) Its own tolerance against the bf16 GEMM of the
+    unquantised operands: e4m3 keeps 3 mantissa bits (relative rounding error up to 2^-4), which on random operands gives ~4 % relative L2."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.05
+    b = torch.randn(N, device=DEV, generator=g)
+    sa, sw = o.FP8_MAX / o.absmax(A), o.FP8_MAX / o.absmax(W)
+    assert abs(o.FP8_MAX / sa - A.abs().max().item()) < 1e-6
+    Mp = o.pad_rows(M, 256)
+    A8 = torch.zeros(Mp, K, device=DEV, dtype=torch.uint8)
+    o.quantize_fp8(A, sa, out=A8[:M])
+    W8 = o.quantize_fp8(W.to(torch.bfloat16), sw)                       # bf16 source: the weight shadows
+    # the encoding is OCP e4m3 (torch.float8_e4m3fn) and the rounding is to nearest
+    Ad = A8[:M].view(torch.float8_e4m3fn).double() / sa
+    Wd = W8.view(torch.float8_e4m3fn).double() / sw
+    assert torch.equal(A8[:M].view(torch.float8_e4m3fn), (A * sa).clamp(-448, 448).to(torch.float8_e4m3fn))
+    res = torch.randn(Mp, N, device=DEV, generator=g) if f32out else None
+    out = torch.zeros(Mp, N, device=DEV, dtype=torch.float32 if f32out else torch.bfloat16)
+    o.gemm_nt_fp8(A8, W8, out, M, 1.0 / (sa * sw), bias=b, res=res)
+    ref = Ad @ Wd.t() + b.double() + (res[:M].double() if f32out else 0)
+    assert rel_err(out[:M], ref) < (5e-5 if f32out else 3e-3)            # fp32 accumulation over up to 5120 terms (measured 1.4e-5); bf16 output: its own rounding
+    assert Mp == M or out[M:].abs().max().item() == 0
+    full = A.double() @ W.to(torch.bfloat16).double().t() + b.double() + (res[:M].double() if f32out else 0)
+    e = rel_err(out[:M], full)
+    assert 5e-3 < e < 8e-2, e
