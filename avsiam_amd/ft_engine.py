@@ -17,7 +17,7 @@ import torch
 from . import ops
 from .arena import ParamArena
 from .config import AVSiamConfig
-from .engine import BF16, F32, I32, U8, LN_EPS_BLOCK, LN_EPS_FINAL, BlockParams, Norm, PatchEmbedder, Stack, _fold_frames, _ln_fwd, _z
+from .engine import BF16, F32, I32, U8, LN_EPS_BLOCK, LN_EPS_FINAL, BlockParams, Norm, PatchEmbedder, Stack, _ln_fwd, _z
 
 EVAL_FRAMES = 10        # `for t_idx in range(10)` at cav_mae_base.py:940
 

@@ -78,7 +78,7 @@ SMALL = dict(embed_dim=128, depth=2, num_heads=2, dec_dim=64, dec_depth=1, dec_h
 def _dp_worker(rank, world, port, q):
     try:
         from oracle import ref_cpu
-        from avsiam_amd.maskplan import ContrastivePlan, make_contrastive_plan
+        from avsiam_amd.maskplan import make_contrastive_plan
         from avsiam_amd.models import CAVMAE_BASE
         from avsiam_amd.param_spec import P1
         _init(rank, world, port)

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 from avsiam_amd.config import AVSiamConfig
 from avsiam_amd.weights import synth_inputs
-from tests.helpers import golden_grads, golden_plan, load_golden
+from tests.helpers import golden_plan, load_golden
 
 pytestmark = pytest.mark.gpu
 

@@ -19,7 +19,7 @@ from avsiam_amd.config import AVSiamConfig
 from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
 from avsiam_amd.param_spec import build_spec
 from avsiam_amd.weights import synth_inputs, synth_state
-from tests.helpers import golden_grads, golden_plan, gpu_grads_vs_golden, load_golden, record_margin, sample_positions
+from tests.helpers import golden_plan, gpu_grads_vs_golden, load_golden, record_margin
 
 pytestmark = pytest.mark.gpu
 
