@@ -1,7 +1,6 @@
 """CPU-side checks of the C-ABI boundary: the library builds, loads, and exports every symbol that
 include/avsiam_hip.h declares (no compute calls - there is no GPU here)."""
 import ctypes
-import os
 
 import pytest
 

@@ -6,8 +6,6 @@ import argparse
 import os
 import sys
 
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avsiam_amd.config import AVSiamConfig  # noqa: E402
 from avsiam_amd.models import CAVMAE_BASE  # noqa: E402
