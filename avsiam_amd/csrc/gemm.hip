@@ -1061,17 +1061,22 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
                           col_scale, colsum, 0x7fffffff, nullptr, nullptr, nullptr, stream);
 }
 
-// fp8 (OCP e4m3) operands, fp32 accumulation, the act-0 epilogue of the bf16 GEMM (alpha, bias, fp32 residual, bf16 or fp32 output).
-// out = alpha * (A8 . B8^T) + bias (+ res); alpha carries the product of the two de-quantisation scales.
+// fp8 (OCP e4m3) operands, fp32 accumulation, the epilogues of the bf16 GEMM for act 0 (alpha, bias, fp32 residual, column-range scale,
+// bf16 or fp32 output) and act 1 (GELU pair: out = gelu'(x), out2 = gelu(x), both bf16).
+// x = alpha * (A8 . B8^T) + bias (+ res); alpha carries the product of the two de-quantisation scales.
 extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long ldb, int M, int N, int K, const float* bias,
-                               const float* res, long long ldr, void* out, long long ldo, int out_f32, float alpha, hipStream_t stream) {
+                               const float* res, long long ldr, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2, float alpha,
+                               int act, int scale_cols, float col_scale, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && N > 0 && K >= 256 && (N % 256) == 0 && (K % 128) == 0, "gemm_nt_fp8: need N%%256==0, K%%128==0, K>=256 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && (ldo % (out_f32 ? 4 : 8)) == 0,
                   "gemm_nt_fp8: operands must keep 16-byte alignment");
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt_fp8: the residual add is implemented for fp32 output");
+    AVS_CHECK_ARG((act == 0 && !out2) || (act == 1 && out2 && !out_f32 && (ldo2 % 8) == 0), "gemm_nt_fp8: act 0, or act 1 with a bf16 output pair");
+    AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt_fp8: scale_cols must be a multiple of 64 within N");
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_nt8_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt8_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (e != hipSuccess) {
             avs_set_error("gemm_nt_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return -1;
@@ -1080,14 +1085,16 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
     }
     // the fp8 matrices as the bf16 matrices they alias (see gemm_nt8_kernel): half the columns, half the leading dimension
     GemmNtArgs a{reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, M, N, K / 2, bias, res, ldr, nullptr, nullptr, 0,
-                 out, ldo, out_f32, nullptr, 0, alpha, 0, 0, 1.0f, nullptr, M, 0x7fffffff, nullptr, nullptr, nullptr};
+                 out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, nullptr, M, 0x7fffffff, nullptr, nullptr, nullptr};
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     }
     const int tiles = ceil_div(M, 256) * (N / 256);
-    gemm_nt8_kernel<0, 1><<<tiles < ncu ? tiles : ncu, 512, 131072, stream>>>(a);
+    const int grid = tiles < ncu ? tiles : ncu;
+    if (act == 0) gemm_nt8_kernel<0, 1><<<grid, 512, 131072, stream>>>(a);
+    else gemm_nt8_kernel<1, 1><<<grid, 512, 131072, stream>>>(a);
     AVS_LAUNCH_CHECK("gemm_nt_fp8");
     return 0;
 }

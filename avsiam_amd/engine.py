@@ -35,6 +35,11 @@ LN_EPS_BLOCK, LN_EPS_FINAL = 1e-5, 1e-6       # nn.LayerNorm default in Block; t
 # re-runs the block's forward (without its last GEMM) in front of the block's backward.  For shapes whose saved activations do not fit
 # 288 GB (ViT-H at batch 64 x 10 frames); costs about 8/12 of the forward GEMMs plus the attention forward again.
 RECOMPUTE = os.environ.get("AVSIAM_RECOMPUTE", "0")
+# fp8 forward (AVSIAM_FP8=1 / bench.py --fp8; BASELINE configs[4]'s "fp8 MFMA path", never the default): the four forward GEMMs of a
+# block (qkv, proj, fc1, fc2) take OCP e4m3 operands - the bf16 activation and the bf16 weight shadow are quantised right in front of the
+# GEMM with a per-tensor scale fixed at first use (448 / (2 * amax): static scaling with a 2x margin, saturating) - and accumulate in
+# fp32; everything the backward reads is still produced in bf16 and the backward itself is the bf16 one.
+FP8 = os.environ.get("AVSIAM_FP8", "0")
 
 
 def _z(shape, dtype, dev):
@@ -176,6 +181,11 @@ class Stack:
         self.row_mod = row_mod
         self.inference = inference
         self.recompute = RECOMPUTE == "1" and not inference
+        self.fp8 = FP8 == "1" and D % 256 == 0 and hidden % 256 == 0 and D >= 256     # the fp8 GEMM's tile constraints (N % 256, K % 128)
+        if self.fp8:
+            self.a8 = torch.empty((ops.pad_rows(rows, 256), max(D, hidden)), dtype=U8, device=dev)     # the activation in front of a GEMM
+            self.w8 = torch.empty((max(3 * D, hidden) * max(D, hidden),), dtype=U8, device=dev)          # that GEMM's weight
+            self.fp8_scale = {}                                                                          # (block, tensor) -> scale, fixed at first use
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
         # rows per attention workgroup (4 or 2 waves of 32 queries / keys), by the mean sequence length of the stack - measured on the
@@ -245,14 +255,32 @@ class Stack:
         if b2 is not None:
             dq, dp = (split, b2.qkv.w, b2.qkv.b, None), (split, b2.proj.w, b2.proj.b, None)
             d1, d2 = (split, b2.fc1.w, b2.fc1.b, None), (split, b2.fc2.w, b2.fc2.b, None)
+        gemm = self._gemm_fp8 if self.fp8 and b2 is None else self._gemm_bf16
         _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
-        ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq)
+        gemm((i, "qkv"), self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq)
         ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i])
-        ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x, dual=dp)
+        gemm((i, "proj"), self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x, dual=dp)
         _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)
-        ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1)
+        gemm((i, "fc1"), self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1)
         if last_gemm:
-            ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2)
+            gemm((i, "fc2"), self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2)
+
+    @staticmethod
+    def _gemm_bf16(key, A, W, out, M, dual=None, **kw):
+        ops.gemm_nt(A, W, out, M, dual=dual, **kw)
+
+    def _gemm_fp8(self, key, A, W, out, M, dual=None, **kw):
+        """The same forward GEMM on e4m3 copies of its operands (module comment at FP8)."""
+        assert dual is None
+        K, N = A.shape[1], W.shape[0]
+        sc = self.fp8_scale.get(key)
+        if sc is None:                                            # first use: per-tensor amax (synchronises once per tensor)
+            sc = self.fp8_scale[key] = (ops.FP8_MAX / (2.0 * max(ops.absmax(A), 1e-12)), ops.FP8_MAX / (2.0 * max(ops.absmax(W), 1e-12)))
+        a8 = self.a8[:A.shape[0], :K] if self.a8.shape[1] == K else self.a8.view(-1)[:A.shape[0] * K].view(A.shape[0], K)
+        w8 = self.w8[:N * K].view(N, K)
+        ops.quantize_fp8(A, sc[0], out=a8)
+        ops.quantize_fp8(W, sc[1], out=w8)
+        ops.gemm_nt_fp8(a8, w8, out, M, 1.0 / (sc[0] * sc[1]), **kw)
 
     def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0, reducer=None):
         """In: d(out) in self.dx[0] (fp32) and self.dxb[0] (bf16).  Out: d(x[0]) in the same two buffers.

@@ -190,14 +190,16 @@ def quantize_fp8(x, scale, out=None):
     return y
 
 
-def gemm_nt_fp8(A8, B8, out, M, alpha, bias=None, res=None):
-    """out[M, N] = alpha * (A8[M, K] @ B8[N, K]^T) + bias (+ res); A8 / B8 uint8 tensors of e4m3 values (quantize_fp8), alpha = 1 / (scale_A * scale_B)"""
-    _chk(A8, U8, "gemm8.A", 2); _chk(B8, U8, "gemm8.B", 2); _chk(bias, F32, "gemm8.bias"); _chk(res, F32, "gemm8.res", 2)
+def gemm_nt_fp8(A8, B8, out, M, alpha, bias=None, res=None, out2=None, act=0, scale_cols=0, col_scale=1.0):
+    """x = alpha * (A8[M, K] @ B8[N, K]^T) + bias (+ res); act 0: out = x; act 1: out = gelu'(x), out2 = gelu(x) (like gemm_nt).
+    A8 / B8: uint8 tensors of e4m3 values (quantize_fp8), alpha = 1 / (scale_A * scale_B)."""
+    _chk(A8, U8, "gemm8.A", 2); _chk(B8, U8, "gemm8.B", 2); _chk(bias, F32, "gemm8.bias"); _chk(res, F32, "gemm8.res", 2); _chk(out2, BF16, "gemm8.out2", 2)
     assert out.dtype in (BF16, F32) and out.dim() == 2 and out.is_contiguous()
     N, K = B8.shape
     assert A8.shape[1] == K and A8.shape[0] >= M and out.shape[0] >= M and out.shape[1] == N
     _launch("gemm_nt_fp8", 2.0 * M * N * K, "avs_gemm_nt_fp8", A8, A8.stride(0), B8, B8.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
-            out, out.stride(0), 1 if out.dtype == F32 else 0, float(alpha), _stream())
+            out, out.stride(0), 1 if out.dtype == F32 else 0, out2, out2.stride(0) if out2 is not None else 0, float(alpha), int(act), int(scale_cols),
+            float(col_scale), _stream())
 
 
 def gemm_tn(A, B, C, M, splits=0):

@@ -157,6 +157,8 @@ def main():
                     help="vit_base = BASELINE.json's metric (configs[1]); vit_large = configs[3]'s shape, vit_huge = configs[4]'s encoder width in bf16 "
                          "on 16x16 patches (use --batch 32: saved activations of batch 64 x 10 frames exceed 288 GB) - extra data points")
     ap.add_argument("--lr", type=float, default=2e-4)
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) forward GEMMs (engine.FP8): configs[4]'s fp8 MFMA path as an extra data point; "
+                    "the line then says dtype fp8-forward/bf16-backward and is NOT the headline metric")
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved "
                     "activations do not fit the GPU, e.g. --model vit_huge at batch 64; never for the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -200,9 +202,12 @@ def main():
     mname = {"vit_base": "ViT-B/16", "vit_large": "ViT-L/16", "vit_huge": "ViT-H/16 (1280 wide, 32 layers, 16 heads of 80)"}[args.model]
     torch.manual_seed(87 + rank)
     log(f"building model (frames={args.frames}, batch={args.batch}/GPU, world={world})")
-    if args.recompute:
+    if args.recompute or args.fp8:
         from avsiam_amd import engine as _engine
-        _engine.RECOMPUTE = "1"
+        if args.recompute:
+            _engine.RECOMPUTE = "1"
+        if args.fp8:
+            _engine.FP8 = "1"
     model = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
     model.set_distributed(world, rank)
     model.publish_grads = False
@@ -260,7 +265,7 @@ def main():
         line = {
             "metric": f"AV pretrain samples/sec ({mname}, 75% mask)", "value": sps, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "fp8(e4m3)-forward/bf16-backward" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x196 + "
                                    f"{args.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": args.audio_tokens,

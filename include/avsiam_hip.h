@@ -56,12 +56,14 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
                      long long ldaux, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
                      int act, int scale_cols, float col_scale, float* colsum, avs_stream_t stream);
 /* ---- fp8 (OCP e4m3) variant of the forward / input-gradient GEMM (BASELINE configs[4]'s "fp8 MFMA path"; not used by the default
- * bf16 path): out = alpha * (A8[M,K] . B8[N,K]^T) + bias (+ res, fp32 output only), fp32 accumulation on v_mfma_f32_16x16x128_f8f6f4,
+ * bf16 path): x = alpha * (A8[M,K] . B8[N,K]^T) + bias (+ res, fp32 output only); act 0: out = x (columns [0, scale_cols) times col_scale);
+ * act 1: out = gelu'(x), out2 = gelu(x) (bf16), as in avs_gemm_nt_bf16.  fp32 accumulation on v_mfma_f32_16x16x128_f8f6f4,
  * the 8-phase 256x256 kernel of the bf16 GEMM with 128-value K-tiles.  alpha carries 1 / (scale_A * scale_B).  N%256==0, K%128==0,
  * K>=256, leading dimensions multiples of 16.  avs_absmax: out = max(out, max |x|) (caller zeroes out; x fp32 or bf16);
  * avs_quantize_fp8: y = e4m3(clamp(x * scale, +-448)), n%4==0. */
 int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long ldb, int M, int N, int K, const float* bias,
-                    const float* res, long long ldr, void* out, long long ldo, int out_f32, float alpha, avs_stream_t stream);
+                    const float* res, long long ldr, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
+                    int act, int scale_cols, float col_scale, avs_stream_t stream);
 int avs_absmax(const void* x, int is_f32, long long n, float* out, avs_stream_t stream);
 int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, avs_stream_t stream);
 /* the same GEMM over TWO weight sets in one launch: rows [0, m_split) of A meet B / bias / colsum, rows [m_split, M) meet
