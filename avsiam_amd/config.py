@@ -26,9 +26,16 @@ class AVSiamConfig:
     audio_f: int = 8             # frequency patches: 128 mel bins / 16
     frames: int = 1              # T: frames per sample (reference pre-training: 1)
     n_classes: int = 21843       # dead in21k head kept for checkpoint-key compatibility
+    stride: int = 0              # patch stride = the patch extent actually used; 0 = `patch`.  14 with patch 16: the 14 x 14 patch grid
+                                 # (ViT-H/14) on 16 x 16 STORAGE - patch-embedding kernels and prediction rows keep 256 positions per
+                                 # channel, of which the 14 x 14 corner is read / scored and the rest is dead weight
     n_groups: int = 5            # multi-ratio groups of the contrastive pass (:534)
     mae_mask_ratio: float = 0.75  # hard-coded at :696
     temperature: float = 0.05    # :647
+
+    @property
+    def st(self):                # patch stride (= used extent)
+        return self.stride or self.patch
 
     @property
     def audio_t(self):           # time patches (64 for target_length 1024)
@@ -36,11 +43,11 @@ class AVSiamConfig:
 
     @property
     def video_tokens(self):      # Lv per frame
-        return (self.img_size // self.patch) ** 2
+        return (self.img_size // self.st) ** 2
 
     @property
     def grid(self):
-        return self.img_size // self.patch
+        return self.img_size // self.st
 
     @property
     def head_dim(self):
@@ -60,11 +67,11 @@ class AVSiamConfig:
 
     @property
     def audio_len(self):         # spectrogram frames (target_length)
-        return self.audio_t * self.patch
+        return self.audio_t * self.st
 
     @property
     def n_mels(self):
-        return self.audio_f * self.patch
+        return self.audio_f * self.st
 
 
 def vit_base(**kw):
@@ -84,3 +91,12 @@ def vit_huge(**kw):
     small test shapes."""
     kw.setdefault("depth", 32)
     return AVSiamConfig(embed_dim=1280, num_heads=16, **kw)
+
+
+def vit_huge14(**kw):
+    """ViT-H/14 geometry (BASELINE.json configs[4]): 14 x 14 patches - 256 tokens per 224 x 224 frame, 9 x 73 = 657 tokens for a
+    1022 x 126 corner of the 1024 x 128 spectrogram - on 16 x 16 patch storage (``stride``), so the GEMMs keep their 64-aligned K."""
+    kw.setdefault("depth", 32)
+    kw.setdefault("audio_tokens", 657)
+    kw.setdefault("audio_f", 9)
+    return AVSiamConfig(embed_dim=1280, num_heads=16, stride=14, **kw)

@@ -47,6 +47,33 @@ __global__ void im2col_video_kernel(const void* __restrict__ vin, const int* __r
     }
 }
 
+// The same gathers for a patch STRIDE S < 16 on 16 x 16 patch storage (config.stride: the 14 x 14 grid of ViT-H/14): token (t, f) / (gy, gx)
+// starts at pixel t*S / gy*S, only the S x S corner of the 256 positions per channel is read, the rest of the row is zero (so the padded
+// positions of the patch-embedding kernel never contribute and never receive a gradient).  Element-wise loads: S need not be a multiple of 4.
+__global__ void im2col_audio_s_kernel(const float* __restrict__ a, const int* __restrict__ row_b, const int* __restrict__ row_tok,
+                                      bf16_t* __restrict__ out, int rows, int tlen, int mel, int tP, int S, InXf xf) {
+    const int r = blockIdx.x;
+    const int q = threadIdx.x >> 4, p = threadIdx.x & 15;
+    const int b = row_b[r], tok = row_tok[r];
+    const int f = tok / tP, t = tok - f * tP;
+    const float v = (q < S && p < S) ? xf_audio(a, xf, b, t * S + q, f * S + p, tlen, mel) : 0.f;
+    out[(size_t)r * 256 + p * 16 + q] = f2bf(v);
+}
+
+__global__ void im2col_video_s_kernel(const void* __restrict__ vin, const int* __restrict__ row_img, const int* __restrict__ row_tok,
+                                      bf16_t* __restrict__ out, int rows, int C, int H, int W, int G, int S, InXf xf) {
+    const int r = blockIdx.x;
+    const int img = row_img[r], tok = row_tok[r];
+    const int gy = tok / G, gx = tok - gy * G;
+    const int K = C * 256;
+    for (int e = threadIdx.x; e < K; e += blockDim.x) {
+        const int c = e >> 8, p = (e >> 4) & 15, q = e & 15;
+        float v = 0.f;
+        if (p < S && q < S) v = xf_video(vin, xf, (((size_t)img * C + c) * H + gy * S + p) * W + gx * S + q, c);
+        out[(size_t)r * K + e] = f2bf(v);
+    }
+}
+
 // fp32 -> bf16 with a scale (d(2*(conv+pos)) = 2*dOut for the embed prologue `x + norm_pre(x)`, :449-450)
 __global__ void cast_scale_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n4, float alpha) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -329,6 +356,30 @@ extern "C" int avs_im2col_video_xf(const void* v, const int* row_img, const int*
 extern "C" int avs_im2col_video(const float* v, const int* row_img, const int* row_tok, bf16_t* out, int rows, int C, int H,
                                 int W, hipStream_t stream) {
     return avs_im2col_video_xf(v, row_img, row_tok, out, rows, C, H, W, nullptr, stream);
+}
+
+extern "C" int avs_im2col_audio_s(const float* a, const int* row_b, const int* row_tok, bf16_t* out, int rows, int tlen, int mel,
+                                 int t_patches, int stride, const avs_input_xf_t* xf, hipStream_t stream) {
+    if (stride == 16) return avs_im2col_audio_xf(a, row_b, row_tok, out, rows, tlen, mel, t_patches, xf, stream);
+    AVS_CHECK_ARG(rows > 0 && a && row_b && row_tok && out && stride > 0 && stride < 16, "im2col_audio_s: bad args (stride %d)", stride);
+    InXf x;
+    if (int rc = avs_make_xf(xf, 1, &x, "im2col_audio_s")) return rc;
+    im2col_audio_s_kernel<<<rows, 256, 0, stream>>>(a, row_b, row_tok, out, rows, tlen, mel, t_patches, stride, x);
+    AVS_LAUNCH_CHECK("im2col_audio_s");
+    return 0;
+}
+
+extern "C" int avs_im2col_video_s(const void* v, const int* row_img, const int* row_tok, bf16_t* out, int rows, int C, int H, int W,
+                                 int stride, const avs_input_xf_t* xf, hipStream_t stream) {
+    if (stride == 16) return avs_im2col_video_xf(v, row_img, row_tok, out, rows, C, H, W, xf, stream);
+    AVS_CHECK_ARG(rows > 0 && v && row_img && row_tok && out && stride > 0 && stride < 16 && (W % stride) == 0 && (H % stride) == 0,
+                  "im2col_video_s: bad args (stride %d)", stride);
+    InXf x;
+    if (int rc = avs_make_xf(xf, 2, &x, "im2col_video_s")) return rc;
+    AVS_CHECK_ARG(x.kind == 0 || C == 3, "im2col_video_s: uint8 frames need 3 channels");
+    im2col_video_s_kernel<<<rows, 256, 0, stream>>>(v, row_img, row_tok, out, rows, C, H, W, W / stride, stride, x);
+    AVS_LAUNCH_CHECK("im2col_video_s");
+    return 0;
 }
 
 extern "C" int avs_cast_scale_bf16(const float* x, bf16_t* y, long long n, float alpha, hipStream_t stream) {

@@ -6,23 +6,27 @@
 // into the index arithmetic: target[b, l, (p*16+q)*C + c] = img[b, c, gy*16+p, gx*16+q]; for audio the image is
 // the transposed spectrogram (:666-668) so target[b, f*tP+t, p*16+q] = a[b, t*16+q, f*16+p].
 // row_loss[r] = mask[r] * mean_e (pred - target)^2 ; loss = sum_r row_loss / sum(mask).
+// S: patch stride = the S x S corner of the 16 x 16 positions that is scored (16: all of them; 14: config.stride, ViT-H/14);
+// `valid` says whether element e belongs to it.
 __device__ __forceinline__ float mae_target(const void* __restrict__ inp, int audio, int r, int e, int L, int C, int H,
-                                            int W, int G, const InXf& xf) {
+                                            int W, int G, int S, const InXf& xf, bool& valid) {
     const int n = r / L, l = r - n * L;
     if (audio) {                       // H = time frames, W = mel bins, G = time patches
         const int f = l / G, t = l - f * G;
         const int p = e >> 4, q = e & 15;
-        return xf_audio(reinterpret_cast<const float*>(inp), xf, n, t * 16 + q, f * 16 + p, H, W);
+        valid = p < S && q < S;
+        return valid ? xf_audio(reinterpret_cast<const float*>(inp), xf, n, t * S + q, f * S + p, H, W) : 0.f;
     }
     const int gy = l / G, gx = l - gy * G;
     const int c = e % C, pq = e / C;
     const int p = pq >> 4, q = pq & 15;
-    return xf_video(inp, xf, (((size_t)n * C + c) * H + gy * 16 + p) * W + gx * 16 + q, c);
+    valid = p < S && q < S;
+    return valid ? xf_video(inp, xf, (((size_t)n * C + c) * H + gy * S + p) * W + gx * S + q, c) : 0.f;
 }
 
 __global__ void mae_loss_fwd_kernel(const float* __restrict__ pred, const void* __restrict__ inp,
                                     const float* __restrict__ mask, float* __restrict__ row_loss, int audio, int L, int C,
-                                    int H, int W, int G, int P, InXf xf) {
+                                    int H, int W, int G, int P, int S, InXf xf) {
     __shared__ float red[4];
     const int r = blockIdx.x;
     if (mask[r] == 0.f) {
@@ -31,13 +35,15 @@ __global__ void mae_loss_fwd_kernel(const float* __restrict__ pred, const void* 
     }
     float s = 0.f;
     for (int e = threadIdx.x; e < P; e += blockDim.x) {
-        const float d = pred[(size_t)r * P + e] - mae_target(inp, audio, r, e, L, C, H, W, G, xf);
+        bool valid;
+        const float tg = mae_target(inp, audio, r, e, L, C, H, W, G, S, xf, valid);
+        const float d = valid ? pred[(size_t)r * P + e] - tg : 0.f;
         s += d * d;
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) row_loss[r] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)P * mask[r];
+    if (threadIdx.x == 0) row_loss[r] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(P / 256 * S * S) * mask[r];      // mean over the scored elements
 }
 
 // deterministic single-block sum: out[0] = scale * sum(x); optionally total[0] = (total_init ? 0 : total[0]) + out[0]
@@ -60,13 +66,17 @@ __global__ void sum_scale_kernel(const float* __restrict__ x, int n, float scale
 // dpred[r, e] = g * 2 (pred - target) mask[r] / (P * nmask)   (bf16: operand of the prediction-head GEMMs)
 __global__ void mae_loss_bwd_kernel(const float* __restrict__ pred, const void* __restrict__ inp,
                                     const float* __restrict__ mask, const float* __restrict__ gout, bf16_t* __restrict__ dpred,
-                                    int audio, int L, int C, int H, int W, int G, int P, float inv_nmask, InXf xf) {
+                                    int audio, int L, int C, int H, int W, int G, int P, int S, float inv_nmask, InXf xf) {
     const int r = blockIdx.x;
     const float m = mask[r];
-    const float k = gout[0] * 2.0f * m * inv_nmask / (float)P;
+    const float k = gout[0] * 2.0f * m * inv_nmask / (float)(P / 256 * S * S);
     for (int e = threadIdx.x; e < P; e += blockDim.x) {
         float d = 0.f;
-        if (m != 0.f) d = k * (pred[(size_t)r * P + e] - mae_target(inp, audio, r, e, L, C, H, W, G, xf));
+        if (m != 0.f) {
+            bool valid;
+            const float tg = mae_target(inp, audio, r, e, L, C, H, W, G, S, xf, valid);
+            if (valid) d = k * (pred[(size_t)r * P + e] - tg);
+        }
         dpred[(size_t)r * P + e] = f2bf(d);
     }
 }
@@ -215,19 +225,25 @@ __global__ void infonce_dlogits_kernel(const float* __restrict__ total, const fl
 // ===================================================================================================
 int avs_make_xf(const avs_input_xf_t* x, int want_kind, InXf* out, const char* who);     // elementwise.hip
 
-extern "C" int avs_mae_loss_fwd_xf(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss,
-                                   float* total, int total_init, int rows, int audio, int L, int C, int H, int W, float nmask,
-                                   const avs_input_xf_t* xf, hipStream_t stream) {
-    AVS_CHECK_ARG(rows > 0 && pred && inp && mask && row_loss && loss && nmask > 0, "mae_loss_fwd: bad args");
+extern "C" int avs_mae_loss_fwd_s(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss,
+                                  float* total, int total_init, int rows, int audio, int L, int C, int H, int W, float nmask,
+                                  int stride, const avs_input_xf_t* xf, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && pred && inp && mask && row_loss && loss && nmask > 0 && stride > 0 && stride <= 16, "mae_loss_fwd: bad args");
     InXf x;
     if (int rc = avs_make_xf(xf, audio ? 1 : 2, &x, "mae_loss_fwd")) return rc;
-    const int G = audio ? H / 16 : W / 16;
+    const int G = audio ? H / stride : W / stride;
     const int P = 256 * (audio ? 1 : C);
-    mae_loss_fwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, row_loss, audio, L, C, H, W, G, P, x);
+    mae_loss_fwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, row_loss, audio, L, C, H, W, G, P, stride, x);
     AVS_LAUNCH_CHECK("mae_loss_fwd");
     sum_scale_kernel<<<1, 1024, 0, stream>>>(row_loss, rows, 1.0f / nmask, loss, total, total_init);
     AVS_LAUNCH_CHECK("mae_loss_sum");
     return 0;
+}
+
+extern "C" int avs_mae_loss_fwd_xf(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss,
+                                   float* total, int total_init, int rows, int audio, int L, int C, int H, int W, float nmask,
+                                   const avs_input_xf_t* xf, hipStream_t stream) {
+    return avs_mae_loss_fwd_s(pred, inp, mask, row_loss, loss, total, total_init, rows, audio, L, C, H, W, nmask, 16, xf, stream);
 }
 
 extern "C" int avs_mae_loss_fwd(const float* pred, const float* inp, const float* mask, float* row_loss, float* loss,
@@ -236,17 +252,23 @@ extern "C" int avs_mae_loss_fwd(const float* pred, const float* inp, const float
     return avs_mae_loss_fwd_xf(pred, inp, mask, row_loss, loss, total, total_init, rows, audio, L, C, H, W, nmask, nullptr, stream);
 }
 
+extern "C" int avs_mae_loss_bwd_s(const float* pred, const void* inp, const float* mask, const float* gout, bf16_t* dpred,
+                                  int rows, int audio, int L, int C, int H, int W, float nmask, int stride, const avs_input_xf_t* xf,
+                                  hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && pred && inp && mask && gout && dpred && nmask > 0 && stride > 0 && stride <= 16, "mae_loss_bwd: bad args");
+    InXf x;
+    if (int rc = avs_make_xf(xf, audio ? 1 : 2, &x, "mae_loss_bwd")) return rc;
+    const int G = audio ? H / stride : W / stride;
+    const int P = 256 * (audio ? 1 : C);
+    mae_loss_bwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, gout, dpred, audio, L, C, H, W, G, P, stride, 1.0f / nmask, x);
+    AVS_LAUNCH_CHECK("mae_loss_bwd");
+    return 0;
+}
+
 extern "C" int avs_mae_loss_bwd_xf(const float* pred, const void* inp, const float* mask, const float* gout, bf16_t* dpred,
                                    int rows, int audio, int L, int C, int H, int W, float nmask, const avs_input_xf_t* xf,
                                    hipStream_t stream) {
-    AVS_CHECK_ARG(rows > 0 && pred && inp && mask && gout && dpred && nmask > 0, "mae_loss_bwd: bad args");
-    InXf x;
-    if (int rc = avs_make_xf(xf, audio ? 1 : 2, &x, "mae_loss_bwd")) return rc;
-    const int G = audio ? H / 16 : W / 16;
-    const int P = 256 * (audio ? 1 : C);
-    mae_loss_bwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, gout, dpred, audio, L, C, H, W, G, P, 1.0f / nmask, x);
-    AVS_LAUNCH_CHECK("mae_loss_bwd");
-    return 0;
+    return avs_mae_loss_bwd_s(pred, inp, mask, gout, dpred, rows, audio, L, C, H, W, nmask, 16, xf, stream);
 }
 
 extern "C" int avs_mae_loss_bwd(const float* pred, const float* inp, const float* mask, const float* gout, bf16_t* dpred,

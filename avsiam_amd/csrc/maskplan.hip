@@ -24,7 +24,8 @@ struct PlanSeq {        // one sequence to draw (int32 x 12, filled by the host)
     int t_patches;      // > 0: structured audio masking on a [f][t] grid with the two bit masks below
     int ids_off;        // offset into ids_out, or -1
     int mask_off;       // offset of this sequence in mask_out (loss-mask layout), used when dec_off >= 0
-    int pad0, pad1, pad2;
+    int tmask_x;        // bits 64..95 of the structured time mask (grids of more than 64 time patches: 73 at patch stride 14)
+    int pad1, pad2;
 };
 
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const PlanSeq* __restric
             v = (float)(r >> 8) * (1.0f / 16777216.0f);           // uniform [0,1) with 24 bits, like torch.rand
             if (s.t_patches > 0) {
                 const int f = i / s.t_patches, t = i - f * s.t_patches;
-                const bool tm = t < 32 ? (tl >> t) & 1u : (th >> (t - 32)) & 1u;
+                const bool tm = t < 32 ? (tl >> t) & 1u : t < 64 ? (th >> (t - 32)) & 1u : ((unsigned)s.tmask_x >> (t - 64)) & 1u;
                 if (tm || ((fm >> f) & 1u)) v = 1.1f;             // "large value will be removed" (:408,413,418,422)
             }
         }

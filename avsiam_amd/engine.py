@@ -404,9 +404,9 @@ class PatchEmbedder:
         """inp: audio [B,time,mel] / video [NF,3,H,W] fp32 - or the raw input (un-normalised fbank / uint8 frames) with its
         transform `xf` (ops.InputXf); out: fp32 [rows(+pad), D] slice of the residual stream."""
         if self.audio:
-            ops.im2col_audio(inp, self.row_src, self.row_tok, self.cols, self.rows, self.cfg.audio_t, xf)
+            ops.im2col_audio(inp, self.row_src, self.row_tok, self.cols, self.rows, self.cfg.audio_t, xf, stride=self.cfg.st)
         else:
-            ops.im2col_video(inp, self.row_src, self.row_tok, self.cols, self.rows, xf)
+            ops.im2col_video(inp, self.row_src, self.row_tok, self.cols, self.rows, xf, stride=self.cfg.st)
         ops.gemm_nt(self.cols, self.lin.w, out, self.rows, bias=self.lin.b, res=self.pos, res_idx=self.row_pos, alpha=2.0)
 
     def backward(self, dx):
@@ -544,14 +544,17 @@ class ContrastivePass:
         # random.sample(range(t), n): the n smallest of t random keys
         rank_t = np.argsort(np.argsort(nprng.random((B, t)), axis=1), axis=1)
         rank_f = np.argsort(np.argsort(nprng.random((B, f)), axis=1), axis=1)
+        assert t <= 96 and f <= 32, "structured masks are bit sets: at most 96 time and 32 frequency patches"
         tm = (rank_t < nt[:, None]).astype(np.uint64)
         fm = (rank_f < nf[:, None]).astype(np.uint64)
-        tbits = (tm << np.arange(t, dtype=np.uint64)[None, :]).sum(axis=1)
+        tbits = (tm[:, :64] << np.arange(min(t, 64), dtype=np.uint64)[None, :]).sum(axis=1)
         fbits = (fm << np.arange(f, dtype=np.uint64)[None, :]).sum(axis=1)
         self.bits_host[:] = 0
         self.bits_host[0, :B] = (tbits & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)
         self.bits_host[1, :B] = (tbits >> np.uint64(32)).astype(np.uint32).view(np.int32)
         self.bits_host[2, :B] = fbits.astype(np.uint32).view(np.int32)
+        if t > 64:                                               # time patches 64.. travel in the descriptor (PlanSeq.tmask_x)
+            d[:B, 9] = (tm[:, 64:] << np.arange(t - 64, dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint32).view(np.int32)
         self.desc_dev.copy_(torch.from_numpy(d), non_blocking=True)
         self.bits_dev.copy_(torch.from_numpy(self.bits_host), non_blocking=True)
         ops.mask_plan(self.desc_dev, d, seed, self.row_src_all, self.row_tok_all, self.bits_dev[0], self.bits_dev[1], self.bits_dev[2],
@@ -798,16 +801,16 @@ class MaePass:
         ops.gemm_nt(self.dn[:self.v_off], self.pred_a.w, self.p_a, self.na_rows, bias=self.pred_a.b)       # :634
         ops.gemm_nt(self.dn[self.v_off:], self.pred_v.w, self.p_v, self.nv_rows, bias=self.pred_v.b)       # :635
         ops.mae_loss_fwd(self.p_a, audio, self.mask_a.view(-1), self.rl_a, self.losses[0:1], True, La, self.nmask_a,
-                         total=self.losses[2:3], total_init=True, xf=xf[0])
+                         total=self.losses[2:3], total_init=True, xf=xf[0], stride=cfg.st)
         ops.mae_loss_fwd(self.p_v, self.imgs, self.mask_v.view(-1), self.rl_v, self.losses[1:2], False, Lv, self.nmask_v,
-                         total=self.losses[2:3], total_init=False, xf=xf[1])                                # loss_mae = a + v (:707)
+                         total=self.losses[2:3], total_init=False, xf=xf[1], stride=cfg.st)               # loss_mae = a + v (:707)
         return self.losses[2:3], self.losses[0:1], self.losses[1:2], self.mask_a, self.mask_v
 
     def backward(self, gout, reducer=None):
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         La, Lv, D, Dd = cfg.audio_tokens, cfg.video_tokens, cfg.embed_dim, cfg.dec_dim
-        ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a, xf=self.xf[0])
-        ops.mae_loss_bwd(self.p_v, self.imgs, self.mask_v.view(-1), gout, self.dp_v, False, Lv, self.nmask_v, xf=self.xf[1])
+        ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a, xf=self.xf[0], stride=cfg.st)
+        ops.mae_loss_bwd(self.p_v, self.imgs, self.mask_v.view(-1), gout, self.dp_v, False, Lv, self.nmask_v, xf=self.xf[1], stride=cfg.st)
         # prediction heads
         ops.gemm_nt(self.dp_a, self.pred_a.wt, self.ddn[:self.v_off], self.na_rows)
         ops.gemm_tn(self.dp_a, self.dn[:self.v_off], self.pred_a.gw, self.na_rows)

@@ -295,18 +295,19 @@ def _xf_arg(xf, kind, per_sample=None):
     return ctypes.addressof(xf)
 
 
-def im2col_audio(a, row_b, row_tok, out, rows, t_patches, xf=None):
+def im2col_audio(a, row_b, row_tok, out, rows, t_patches, xf=None, stride=16):
+    """stride < 16: patch stride on 16 x 16 patch storage (config.stride) - the S x S corner of every 256-wide row is filled, the rest zero"""
     _chk(a, F32, "im2col.a", 3); _chk(row_b, I32, "im2col.row_b"); _chk(row_tok, I32, "im2col.row_tok"); _chk(out, BF16, "im2col.out", 2)
     assert out.shape[1] == 256 and out.shape[0] >= rows and row_b.numel() >= rows and row_tok.numel() >= rows
-    assert a.shape[1] == t_patches * 16 and a.shape[2] % 16 == 0
-    _lib.call("avs_im2col_audio_xf", a, row_b, row_tok, out, rows, a.shape[1], a.shape[2], t_patches, _xf_arg(xf, 1, a.shape[0]), _stream())
+    assert a.shape[1] == t_patches * stride and a.shape[2] % stride == 0
+    _lib.call("avs_im2col_audio_s", a, row_b, row_tok, out, rows, a.shape[1], a.shape[2], t_patches, int(stride), _xf_arg(xf, 1, a.shape[0]), _stream())
 
 
-def im2col_video(v, row_img, row_tok, out, rows, xf=None):
+def im2col_video(v, row_img, row_tok, out, rows, xf=None, stride=16):
     _chk(v, U8 if xf is not None else F32, "im2col.v", 4); _chk(row_img, I32, "im2col.row_img"); _chk(row_tok, I32, "im2col.row_tok"); _chk(out, BF16, "im2col.out", 2)
     NF, C, H, W = v.shape
-    assert out.shape[1] == C * 256 and out.shape[0] >= rows and row_img.numel() >= rows and row_tok.numel() >= rows and W % 16 == 0
-    _lib.call("avs_im2col_video_xf", v, row_img, row_tok, out, rows, C, H, W, _xf_arg(xf, 2), _stream())
+    assert out.shape[1] == C * 256 and out.shape[0] >= rows and row_img.numel() >= rows and row_tok.numel() >= rows and W % stride == 0
+    _lib.call("avs_im2col_video_s", v, row_img, row_tok, out, rows, C, H, W, int(stride), _xf_arg(xf, 2), _stream())
 
 
 PLAN_FIELDS = 12      # int32 per sequence descriptor of avs_mask_plan
@@ -336,7 +337,8 @@ def mask_plan(seqs_dev, seqs_host, seed, row_src, row_tok, tmask_lo=None, tmask_
     if (t_p > 0).any():
         assert all(t is not None and t.numel() >= nseq for t in (tmask_lo, tmask_hi, fmask))
         sel = t_p > 0
-        assert (t_p[sel] <= 64).all() and (L[sel] % t_p[sel] == 0).all() and (L[sel] // t_p[sel] <= 32).all()
+        # time patches: 64 bits in tmask_lo / tmask_hi + 32 in the descriptor (field 9, PlanSeq.tmask_x); frequency patches: 32 bits
+        assert (t_p[sel] <= 96).all() and (L[sel] % t_p[sel] == 0).all() and (L[sel] // t_p[sel] <= 32).all()
     _lib.call("avs_mask_plan", seqs_dev, nseq, tmask_lo, tmask_hi, fmask, int(seed) & 0xFFFFFFFFFFFFFFFF, row_src, row_tok, src_row,
               mask_out, ids_out, _stream())
 
@@ -392,22 +394,22 @@ def segment_mean_bwd(dreps, seg_start, dy, nseg, scale=1.0):
     _lib.call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], float(scale), _stream())
 
 
-def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, total_init=True, xf=None):
+def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, total_init=True, xf=None, stride=16):
     _chk(pred, F32, "mae.pred", 2); _chk(inp, U8 if (xf is not None and not audio) else F32, "mae.inp"); _chk(mask, F32, "mae.mask"); _chk(row_loss, F32, "mae.row_loss"); _chk(loss, F32, "mae.loss")
     _chk(total, F32, "mae.total")
     rows = mask.numel()
     if audio:
         C, H, W = 1, inp.shape[1], inp.shape[2]          # [B, time, mel]
-        assert inp.dim() == 3 and rows == inp.shape[0] * L and pred.shape[1] == 256 and (H // 16) * (W // 16) == L
+        assert inp.dim() == 3 and rows == inp.shape[0] * L and pred.shape[1] == 256 and (H // stride) * (W // stride) == L
     else:
         C, H, W = inp.shape[-3:]
-        assert rows == inp.numel() // (C * H * W) * L and pred.shape[1] == 256 * C and (H // 16) * (W // 16) == L
+        assert rows == inp.numel() // (C * H * W) * L and pred.shape[1] == 256 * C and (H // stride) * (W // stride) == L
     assert pred.shape[0] >= rows and row_loss.numel() >= rows
-    _lib.call("avs_mae_loss_fwd_xf", pred, inp, mask, row_loss, loss, total, int(bool(total_init)), rows, int(audio), L, C, H, W,
-              float(nmask), _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), _stream())
+    _lib.call("avs_mae_loss_fwd_s", pred, inp, mask, row_loss, loss, total, int(bool(total_init)), rows, int(audio), L, C, H, W,
+              float(nmask), int(stride), _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), _stream())
 
 
-def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask, xf=None):
+def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask, xf=None, stride=16):
     _chk(pred, F32, "maeb.pred", 2); _chk(inp, U8 if (xf is not None and not audio) else F32, "maeb.inp"); _chk(mask, F32, "maeb.mask"); _chk(gout, F32, "maeb.gout"); _chk(dpred, BF16, "maeb.dpred", 2)
     rows = mask.numel()
     if audio:
@@ -415,7 +417,7 @@ def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask, xf=None):
     else:
         C, H, W = inp.shape[-3:]
     assert pred.shape[0] >= rows and dpred.shape[0] >= rows and dpred.shape[1] == pred.shape[1] == 256 * C
-    _lib.call("avs_mae_loss_bwd_xf", pred, inp, mask, gout, dpred, rows, int(audio), L, C, H, W, float(nmask),
+    _lib.call("avs_mae_loss_bwd_s", pred, inp, mask, gout, dpred, rows, int(audio), L, C, H, W, float(nmask), int(stride),
               _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), _stream())
 
 

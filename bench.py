@@ -153,9 +153,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--audio-tokens", type=int, default=512)
-    ap.add_argument("--model", choices=("vit_base", "vit_large", "vit_huge"), default="vit_base",
+    ap.add_argument("--model", choices=("vit_base", "vit_large", "vit_huge", "vit_huge14"), default="vit_base",
                     help="vit_base = BASELINE.json's metric (configs[1]); vit_large = configs[3]'s shape, vit_huge = configs[4]'s encoder width in bf16 "
-                         "on 16x16 patches (use --batch 32: saved activations of batch 64 x 10 frames exceed 288 GB) - extra data points")
+                         "on 16x16 patches (use --batch 32: saved activations of batch 64 x 10 frames exceed 288 GB), vit_huge14 = the same on the "
+                         "14x14 patch grid (256 tokens per frame, 657 audio tokens) - extra data points")
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) forward GEMMs (engine.FP8): configs[4]'s fp8 MFMA path as an extra data point; "
                     "the line then says dtype fp8-forward/bf16-backward and is NOT the headline metric")
@@ -197,9 +198,13 @@ def main():
     elif args.model == "vit_huge":
         from avsiam_amd.config import vit_huge
         cfg = vit_huge(audio_tokens=args.audio_tokens, frames=args.frames)
+    elif args.model == "vit_huge14":
+        from avsiam_amd.config import vit_huge14
+        cfg = vit_huge14(frames=args.frames)
     else:
         cfg = AVSiamConfig(audio_tokens=args.audio_tokens, frames=args.frames)
-    mname = {"vit_base": "ViT-B/16", "vit_large": "ViT-L/16", "vit_huge": "ViT-H/16 (1280 wide, 32 layers, 16 heads of 80)"}[args.model]
+    mname = {"vit_base": "ViT-B/16", "vit_large": "ViT-L/16", "vit_huge": "ViT-H/16 (1280 wide, 32 layers, 16 heads of 80)",
+             "vit_huge14": "ViT-H/14 (1280 wide, 32 layers, 16 heads of 80, 14x14 patches)"}[args.model]
     torch.manual_seed(87 + rank)
     log(f"building model (frames={args.frames}, batch={args.batch}/GPU, world={world})")
     if args.recompute or args.fp8:
@@ -266,9 +271,9 @@ def main():
             "metric": f"AV pretrain samples/sec ({mname}, 75% mask)", "value": sps, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp8(e4m3)-forward/bf16-backward" if args.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x196 + "
-                                   f"{args.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
-                       "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": args.audio_tokens,
+            "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x{cfg.video_tokens} + "
+                                   f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
+                       "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
                        "parallelism": f"dp{world}", "gflop_per_sample": gf, **({"activation_recompute": True} if args.recompute else {})},
             "model_tflops": sps * gf / 1e3, "mfu_vs_dense_bf16_peak": sps * gf / 1e3 / (world * PEAK_BF16_TFLOPS),
             "final_losses": {"loss_mae": losses[0], "loss_mae_a": losses[1], "loss_mae_v": losses[2], "loss_c": losses[3], "c_acc": losses[4]},

@@ -176,6 +176,19 @@ int avs_mae_loss_fwd_xf(const float* pred, const void* inp, const float* mask, f
                         avs_stream_t stream);
 int avs_mae_loss_bwd_xf(const float* pred, const void* inp, const float* mask, const float* gout, avs_bf16* dpred, int rows,
                         int audio, int L, int C, int H, int W, float nmask, const avs_input_xf* xf, avs_stream_t stream);
+/* the same four with a patch STRIDE (1..16) on 16 x 16 patch storage: token (t, f) / (gy, gx) starts at pixel t*stride / gy*stride, only
+ * the stride x stride corner of the 256 positions per channel is gathered (the rest of the im2col row is zero) / scored (mean over the
+ * scored elements; dpred is zero elsewhere).  stride 16 = the entry points above.  14: the patch grid of ViT-H/14 (config.stride). */
+int avs_im2col_audio_s(const float* a, const int* row_b, const int* row_tok, avs_bf16* out, int rows, int tlen, int mel, int t_patches,
+                       int stride, const avs_input_xf* xf, avs_stream_t stream);
+int avs_im2col_video_s(const void* v, const int* row_img, const int* row_tok, avs_bf16* out, int rows, int C, int H, int W, int stride,
+                       const avs_input_xf* xf, avs_stream_t stream);
+int avs_mae_loss_fwd_s(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss, float* total,
+                       int total_init, int rows, int audio, int L, int C, int H, int W, float nmask, int stride, const avs_input_xf* xf,
+                       avs_stream_t stream);
+int avs_mae_loss_bwd_s(const float* pred, const void* inp, const float* mask, const float* gout, avs_bf16* dpred, int rows, int audio,
+                       int L, int C, int H, int W, float nmask, int stride, const avs_input_xf* xf, avs_stream_t stream);
+
 
 /* ---- bidirectional InfoNCE (forward_contrastive, cav_mae_base.py:641-661) */
 int avs_l2norm_fwd(const float* x, float* xn, float* norm, int rows, int D, avs_stream_t stream);

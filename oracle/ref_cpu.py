@@ -56,24 +56,25 @@ def block(x, P, prefix, heads, modality=None):
     return x
 
 
-def patch_embed(img, w, b):
-    """PatchEmbed.forward :98-99 - conv k=s=patch, flatten(2).transpose(1,2)."""
-    p = w.shape[-1]
-    return F.conv2d(img, w, b, stride=p).flatten(2).transpose(1, 2)
+def patch_embed(img, w, b, stride=0):
+    """PatchEmbed.forward :98-99 - conv k=s=patch, flatten(2).transpose(1,2).  stride (config.stride, e.g. 14 on 16 x 16 storage):
+    the stride x stride corner of the stored kernel is the convolution kernel, the rest of it is dead weight."""
+    s = stride or w.shape[-1]
+    return F.conv2d(img, w[..., :s, :s], b, stride=s).flatten(2).transpose(1, 2)
 
 
-def embed_audio(P, a):
+def embed_audio(P, a, stride=0):
     """:444-450 / :511-517.  a [B, time, mel] -> [B,1,mel,time] -> tokens f*t_patches + t.
     ``a + norm_pre_a(a)`` with norm_pre = Identity doubles the embedding."""
     a = a.unsqueeze(1).transpose(2, 3)
-    a = patch_embed(a, P["vit_base.patch_embed_a.proj.weight"], P["vit_base.patch_embed_a.proj.bias"])
+    a = patch_embed(a, P["vit_base.patch_embed_a.proj.weight"], P["vit_base.patch_embed_a.proj.bias"], stride)
     a = a + P["vit_base.pos_embed_a"]
     return a + a
 
 
-def embed_video(P, v):
+def embed_video(P, v, stride=0):
     """:453-455 / :520-522.  v [N,3,H,W]."""
-    v = patch_embed(v, P["vit_base.patch_embed.proj.weight"], P["vit_base.patch_embed.proj.bias"])
+    v = patch_embed(v, P["vit_base.patch_embed.proj.weight"], P["vit_base.patch_embed.proj.bias"], stride)
     v = v + P["vit_base.pos_embed"][:, 1:]
     return v + v
 
@@ -92,9 +93,9 @@ def _gather(x, ids):
 
 def forward_encoder_mae(P, cfg, a, v, plan):
     """forward_encoder :441-504 with the 75 % unstructured plan supplied."""
-    a = embed_audio(P, a)
+    a = embed_audio(P, a, cfg.stride)
     vv, T = _fold_frames(v)
-    vv = embed_video(P, vv)
+    vv = embed_video(P, vv, cfg.stride)
     B = a.shape[0]
     a = _gather(a, plan.ids_keep_a)
     vv = _gather(vv, plan.ids_keep_v.reshape(B * T, -1))
@@ -111,9 +112,9 @@ def forward_encoder_mmixed(P, cfg, a, v, plan):
     """forward_encoder_mmixed :508-594: multi-ratio groups through the shared (Siamese) blocks,
     final norm + token mean.  Samples with equal kept length are batched; results are returned in
     natural sample order (the reference's inverse permutation :575-590 does the same)."""
-    a = embed_audio(P, a)
+    a = embed_audio(P, a, cfg.stride)
     vv, T = _fold_frames(v)
-    vv = embed_video(P, vv)
+    vv = embed_video(P, vv, cfg.stride)
     B = a.shape[0]
     vv = vv.reshape(B, T, vv.shape[1], vv.shape[2])
     ca = [None] * B
@@ -172,14 +173,20 @@ def patchify(imgs, c, h, w, p=16):
 
 def mae_loss(cfg, inp, pred, mask, modality):
     """forward_mae_loss :663-683 (norm_pix_loss branch is commented out in the reference)."""
-    p = cfg.patch
+    p = cfg.st
+    c = 1 if modality == 'a' else cfg.in_chans
     if modality == 'a':
         inp = inp.unsqueeze(1).transpose(2, 3)
         target = patchify(inp, 1, inp.shape[2] // p, inp.shape[3] // p, p)
     else:
         vv, T = _fold_frames(inp)
         target = patchify(vv, cfg.in_chans, vv.shape[2] // p, vv.shape[3] // p, p)
-        target = target.reshape(pred.shape)
+    if p != cfg.patch:
+        # patch stride on larger patch storage (config.stride): the prediction row keeps patch x patch positions per channel in (p, q, c)
+        # order; the stride x stride corner is scored, the rest of the row is dead
+        P0 = cfg.patch
+        pred = pred.reshape(*pred.shape[:-1], P0, P0, c)[..., :p, :p, :].reshape(*pred.shape[:-1], p * p * c)
+    target = target.reshape(pred.shape)
     loss = ((pred - target) ** 2).mean(dim=-1)
     return (loss * mask).sum() / mask.sum()
 
@@ -286,7 +293,7 @@ def _head(x, P, name):
 
 def ft_encode_audio(P, cfg, a):
     """:829-841 - all 512 audio tokens through the shared blocks with the '_a' norms, then norm_a."""
-    a = embed_audio(P, a)
+    a = embed_audio(P, a, cfg.stride)
     for i in range(cfg.depth):
         a = block(a, P, f"vit_base.blocks.{i}", cfg.num_heads, "a")
     return _ln(a, P, "vit_base.norm_a", LN_EPS_FINAL)
@@ -295,7 +302,7 @@ def ft_encode_audio(P, cfg, a):
 def ft_encode_video(P, cfg, v):
     """:851-860 - v [B,T,3,H,W] folded to (b t); '_v' norms, then norm.  -> [(b t), Lv, D]"""
     vv = v.reshape(v.shape[0] * v.shape[1], *v.shape[2:])
-    vv = embed_video(P, vv)
+    vv = embed_video(P, vv, cfg.stride)
     for i in range(cfg.depth):
         vv = block(vv, P, f"vit_base.blocks.{i}", cfg.num_heads, "v")
     return _ln(vv, P, "vit_base.norm", LN_EPS_FINAL)

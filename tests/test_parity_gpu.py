@@ -298,3 +298,65 @@ def test_fp8_forward_mode_against_bf16(which):
             worst_ratio = max(worst_ratio, abs(float(g1.norm() / g0.norm()) - 1))
     record_margin(f"fp8_forward_{which}", loss_rel=abs(l1 - l0) / abs(l0), grad_cos_min=worst_cos, grad_norm_ratio_err=worst_ratio)
     assert worst_cos > 0.98 and worst_ratio < 0.06, (worst_cos, worst_ratio)
+
+
+@pytest.mark.parametrize("which", ["mae", "contrastive"])
+def test_vit_huge14_geometry_matches_oracle(which):
+    """BASELINE.json configs[4]'s geometry: 14 x 14 patches (256 tokens per 224 x 224 frame, 9 x 73 = 657 audio tokens from a 1022 x 126
+    spectrogram corner) as a patch STRIDE of 14 on 16 x 16 patch storage (config.stride), ViT-H width (heads of 80), 2 layers deep at
+    batch 2 x 2 frames, against the oracle - which convolves with the 14 x 14 corner of the stored kernels and scores the 14 x 14 corner of
+    every prediction row."""
+    from avsiam_amd.config import vit_huge14
+    import random
+    cfg = vit_huge14(frames=2, depth=2)
+    assert (cfg.video_tokens, cfg.audio_tokens, cfg.audio_len, cfg.n_mels) == (256, 657, 1022, 126)
+    B = 2
+    a, v = synth_inputs(cfg, B, 31)
+    gen = torch.Generator().manual_seed(5)
+    mae = which == "mae"
+    plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(5))
+    m = _model(cfg, 95)
+    out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
+    out[0].backward()
+    ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 95)
+    for i in (0, 1, 2, 3, 4):
+        assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+    _compare_grads(m, rgrads, cos_min=0.9998, ratio_tol=0.02, tag=f"vit_huge14_{which}")
+    # the dead corner of the stored patch kernels never receives a gradient
+    g = m._params["vit_base.patch_embed.proj.weight"].grad
+    assert g is not None and float(g[..., 14:, :].abs().max()) == 0 and float(g[..., :, 14:].abs().max()) == 0
+
+
+def test_vit_huge14_device_drawn_plan():
+    """The default path (plans drawn on the device) at the 14 x 14 geometry: 657- and 256-token sequences through the mask-plan kernel,
+    the contrastive pass's structured time masks over 73 time patches (bits 64.. travel in the sequence descriptor), read back and fed to
+    the oracle."""
+    from avsiam_amd.config import vit_huge14
+    from avsiam_amd.models import CAVMAE_BASE
+    cfg = vit_huge14(frames=1, depth=1)
+    B = 6
+    a, v = synth_inputs(cfg, B, 37)
+    m = CAVMAE_BASE(cfg=cfg, init_seed=94, init_mode="random", verbose=False, plan_seed=321).cuda()
+    out = m(a.cuda(), v.cuda(), mae_loss_weight=0, contrast_loss_weight=1)
+    out[0].backward()
+    plan = m.last_plans(B)["contrastive"]
+    ref, extras, rgrads = _oracle(cfg, a, v, plan, False, 94)
+    for i in (0, 3, 4):
+        assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
+    # structured masking removes whole time columns - also columns 64..72
+    t = cfg.audio_t
+    late = False
+    for _ in range(3):
+        for keep in m.last_plans(B)["contrastive"].a_keep:
+            if keep.numel() < cfg.audio_tokens:
+                cols = torch.zeros(t, dtype=torch.bool)
+                cols[(keep % t).unique()] = True
+                late = late or bool((~cols[64:]).any())
+        m(a.cuda(), v.cuda(), mae_loss_weight=0, contrast_loss_weight=1)
+    assert late
+    out = m(a.cuda(), v.cuda(), mae_loss_weight=1, contrast_loss_weight=0)
+    out[0].backward()
+    plan = m.last_plans(B)["mae"]
+    ref, extras, rgrads = _oracle(cfg, a, v, plan, True, 94)
+    for i in (0, 1, 2):
+        assert abs(out[i].item() - ref[i].item()) <= LOSS_RTOL * abs(ref[i].item()) + 1e-6, (i, out[i].item(), ref[i].item())
