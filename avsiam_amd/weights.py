@@ -140,6 +140,10 @@ def state_from_vit(vit_sd, cfg: AVSiamConfig, seed: int = 0):
             if k.startswith(("pre_logits", "fc_norm", "head_dist")):     # timm variants carry these; the reference drops them (strict=False)
                 continue
             raise KeyError(f"checkpoint key '{k}' has no counterpart in the CAVMAE_BASE schema")
+        if k == "patch_embed.proj.weight" and cfg.st != cfg.patch and tuple(val.shape[-2:]) == (cfg.st, cfg.st):
+            # a stride x stride kernel (timm's patch14) into patch x patch storage (config.stride): zero-padded; the padded positions are
+            # never read (the im2col columns there are zero) and never receive a gradient
+            val = torch.nn.functional.pad(val, (0, cfg.patch - cfg.st, 0, cfg.patch - cfg.st))
         if tuple(val.shape) != tuple(st[name].shape):
             raise ValueError(f"checkpoint key '{k}': shape {tuple(val.shape)} != {tuple(st[name].shape)}")
         st[name] = val.detach().to(torch.float32).clone()
