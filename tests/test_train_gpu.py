@@ -77,3 +77,27 @@ def test_train_loop_and_validate(tmp_path):
     missing = m2.load_state_dict({k[len("module."):]: v for k, v in sd.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     assert torch.equal(m2._params["decoder_embed.weight"].cpu(), m._params["decoder_embed.weight"].cpu())
+
+
+def test_fp8_forward_with_recompute_trains_at_the_14x14_geometry():
+    """The combination behind the configs[4]-like bench line (ViT-H/14 geometry, fp8 forward GEMMs, per-layer activation recompute,
+    device-drawn plans): a few training steps on one fixed batch stay finite and reduce the MAE loss."""
+    from avsiam_amd import engine
+    from avsiam_amd.config import vit_huge14
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.traintest_cavmae_base import train_step
+    cfg = vit_huge14(frames=2, depth=2)
+    a, v = synth_inputs(cfg, 4, 41)
+    a, v = a.cuda(), v.cuda()
+    try:
+        engine.FP8, engine.RECOMPUTE = "1", "1"
+        m = CAVMAE_BASE(cfg=cfg, init_seed=7, init_mode="random", verbose=False, plan_seed=9).cuda()
+        m.publish_grads = False
+        hist = []
+        for _ in range(8):
+            out = train_step(m, a, v, 2e-4)
+            hist.append([float(x.item()) for x in out])
+    finally:
+        engine.FP8, engine.RECOMPUTE = "0", "0"
+    assert all(x == x and abs(x) < 1e4 for h in hist for x in h), hist
+    assert hist[-1][0] < hist[0][0], (hist[0], hist[-1])          # loss_mae
