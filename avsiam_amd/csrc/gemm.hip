@@ -42,6 +42,8 @@ struct GemmNtArgs {
     // two weight sets in one launch (avs_gemm_nt_bf16_dual): rows [m_split, M) use B2 / bias2 / colsum2 instead of
     // B / bias / colsum.  m_split is a multiple of 256, so a tile (full or half-height) never straddles it.
     int m_split; const bf16_t* B2; const float* bias2; float* colsum2;
+    // fp8-forward mode, act 1 only: out8 (may be NULL) receives e4m3(clamp(gelu(x) * out8_scale, +-448)) - the operand of the fc2 GEMM
+    uint8_t* out8; long long ldo8; float out8_scale;
 };
 
 
@@ -164,7 +166,7 @@ __device__ __forceinline__ void nt_epilogue_stage_bias(const GemmNtArgs& a, char
     sbias[lane] = bias ? bias[nw0 + lane] : 0.f;
 }
 
-template <int ACT, int MI>
+template <int ACT, int MI, bool Q8 = false>
 __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], EpiPrefetch<MI>& pf, char* smem, int wave, int lane,
                                             int mw0, int nw0) {
     const int fr = lane & 15, fq = lane >> 4;
@@ -262,6 +264,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                         gq.x = pack_bf2(gelu_erf(v0[0]), gelu_erf(v0[1])); gq.y = pack_bf2(gelu_erf(v0[2]), gelu_erf(v0[3]));
                         gq.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); gq.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
                         NT_STORE(reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n), (u32x4{gq.x, gq.y, gq.z, gq.w}));
+                        if (Q8 && a.out8) {
+                            const float q = a.out8_scale;
+                            auto q8 = [&](float x) { return __builtin_amdgcn_fmed3f(gelu_erf(x) * q, -448.f, 448.f); };
+                            int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q8(v0[0]), q8(v0[1]), 0, false);
+                            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q8(v0[2]), q8(v0[3]), w0, true);
+                            int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q8(v1[0]), q8(v1[1]), 0, false);
+                            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q8(v1[2]), q8(v1[3]), w1, true);
+                            *reinterpret_cast<uint2*>(a.out8 + (size_t)m * a.ldo8 + n) = make_uint2((unsigned)w0, (unsigned)w1);
+                        }
                     }
                 }
             }
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
                 for (int j = 0; j < MI; ++j) acc[i][j] *= a.alpha;
             GemmNtArgs e = a;
             e.alpha = 1.0f;
-            nt_epilogue<ACT, MI>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
+            nt_epilogue<ACT, MI, true>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
         } else {
             nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
         }
@@ -980,7 +991,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt: the residual add is implemented for fp32 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M,
-                 m_split, B2, bias2, colsum2};
+                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;
@@ -1066,7 +1077,8 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
 // x = alpha * (A8 . B8^T) + bias (+ res); alpha carries the product of the two de-quantisation scales.
 extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long ldb, int M, int N, int K, const float* bias,
                                const float* res, long long ldr, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2, float alpha,
-                               int act, int scale_cols, float col_scale, hipStream_t stream) {
+                               int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale, hipStream_t stream) {
+    AVS_CHECK_ARG(!out8 || (act == 1 && (ldo8 % 8) == 0 && ldo8 >= N), "gemm_nt_fp8: the e4m3 copy of gelu(x) goes with act 1");
     AVS_CHECK_ARG(M > 0 && N > 0 && K >= 256 && (N % 256) == 0 && (K % 128) == 0, "gemm_nt_fp8: need N%%256==0, K%%128==0, K>=256 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && (ldo % (out_f32 ? 4 : 8)) == 0,
                   "gemm_nt_fp8: operands must keep 16-byte alignment");
@@ -1085,7 +1097,8 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
     }
     // the fp8 matrices as the bf16 matrices they alias (see gemm_nt8_kernel): half the columns, half the leading dimension
     GemmNtArgs a{reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, M, N, K / 2, bias, res, ldr, nullptr, nullptr, 0,
-                 out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, nullptr, M, 0x7fffffff, nullptr, nullptr, nullptr};
+                 out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, nullptr, M, 0x7fffffff, nullptr, nullptr, nullptr,
+                 out8, ldo8, out8_scale};
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;

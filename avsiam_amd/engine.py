@@ -94,11 +94,11 @@ class BlockParams:
         self.fc2 = Linear(arena, f"{prefix}.mlp.fc2.weight", f"{prefix}.mlp.fc2.bias")
 
 
-def _ln_fwd(x, norms, y, mean, rstd, rows, eps, row_mod=None, out_map=None):
+def _ln_fwd(x, norms, y, mean, rstd, rows, eps, row_mod=None, out_map=None, y8=None, q8=1.0):
     n0 = norms[0]
     n1 = norms[1] if len(norms) > 1 else None
     ops.layernorm_fwd(x, n0.g, n0.b, y, mean, rstd, rows, eps, n1.g if n1 else None, n1.b if n1 else None,
-                      row_mod if n1 else None, out_map)
+                      row_mod if n1 else None, out_map, y8=y8, q8=q8)
 
 
 def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None, dcol=None):
@@ -186,6 +186,8 @@ class Stack:
             self.a8 = torch.empty((ops.pad_rows(rows, 256), max(D, hidden)), dtype=U8, device=dev)     # the activation in front of a GEMM
             self.w8 = torch.empty((max(3 * D, hidden) * max(D, hidden),), dtype=U8, device=dev)          # that GEMM's weight
             self.fp8_scale = {}                                                                          # (block, tensor) -> scale, fixed at first use
+            self.ln8 = torch.zeros((ops.pad_rows(rows, 256), D), dtype=U8, device=dev)                   # e4m3 copy a LayerNorm writes for its GEMM
+            self.act8 = torch.zeros((ops.pad_rows(rows, 256), hidden), dtype=U8, device=dev)             # ... and fc1's GELU epilogue for fc2
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
         # rows per attention workgroup (4 or 2 waves of 32 queries / keys), by the mean sequence length of the stack - measured on the
@@ -255,30 +257,40 @@ class Stack:
         if b2 is not None:
             dq, dp = (split, b2.qkv.w, b2.qkv.b, None), (split, b2.proj.w, b2.proj.b, None)
             d1, d2 = (split, b2.fc1.w, b2.fc1.b, None), (split, b2.fc2.w, b2.fc2.b, None)
-        gemm = self._gemm_fp8 if self.fp8 and b2 is None else self._gemm_bf16
-        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
-        gemm((i, "qkv"), self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq)
+        f8 = self.fp8 and b2 is None
+        gemm = self._gemm_fp8 if f8 else self._gemm_bf16
+        # once a GEMM's activation scale is fixed (after its first use) the LayerNorm in front of it writes the e4m3 copy itself
+        q_qkv = self.fp8_scale.get((i, "qkv")) if f8 else None
+        q_fc1 = self.fp8_scale.get((i, "fc1")) if f8 else None
+        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod, y8=self.ln8 if q_qkv else None, q8=q_qkv[0] if q_qkv else 1.0)
+        gemm((i, "qkv"), self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq,
+             **({"a8": self.ln8} if q_qkv else {}))
         ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i])
         gemm((i, "proj"), self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x, dual=dp)
-        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)
-        gemm((i, "fc1"), self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1)
+        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod, y8=self.ln8 if q_fc1 else None, q8=q_fc1[0] if q_fc1 else 1.0)
+        q_fc2 = self.fp8_scale.get((i, "fc2")) if f8 and last_gemm else None           # ... and fc1's GELU epilogue the copy for fc2
+        gemm((i, "fc1"), self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1,
+             **({"a8": self.ln8} if q_fc1 else {}), **({"out8": self.act8, "out8_scale": q_fc2[0]} if q_fc2 else {}))
         if last_gemm:
-            gemm((i, "fc2"), self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2)
+            gemm((i, "fc2"), self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2,
+                 **({"a8": self.act8} if q_fc2 else {}))
 
     @staticmethod
     def _gemm_bf16(key, A, W, out, M, dual=None, **kw):
         ops.gemm_nt(A, W, out, M, dual=dual, **kw)
 
-    def _gemm_fp8(self, key, A, W, out, M, dual=None, **kw):
-        """The same forward GEMM on e4m3 copies of its operands (module comment at FP8)."""
+    def _gemm_fp8(self, key, A, W, out, M, dual=None, a8=None, **kw):
+        """The same forward GEMM on e4m3 copies of its operands (module comment at FP8).  a8: the activation already in e4m3 at this
+        GEMM's scale (written by its producer)."""
         assert dual is None
         K, N = A.shape[1], W.shape[0]
         sc = self.fp8_scale.get(key)
         if sc is None:                                            # first use: per-tensor amax (synchronises once per tensor)
             sc = self.fp8_scale[key] = (ops.FP8_MAX / (2.0 * max(ops.absmax(A), 1e-12)), ops.FP8_MAX / (2.0 * max(ops.absmax(W), 1e-12)))
-        a8 = self.a8[:A.shape[0], :K] if self.a8.shape[1] == K else self.a8.view(-1)[:A.shape[0] * K].view(A.shape[0], K)
         w8 = self.w8[:N * K].view(N, K)
-        ops.quantize_fp8(A, sc[0], out=a8)
+        if a8 is None:
+            a8 = self.a8[:A.shape[0], :K] if self.a8.shape[1] == K else self.a8.view(-1)[:A.shape[0] * K].view(A.shape[0], K)
+            ops.quantize_fp8(A, sc[0], out=a8)
         ops.quantize_fp8(W, sc[1], out=w8)
         ops.gemm_nt_fp8(a8, w8, out, M, 1.0 / (sc[0] * sc[1]), **kw)
 

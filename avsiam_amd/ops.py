@@ -88,7 +88,7 @@ def layernorm_ws(rows, D):
     return _lib.load().avs_layernorm_ws_floats(rows, D)
 
 
-def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod=None, out_map=None):
+def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod=None, out_map=None, y8=None, q8=1.0):
     D = x.shape[1]
     _chk(x, F32, "ln.x", 2); _chk(y, y.dtype if y.dtype in (BF16, F32) else BF16, "ln.y", 2); _chk(mean, F32, "ln.mean"); _chk(rstd, F32, "ln.rstd")
     _chk(g0, F32, "ln.g0"); _chk(b0, F32, "ln.b0"); _chk(g1, F32, "ln.g1"); _chk(b1, F32, "ln.b1")
@@ -101,8 +101,11 @@ def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod
         assert out_map.numel() >= rows
     else:
         assert y.shape[0] >= rows
-    _launch("layernorm_fwd", float(rows) * D * (4 + y.element_size()), "avs_layernorm_fwd", x, g0, b0, g1, b1, row_mod, out_map, y, 1 if y.dtype == F32 else 0, mean, rstd, rows, D,
-              float(eps), _stream())
+    if y8 is not None:
+        _chk(y8, U8, "ln.y8", 2)
+        assert y8.shape[1] == D and y8.shape[0] >= rows and y.dtype == BF16 and out_map is None
+    _launch("layernorm_fwd", float(rows) * D * (4 + y.element_size()), "avs_layernorm_fwd_q8", x, g0, b0, g1, b1, row_mod, out_map, y, 1 if y.dtype == F32 else 0, mean, rstd, rows, D,
+              float(eps), y8, float(q8), _stream())
 
 
 def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=None, db1=None, row_mod=None,
@@ -190,16 +193,17 @@ def quantize_fp8(x, scale, out=None):
     return y
 
 
-def gemm_nt_fp8(A8, B8, out, M, alpha, bias=None, res=None, out2=None, act=0, scale_cols=0, col_scale=1.0):
+def gemm_nt_fp8(A8, B8, out, M, alpha, bias=None, res=None, out2=None, act=0, scale_cols=0, col_scale=1.0, out8=None, out8_scale=1.0):
     """x = alpha * (A8[M, K] @ B8[N, K]^T) + bias (+ res); act 0: out = x; act 1: out = gelu'(x), out2 = gelu(x) (like gemm_nt).
     A8 / B8: uint8 tensors of e4m3 values (quantize_fp8), alpha = 1 / (scale_A * scale_B)."""
     _chk(A8, U8, "gemm8.A", 2); _chk(B8, U8, "gemm8.B", 2); _chk(bias, F32, "gemm8.bias"); _chk(res, F32, "gemm8.res", 2); _chk(out2, BF16, "gemm8.out2", 2)
+    _chk(out8, U8, "gemm8.out8", 2)
     assert out.dtype in (BF16, F32) and out.dim() == 2 and out.is_contiguous()
     N, K = B8.shape
     assert A8.shape[1] == K and A8.shape[0] >= M and out.shape[0] >= M and out.shape[1] == N
     _launch("gemm_nt_fp8", 2.0 * M * N * K, "avs_gemm_nt_fp8", A8, A8.stride(0), B8, B8.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
             out, out.stride(0), 1 if out.dtype == F32 else 0, out2, out2.stride(0) if out2 is not None else 0, float(alpha), int(act), int(scale_cols),
-            float(col_scale), _stream())
+            float(col_scale), out8, out8.stride(0) if out8 is not None else 0, float(out8_scale), _stream())
 
 
 def gemm_tn(A, B, C, M, splits=0):

@@ -34,6 +34,11 @@ int avs_layernorm_ws_floats(int rows, int D);
 int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
                       const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd, int rows,
                       int D, float eps, avs_stream_t stream);
+/* the same, also writing y8 = e4m3(clamp(y * q8, +-448)) (bf16 output only; y8 may be NULL): the fp8 operand of the forward GEMM that
+ * consumes this LayerNorm in the fp8-forward mode, without a quantising pass of its own */
+int avs_layernorm_fwd_q8(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
+                         const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd, int rows,
+                         int D, float eps, uint8_t* y8, float q8, avs_stream_t stream);
 /* dx = dres + LN'(dy) (dres may be NULL; dx may alias dres); dy is bf16, or fp32 when dy_f32; dx_bf16 (may be NULL) gets a
  * bf16 copy of dx; dg/db are accumulated (+=); dcol (may be NULL) accumulates the column sum of dx, i.e. the bias gradient
  * of the Linear that produced this residual branch; ws: avs_layernorm_ws_floats */
@@ -57,13 +62,14 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
                      int act, int scale_cols, float col_scale, float* colsum, avs_stream_t stream);
 /* ---- fp8 (OCP e4m3) variant of the forward / input-gradient GEMM (BASELINE configs[4]'s "fp8 MFMA path"; not used by the default
  * bf16 path): x = alpha * (A8[M,K] . B8[N,K]^T) + bias (+ res, fp32 output only); act 0: out = x (columns [0, scale_cols) times col_scale);
- * act 1: out = gelu'(x), out2 = gelu(x) (bf16), as in avs_gemm_nt_bf16.  fp32 accumulation on v_mfma_f32_16x16x128_f8f6f4,
+ * act 1: out = gelu'(x), out2 = gelu(x) (bf16), as in avs_gemm_nt_bf16, and out8 (may be NULL) = e4m3(gelu(x) * out8_scale) for the next fp8 GEMM.
+ * fp32 accumulation on v_mfma_f32_16x16x128_f8f6f4,
  * the 8-phase 256x256 kernel of the bf16 GEMM with 128-value K-tiles.  alpha carries 1 / (scale_A * scale_B).  N%256==0, K%128==0,
  * K>=256, leading dimensions multiples of 16.  avs_absmax: out = max(out, max |x|) (caller zeroes out; x fp32 or bf16);
  * avs_quantize_fp8: y = e4m3(clamp(x * scale, +-448)), n%4==0. */
 int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long ldb, int M, int N, int K, const float* bias,
                     const float* res, long long ldr, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
-                    int act, int scale_cols, float col_scale, avs_stream_t stream);
+                    int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale, avs_stream_t stream);
 int avs_absmax(const void* x, int is_f32, long long n, float* out, avs_stream_t stream);
 int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, avs_stream_t stream);
 /* the same GEMM over TWO weight sets in one launch: rows [0, m_split) of A meet B / bias / colsum, rows [m_split, M) meet
