@@ -97,7 +97,7 @@ __global__ void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const in
 // columns with one 16-byte load each (a full 128-B line per row), 32 row-lanes stride the rows; partial sums are
 // combined through LDS and leave as one atomic per column per block.
 constexpr int COLSUM_ROWS = 512;
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* out, int rows, int C) {
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long long ld, float* out, int rows) {
     __shared__ float red[32][65];
     const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c0 = blockIdx.x * 64 + cg * 8;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     const int r1 = min(rows, r0 + COLSUM_ROWS);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = r0 + rl; r < r1; r += 32) {
-        const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)r * C + c0);
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)r * ld + c0);
         acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
         acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
         acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
@@ -450,11 +450,40 @@ extern "C" int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long
     return 0;
 }
 
-extern "C" int avs_colsum_bf16(const bf16_t* x, float* out, int rows, int C, hipStream_t stream) {
-    AVS_CHECK_ARG(rows > 0 && (C % 64) == 0 && x && out, "colsum: C must be a multiple of 64");
+extern "C" int avs_colsum_bf16(const bf16_t* x, long long ld, float* out, int rows, int C, hipStream_t stream) {
+    AVS_CHECK_ARG(rows > 0 && (C % 64) == 0 && ld >= C && (ld % 8) == 0 && x && out, "colsum: C must be a multiple of 64, ld of 8");
     dim3 grid(C / 64, ceil_div(rows, COLSUM_ROWS));
-    colsum_bf16_kernel<<<grid, 256, 0, stream>>>(x, out, rows, C);
+    colsum_bf16_kernel<<<grid, 256, 0, stream>>>(x, ld, out, rows);
     AVS_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+// y[n] += alpha * sum_k x[k] * W[k][n]   (x fp32 [K], W bf16 [K][N] with leading dimension ld, y fp32 [N]; N % 256 == 0, K % 32 == 0).
+// The value third of the qkv bias gradient: rows of the softmax sum to one, so d(loss)/d(b_v) = column sum of dO, and dO = dY.W_proj
+// gives colsum(dO) = colsum(dY).W_proj = (proj bias gradient).W_proj - a [D] x [D, D] product of quantities the backward already
+// holds, instead of a pass over the [rows, 3D] qkv gradient (the key third is identically zero: a key bias shifts every score of a
+// query alike).  Attention.qkv / proj: /root/reference/src/models/cav_mae_base.py:51,60-77.
+__global__ __launch_bounds__(256) void vecmat_bf16_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W, long long ld,
+                                                          float* y, float alpha) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + lane * 4;
+    const int k0 = blockIdx.y * 32 + wave * 8;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xv = x[k0 + j];
+        const uint2 w = *reinterpret_cast<const uint2*>(W + (size_t)(k0 + j) * ld + n);
+        acc[0] = fmaf(xv, __uint_as_float(w.x << 16), acc[0]); acc[1] = fmaf(xv, __uint_as_float(w.x & 0xffff0000u), acc[1]);
+        acc[2] = fmaf(xv, __uint_as_float(w.y << 16), acc[2]); acc[3] = fmaf(xv, __uint_as_float(w.y & 0xffff0000u), acc[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(y + n + j, alpha * acc[j]);
+}
+
+extern "C" int avs_vecmat_bf16(const float* x, const bf16_t* W, long long ld, float* y, int K, int N, float alpha, hipStream_t stream) {
+    AVS_CHECK_ARG(x && W && y && K > 0 && N > 0 && (N % 256) == 0 && (K % 32) == 0 && ld >= N && (ld % 4) == 0, "vecmat: N %% 256, K %% 32");
+    vecmat_bf16_kernel<<<dim3(N / 256, K / 32), 256, 0, stream>>>(x, W, ld, y, alpha);
+    AVS_LAUNCH_CHECK("vecmat");
     return 0;
 }
 

@@ -80,12 +80,14 @@ constexpr int LN_MIN_ROWS_PER_WAVE = 4;      // the workspace is sized for this 
 constexpr int LN_SETS = 5;                   // dgamma0, dbeta0, dgamma1, dbeta1, column-sum of dx
 constexpr int LN_REDUCE_CHUNKS = 64;
 
-template <int NV, bool F32IO, bool HAS_RES, int LN_ROWS_PER_WAVE>
+// RES: 0 no residual gradient | 1 fp32 dres | 2 bf16 dres (the bf16 gradient stream: the previous LayerNorm backward's dx_bf16).
+// dx (fp32) may be NULL when only the bf16 copy is wanted.
+template <int NV, bool F32IO, int RES, int LN_ROWS_PER_WAVE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ g0, const float* __restrict__ g1,
                                                      const uint8_t* __restrict__ row_mod, const int* __restrict__ out_map,
-                                                     const float* dres, float* dx, bf16_t* __restrict__ dx_bf16,
+                                                     const void* dres, float* dx, bf16_t* __restrict__ dx_bf16,
                                                      float* __restrict__ ws, int rows) {
     constexpr int D = NV * 256;
     constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
@@ -118,9 +120,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         float s1 = 0.f, s2 = 0.f;
         // the residual-gradient row is loaded together with x and dy (not after the two reductions, where its latency
         // would be exposed once per row)
-        const float4* drr = reinterpret_cast<const float4*>(dres + (size_t)row * D);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) rsd[i] = HAS_RES ? drr[i * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NV; ++i) {
+            if (RES == 1) {
+                rsd[i] = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dres) + (size_t)row * D)[i * 64 + lane];
+            } else if (RES == 2) {
+                const uint2 rv = reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(dres) + (size_t)row * D)[i * 64 + lane];
+                rsd[i] = make_float4(__uint_as_float(rv.x << 16), __uint_as_float(rv.x & 0xffff0000u), __uint_as_float(rv.y << 16),
+                                     __uint_as_float(rv.y & 0xffff0000u));
+            } else {
+                rsd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float4 xv = xr[i * 64 + lane];
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             float4 o;
             o.x = rs * (gy[i].x - m1 - xh[i].x * m2) + rsd[i].x; o.y = rs * (gy[i].y - m1 - xh[i].y * m2) + rsd[i].y;
             o.z = rs * (gy[i].z - m1 - xh[i].z * m2) + rsd[i].z; o.w = rs * (gy[i].w - m1 - xh[i].w * m2) + rsd[i].w;
-            dxr[i * 64 + lane] = o;
+            if (dx) dxr[i * 64 + lane] = o;
             dc[i].x += o.x; dc[i].y += o.y; dc[i].z += o.z; dc[i].w += o.w;      // column sum of dx (bias grad of the producer Linear)
             if (dx_bf16) {
                 uint2 ob;
@@ -228,13 +239,16 @@ extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b
 
 // dg*/db* are ACCUMULATED into (+=); dx may alias dres; dx_bf16 (optional) receives a bf16 copy of dx; dcol (optional)
 // accumulates the column sum of dx (the bias gradient of the Linear whose output gradient dx is).
+// dres_bf16: dres is a bf16 matrix (the previous LayerNorm backward's dx_bf16: the residual-gradient stream kept in bf16 between the
+// blocks, 6 B per element less traffic); dx may then be NULL (only the bf16 copy is written).  dx_bf16 must not alias a bf16 dres.
 // ws: avs_layernorm_ws_floats(rows, D) floats.
 extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd,
                                  const float* g0, const float* g1, const uint8_t* row_mod, const int* out_map,
-                                 const float* dres, float* dx, bf16_t* dx_bf16, float* dg0, float* db0, float* dg1,
+                                 const void* dres, int dres_bf16, float* dx, bf16_t* dx_bf16, float* dg0, float* db0, float* dg1,
                                  float* db1, float* dcol, float* ws, int rows, int D, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
-    AVS_CHECK_ARG(dy && x && mean && rstd && g0 && dx && ws, "layernorm_bwd: null pointer");
+    AVS_CHECK_ARG(dy && x && mean && rstd && g0 && (dx || dx_bf16) && ws, "layernorm_bwd: null pointer");
+    AVS_CHECK_ARG(!(dres && dres_bf16 && (const void*)dx_bf16 == dres), "layernorm_bwd: dx_bf16 must not alias a bf16 dres");
     if (g_ln_rpw < 0) { const char* e = getenv("AVSIAM_LN_RPW"); g_ln_rpw = e ? atoi(e) : 0; }
     // A block of 4 waves x RPW rows writes one slab of parameter-gradient partial sums; fewer rows per wave = more blocks
     // (helps only when 16 rows leave most CUs with a single block) and more slab traffic.
@@ -244,8 +258,9 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
     dim3 grid(nblocks), block(256);
 #define LN_BWD_R(NV, F, R)                                                                                                                     \
     do {                                                                                                                                       \
-        if (dres) ln_bwd_kernel<NV, F, true, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);   \
-        else ln_bwd_kernel<NV, F, false, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);       \
+        if (dres && dres_bf16) ln_bwd_kernel<NV, F, 2, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);   \
+        else if (dres) ln_bwd_kernel<NV, F, 1, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);   \
+        else ln_bwd_kernel<NV, F, 0, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);       \
     } while (0)
 #define LN_BWD(NV, F)                                                                                                                          \
     do {                                                                                                                                       \

@@ -40,6 +40,13 @@ RECOMPUTE = os.environ.get("AVSIAM_RECOMPUTE", "0")
 # GEMM with a per-tensor scale fixed at first use (448 / (2 * amax): static scaling with a 2x margin, saturating) - and accumulate in
 # fp32; everything the backward reads is still produced in bf16 and the backward itself is the bf16 one.
 FP8 = os.environ.get("AVSIAM_FP8", "0")
+# The residual-GRADIENT stream between the blocks of a stack (AVSIAM_GRAD_STREAM=bf16 | fp32).  bf16 (default): a LayerNorm backward
+# reads the upstream residual gradient from the bf16 copy the previous LayerNorm backward wrote for the GEMMs anyway and writes
+# only its own bf16 copy - 10 instead of 16 bytes per element and call (the kernel is HBM-bound); the sum itself is formed in fp32
+# registers and rounded once per LayerNorm (2 x depth roundings of 2^-9 along a stack: ~0.5 % rms at the bottom of 12 blocks,
+# inside the bf16 operand noise the gradients already carry).  A stack's OUTPUT gradient (block 0) is still written in fp32.
+# fp32: the round-2 behaviour (fp32 stream beside the bf16 copies).
+GRAD_STREAM = os.environ.get("AVSIAM_GRAD_STREAM", "bf16")
 
 
 def _z(shape, dtype, dev):
@@ -107,6 +114,11 @@ def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, 
     n1 = norms[1] if len(norms) > 1 else None
     ops.layernorm_bwd(dy, x, mean, rstd, n0.g, dx, n0.dg, n0.db, ws, rows, n1.g if n1 else None, n1.dg if n1 else None,
                       n1.db if n1 else None, row_mod if n1 else None, out_map, dres, dx_bf16, dcol)
+
+
+def _dx_in(stack):
+    """fp32 buffer for the gradient a stack's backward STARTS from: only the fp32 gradient stream reads it"""
+    return None if GRAD_STREAM == "bf16" else stack.dx[0]
 
 
 class _SideStream:
@@ -295,7 +307,8 @@ class Stack:
         ops.gemm_nt_fp8(a8, w8, out, M, 1.0 / (sc[0] * sc[1]), **kw)
 
     def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0, reducer=None):
-        """In: d(out) in self.dx[0] (fp32) and self.dxb[0] (bf16).  Out: d(x[0]) in the same two buffers.
+        """In: d(out) in self.dxb[0] (bf16) - and in self.dx[0] (fp32) when GRAD_STREAM is "fp32".  Out: d(x[0]) in self.dx[0] (fp32)
+        and self.dxb[0].
         reducer (comm.GradReducer, data parallel): told which ranges of the gradient arena are final as the blocks complete.
         Bias gradients of fc2 / proj are column sums of the residual-stream gradient and come out of the LayerNorm
         backward that produces it (`dcol`); `last_fc2_bias_done` says the caller's LN backward already did that for
@@ -314,6 +327,7 @@ class Stack:
         mode = "0" if self.recompute else WGRAD_STREAM_MODE
         side = _side_stream(dxo.device) if mode in ("1", "2") else _Inline()
         excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
+        g16 = GRAD_STREAM == "bf16"   # the residual gradient travels between the LayerNorm backwards in bf16 only
 
         def block_done(j):
             """Every kernel writing block j's parameter gradients is queued on the current stream or joined into it."""
@@ -355,8 +369,8 @@ class Stack:
                 wgrads(i, "dfc1", (self.dfc1, self.ln2[i], "fc1"))
                 side.before_write("dbm")
             for lo, hi, bl in ranges:
-                _ln_bwd(self.dln[lo:], self.xmid[i][lo:], st[2][lo:], st[3][lo:], bl[i].n2, dxm[lo:], self.lnws, hi - lo,
-                        None if one else self.row_mod, dres=dxo[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb)
+                _ln_bwd(self.dln[lo:], self.xmid[i][lo:], st[2][lo:], st[3][lo:], bl[i].n2, None if g16 else dxm[lo:], self.lnws, hi - lo,
+                        None if one else self.row_mod, dres=(dbo if g16 else dxo)[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb)
             # proj
             ops.gemm_nt(dbm, bp.proj.wt, self.datt, M, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
             if excl:                  # the three wgrads whose operands exist now run beside the attention backward
@@ -373,9 +387,13 @@ class Stack:
             if not excl:
                 side.before_write("dbo")
             for lo, hi, bl in ranges:
-                ops.colsum(self.dqkv[lo:], bl[i].qkv.gb, hi - lo)
-                _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, dxo[lo:], self.lnws, hi - lo,
-                        None if one else self.row_mod, dres=dxm[lo:], dx_bf16=dbo[lo:],
+                # qkv bias gradient: only the query third needs the dqkv matrix.  value third = column sum of dO = (proj bias
+                # gradient, complete since this block's LayerNorm-2 backward) . W_proj; key third = 0 exactly (ops.vecmat)
+                D = self.D
+                ops.colsum(self.dqkv[lo:, :D], bl[i].qkv.gb[:D], hi - lo)
+                ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * D:])
+                _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, None if g16 and i > 0 else dxo[lo:], self.lnws,
+                        hi - lo, None if one else self.row_mod, dres=(dbm if g16 else dxm)[lo:], dx_bf16=dbo[lo:],
                         dcol=bl[i - 1].fc2.gb if i > 0 else None)
         side.join()
         if reducer is not None:
@@ -639,7 +657,7 @@ class ContrastivePass:
         self.dreps[B:].copy_(self.dV[r * B:(r + 1) * B])
         torch.index_select(self.dreps, 0, self.slot_to_row, out=self.dreps_slot)
         ops.segment_mean_bwd(self.dreps_slot, self.seg_start, self.yf, 2 * B, float(W))
-        _ln_bwd(self.yf, st.out, self.fstat[0], self.fstat[1], self.final, st.dx[0], st.lnws, self.rows, st.row_mod,
+        _ln_bwd(self.yf, st.out, self.fstat[0], self.fstat[1], self.final, _dx_in(st), st.lnws, self.rows, st.row_mod,
                 dx_bf16=st.dxb[0], dcol=self.blocks[-1].fc2.gb)
         st.backward(self.blocks, last_fc2_bias_done=True, reducer=reducer)
         self.emb_a.backward(st.dx[0][:self.rows_a])
@@ -832,7 +850,7 @@ class MaePass:
         ops.colsum(self.dp_v, self.pred_v.gb, self.nv_rows)
         sd = self.st_dec
         rows_d = B * self.Ltot
-        _ln_bwd(self.ddn, sd.out, self.dn_stat[0], self.dn_stat[1], self.dec_norm, sd.dx[0], sd.lnws, rows_d,
+        _ln_bwd(self.ddn, sd.out, self.dn_stat[0], self.dn_stat[1], self.dec_norm, _dx_in(sd), sd.lnws, rows_d,
                 out_map=self.dn_map, dx_bf16=sd.dxb[0], dcol=self.blk_dec[-1].fc2.gb)
         sd.backward(self.blk_dec, last_fc2_bias_done=True, reducer=reducer)
         g = self.gtok
@@ -841,24 +859,27 @@ class MaePass:
         rows_j = B * self.n_enc
         ops.cast_scale(self.dde, self.dde_b, rows_j * Dd, 1.0)
         sm = self.st_mm
-        ops.gemm_nt(self.dde_b, self.dec_embed.wt, sm.dx[0], rows_j)
+        if GRAD_STREAM == "bf16":                       # the joint layers' backward starts from the bf16 gradient alone
+            ops.gemm_nt(self.dde_b, self.dec_embed.wt, sm.dxb[0], rows_j)
+        else:
+            ops.gemm_nt(self.dde_b, self.dec_embed.wt, sm.dx[0], rows_j)
+            ops.cast_scale(sm.dx[0], sm.dxb[0], rows_j * D, 1.0)
         ops.gemm_tn(self.dde_b, self.xj_b, self.dec_embed.gw, rows_j)
         ops.colsum(self.dde_b, self.dec_embed.gb, rows_j)
-        ops.cast_scale(sm.dx[0], sm.dxb[0], rows_j * D, 1.0)
         sm.backward(self.blk_mm, reducer=reducer)
         if self.grouped:
             st, ra = self.st_t, self.rows_a
             for lo, fin, fstat, omap, rows, blks in ((0, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.blk_a),
                                                      (ra, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.blk_v)):
-                _ln_bwd(sm.dx[0], st.out[lo:], fstat[0], fstat[1], fin, st.dx[0][lo:], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0][lo:],
-                        dcol=blks[-1].fc2.gb)
+                _ln_bwd(sm.dx[0], st.out[lo:], fstat[0], fstat[1], fin, None if GRAD_STREAM == "bf16" else st.dx[0][lo:], st.lnws, rows,
+                        out_map=omap, dx_bf16=st.dxb[0][lo:], dcol=blks[-1].fc2.gb)
             st.backward(self.blk_a, last_fc2_bias_done=True, blocks2=self.blk_v, split=ra, reducer=reducer)
             self.emb_a.backward(st.dx[0][:ra])
             self.emb_v.backward(st.dx[0][ra:])
             return
         for st, fin, fstat, omap, rows, emb, blks in ((self.st_a, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.emb_a, self.blk_a),
                                                       (self.st_v, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.emb_v, self.blk_v)):
-            _ln_bwd(sm.dx[0], st.out, fstat[0], fstat[1], fin, st.dx[0], st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0],
+            _ln_bwd(sm.dx[0], st.out, fstat[0], fstat[1], fin, _dx_in(st), st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0],
                     dcol=blks[-1].fc2.gb)
             st.backward(blks, last_fc2_bias_done=True, reducer=reducer)
             emb.backward(st.dx[0])

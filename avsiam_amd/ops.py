@@ -110,24 +110,30 @@ def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod
 
 def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=None, db1=None, row_mod=None,
                   out_map=None, dres=None, dx_bf16=None, dcol=None):
+    """dres: fp32, or bf16 (the residual-gradient stream kept in bf16: the previous call's dx_bf16); dx (fp32) may be None when
+    dx_bf16 is given."""
     D = x.shape[1]
     _chk(dy, dy.dtype if dy.dtype in (BF16, F32) else BF16, "lnb.dy", 2); _chk(x, F32, "lnb.x", 2); _chk(dx, F32, "lnb.dx", 2)
-    _chk(dres, F32, "lnb.dres", 2); _chk(dx_bf16, BF16, "lnb.dx_bf16", 2); _chk(dcol, F32, "lnb.dcol")
+    _chk(dres, dres.dtype if dres is not None and dres.dtype in (BF16, F32) else F32, "lnb.dres", 2)
+    _chk(dx_bf16, BF16, "lnb.dx_bf16", 2); _chk(dcol, F32, "lnb.dcol")
     assert dcol is None or dcol.numel() == D
+    assert dx is not None or dx_bf16 is not None
     if dx_bf16 is not None:
         assert dx_bf16.shape[0] >= rows and dx_bf16.shape[1] == D
+        assert dres is None or dres.dtype != BF16 or dres.data_ptr() != dx_bf16.data_ptr(), "dx_bf16 must not alias a bf16 dres"
     _chk(ws, F32, "lnb.ws"); _chk(row_mod, U8, "lnb.row_mod"); _chk(out_map, I32, "lnb.out_map")
     for t, n in ((g0, "g0"), (g1, "g1"), (dg0, "dg0"), (db0, "db0"), (dg1, "dg1"), (db1, "db1"), (mean, "mean"), (rstd, "rstd")):
         _chk(t, F32, "lnb." + n)
-    assert x.shape[0] >= rows and dx.shape[0] >= rows and dy.shape[1] == D and dx.shape[1] == D
+    assert x.shape[0] >= rows and dy.shape[1] == D and (dx is None or (dx.shape[0] >= rows and dx.shape[1] == D))
     assert ws.numel() >= layernorm_ws(rows, D)
     if out_map is None:
         assert dy.shape[0] >= rows
     if dres is not None:
         assert dres.shape[0] >= rows and dres.shape[1] == D
-    _launch("layernorm_bwd", float(rows) * D * (dy.element_size() + 4 + 4 + (4 if dres is not None else 0) + (2 if dx_bf16 is not None else 0)),
-            "avs_layernorm_bwd", dy, 1 if dy.dtype == F32 else 0, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16,
-            dg0, db0, dg1, db1, dcol, ws, rows, D, _stream())
+    nbytes = dy.element_size() + 4 + (4 if dx is not None else 0) + (dres.element_size() if dres is not None else 0) + (2 if dx_bf16 is not None else 0)
+    _launch("layernorm_bwd", float(rows) * D * nbytes,
+            "avs_layernorm_bwd", dy, 1 if dy.dtype == F32 else 0, x, mean, rstd, g0, g1, row_mod, out_map, dres,
+            1 if dres is not None and dres.dtype == BF16 else 0, dx, dx_bf16, dg0, db0, dg1, db1, dcol, ws, rows, D, _stream())
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -262,8 +268,10 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
     D = qkv.shape[1] // 3
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape and D // H in (32, 64, 80)
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
-    # algorithmic HBM bytes of the two kernels: dQ reads q, k, v, o, dO and writes dq (+ delta); dK/dV reads q, k, v, dO and writes dk, dv
-    _launch("attn_bwd_hd%d" % (D // H), (10.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
+    # algorithmic FLOP: 8 * sum L^2 * D - the four products of the backward (dV, dP, dQ, dK); the recomputation of S = Q.K^T that the
+    # kernels pay instead of keeping an L x L tensor is NOT counted.  Algorithmic HBM bytes of the two kernels: dQ
+    # reads q, k, v, o, dO and writes dq (+ delta); dK/dV reads q, k, v, dO and writes dk, dv
+    _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
             out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
 
 
@@ -361,9 +369,20 @@ def scatter_add_rows(src, idx, dst, rows, scale=1.0):
 
 
 def colsum(x, out, rows):
-    _chk(x, BF16, "colsum.x", 2); _chk(out, F32, "colsum.out")
+    """out[c] += sum_r x[r, c]; x may be a column range of a wider row-major matrix (stride(1) == 1)"""
+    if not (x.is_cuda and x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.storage_offset() % 8 == 0):
+        raise _lib.AvsiamHipError("colsum.x: need a row-major bf16 GPU matrix (or a column range of one, 16-byte aligned)")
+    _chk(out, F32, "colsum.out")
     assert x.shape[0] >= rows and out.numel() == x.shape[1]
-    _lib.call("avs_colsum_bf16", x, out, rows, x.shape[1], _stream())
+    _lib.call("avs_colsum_bf16", x, x.stride(0), out, rows, x.shape[1], _stream())
+
+
+def vecmat(x, W, y, alpha=1.0):
+    """y[n] += alpha * sum_k x[k] * W[k, n]   (x fp32 [K], W bf16 [K, N], y fp32 [N])"""
+    _chk(x, F32, "vecmat.x"); _chk(W, BF16, "vecmat.W", 2); _chk(y, F32, "vecmat.y")
+    K, N = W.shape
+    assert x.numel() == K and y.numel() == N and N % 256 == 0 and K % 32 == 0
+    _lib.call("avs_vecmat_bf16", x, W, W.stride(0), y, K, N, float(alpha), _stream())
 
 
 def unshuffle_fwd(x, src_row, pos_row, row_mod, mask_token, pos_a, pos_v, mod_a, mod_v, out, rows):

@@ -26,28 +26,13 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X
 PEAK_HBM_GBS = 8000.0          # HBM3E peak, same table (6.3 TB/s is what a float4 copy achieves)
 
 
-def cpu_baseline(cfg, batch=2, warmup=1, steps=3):
-    """the oracle (oracle/ref_cpu.py, the CPU restatement of the reference validated against it) timed on THIS
-    node's host cores in the same run, on a bounded sample of the same workload: `warmup` + `steps` full reference steps (both
-    passes forward + backward + both Adam updates) at a small batch of the same configuration, fp32 torch, all the cores the
-    process may use.  A reported baseline, never a target."""
-    import platform
+def _cpu_leg(cfg, batch, warmup, steps, cores, label):
+    """`warmup` + `steps` full reference steps (both passes forward + backward + both Adam updates) of the oracle at one shape"""
+    import random
     from avsiam_amd.flops import gflop_per_sample
     from avsiam_amd.maskplan import make_contrastive_plan, make_mae_plan
     from avsiam_amd.weights import synth_inputs, synth_state
     from oracle import ref_cpu
-    import random
-    cores, cores_note = usable_cores()
-    torch.set_num_threads(cores)
-    cpu_model = platform.processor() or "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for ln in f:
-                if ln.startswith("model name"):
-                    cpu_model = ln.split(":", 1)[1].strip()
-                    break
-    except Exception:
-        pass
     B = batch
     P = {k: t.clone().requires_grad_(True) for k, t in synth_state(cfg, 0, "init", include_dead=False).items()}
     a, v = synth_inputs(cfg, B, 87)
@@ -66,19 +51,57 @@ def cpu_baseline(cfg, batch=2, warmup=1, steps=3):
     for i in range(warmup):
         t0 = time.time()
         step()
-        log(f"cpu baseline: warm-up step {i} took {time.time() - t0:.1f} s ({cores} threads)")
+        log(f"cpu baseline [{label}]: warm-up step {i} took {time.time() - t0:.1f} s ({cores} threads)")
     times = []
     for i in range(steps):
         t0 = time.time()
         step()
         times.append(time.time() - t0)
-        log(f"cpu baseline: timed step {i} took {times[-1]:.1f} s")
+        log(f"cpu baseline [{label}]: timed step {i} took {times[-1]:.1f} s")
     dt = sum(times) / len(times)
-    return {"value": B / dt, "unit": "samples/s", "cores": cores, "cores_note": cores_note, "kind": "port", "cpu_model": cpu_model, "torch": torch.__version__,
-            "batch": B, "warmup_steps": warmup, "timed_steps": steps, "step_seconds": [round(t, 3) for t in times],
-            "sample": f"{warmup} warm-up + {steps} timed full steps (contrastive + MAE fwd/bwd, 2x Adam) at batch {B} of the same config "
-                      f"({cfg.frames} frames x{cfg.video_tokens} + {cfg.audio_tokens} audio tokens), fp32 torch CPU, {cores} threads, mean {dt:.2f} s/step",
-            "gflops": B * gflop_per_sample(cfg, B) / dt}
+    return {"config": label, "value": B / dt, "unit": "samples/s", "batch": B, "frames": cfg.frames, "audio_tokens": cfg.audio_tokens,
+            "warmup_steps": warmup, "timed_steps": steps, "step_seconds": [round(t, 3) for t in times],
+            "gflop_per_sample": gflop_per_sample(cfg, B), "gflops": B * gflop_per_sample(cfg, B) / dt}
+
+
+def cpu_baseline(cfg, batch=2, warmup=1, steps=2, survey_legs=True):
+    """SURVEY.md 8(d) / BASELINE.md section 3: the oracle (oracle/ref_cpu.py, the CPU restatement of the reference validated against
+    it) timed on THIS node's host cores in the same run, fp32 torch, all the cores the process may use - full reference steps (both
+    passes forward + backward + both Adam updates), each a bounded sample:
+      main  a small batch of the SAME configuration as the GPU line (its `value` is the object's `value`)
+      C1    BASELINE.json configs[0]: batch 4, 1 frame, 128 audio tokens           (survey_legs; ViT-B only)
+      C2    configs[1]'s shape under the reference's one-frame semantics: batch 8, 1 frame, 512 audio tokens
+    A reported baseline, never a target."""
+    import dataclasses
+    import platform
+    cores, cores_note = usable_cores()
+    torch.set_num_threads(cores)
+    cpu_model = platform.processor() or "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    main = _cpu_leg(cfg, batch, warmup, steps, cores, "same config as the GPU line, small batch")
+    B, dt = batch, sum(main["step_seconds"]) / len(main["step_seconds"])
+    out = {"value": main["value"], "unit": "samples/s", "cores": cores, "cores_note": cores_note, "kind": "port", "cpu_model": cpu_model,
+           "torch": torch.__version__, "batch": B, "warmup_steps": warmup, "timed_steps": steps, "step_seconds": main["step_seconds"],
+           "sample": f"{warmup} warm-up + {steps} timed full steps (contrastive + MAE fwd/bwd, 2x Adam) at batch {B} of the same config "
+                     f"({cfg.frames} frames x{cfg.video_tokens} + {cfg.audio_tokens} audio tokens), fp32 torch CPU, {cores} threads, mean {dt:.2f} s/step",
+           "gflops": main["gflops"]}
+    if survey_legs and cfg.embed_dim == 768 and cfg.st == cfg.patch:
+        legs = []
+        for label, kw, b, w, n in (("C1: BASELINE configs[0] (batch 4, 1 frame x196 + 128 audio tokens)", {"frames": 1, "audio_tokens": 128}, 4, 1, 3),
+                                   ("C2-shaped (batch 8, 1 frame x196 + 512 audio tokens: reference pre-training semantics)", {"frames": 1, "audio_tokens": 512}, 8, 1, 2)):
+            try:
+                legs.append(_cpu_leg(dataclasses.replace(cfg, **kw), b, w, n, cores, label))
+            except Exception as e:                                   # a report, never a gate
+                legs.append({"config": label, "value": None, "error": repr(e)})
+        out["survey_configs"] = legs
+    return out
 
 
 def usable_cores():
@@ -123,19 +146,43 @@ def _sha1(path):
         return hashlib.sha1(f.read()).hexdigest()
 
 
+def _pmc_file(args, name, kernel_file):
+    """A stored PMC summary (profiles/rNN/<name>, newest round first) if it was measured on THIS workload and on the kernel source as
+    it is now (SHA-1 stored beside the numbers); else None."""
+    if args.batch != 64 or args.frames != 10 or args.audio_tokens != 512 or args.model != "vit_base" or args.fp8 or args.recompute:
+        return None
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d["source_sha1"].get(kernel_file) == _sha1(os.path.join(ROOT, "avsiam_amd", "csrc", kernel_file)):
+                return d
+        except Exception:
+            pass
+    return None
+
+
 def pmc_traffic(args, kernel_file="gemm.hip", key="gemm_nt"):
     """HBM bytes per launch of a kernel family, measured OFFLINE with rocprofv3 PMC passes of this same command (FETCH_SIZE and
-    WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md) and stored in profiles/r02/traffic.json together with the
+    WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md) and stored in profiles/rNN/traffic.json together with the
     SHA-1 of the kernel source it was measured on.  null when the stored figure is for another workload or another kernel source."""
-    path = os.path.join(ROOT, "profiles", "r02", "traffic.json")
-    if not os.path.exists(path) or args.batch != 64 or args.frames != 10 or args.audio_tokens != 512 or args.model != "vit_base":
-        return None
+    d = _pmc_file(args, "traffic.json", kernel_file)
     try:
-        with open(path) as f:
-            d = json.load(f)
-        if d["source_sha1"].get(kernel_file) != _sha1(os.path.join(ROOT, "avsiam_amd", "csrc", kernel_file)):
-            return None
-        return float(d["kernels"][key]["hbm_bytes_per_launch"])
+        return float(d["kernels"][key]["hbm_bytes_per_launch"]) if d else None
+    except Exception:
+        return None
+
+
+def pmc_busy(args, kernel_file="gemm.hip", key="gemm_nt"):
+    """Matrix-pipe busy fraction of a kernel family (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD cycles; tools/pmc_busy.sh ->
+    profiles/rNN/pmc_busy.json), gated on the kernel source's SHA-1 like the traffic figure."""
+    d = _pmc_file(args, "pmc_busy.json", kernel_file)
+    try:
+        k = d["kernels"][key]
+        return {"mfma_busy": k["mfma_busy"], "valu_active_of_wave_time": k["valu_active_of_wave_time"], "wait_any_of_wave_time": k["wait_any_of_wave_time"]} if d else None
     except Exception:
         return None
 
@@ -162,6 +209,9 @@ def main():
                     "the line then says dtype fp8-forward/bf16-backward and is NOT the headline metric")
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved "
                     "activations do not fit the GPU, e.g. --model vit_huge at batch 64; never for the headline metric")
+    ap.add_argument("--force-dp", action="store_true", help="form the RCCL process group and issue EVERY collective of the data-parallel step "
+                    "(packed embedding all-gather, chunked overlapped gradient all-reduce) even at world size 1 - the most of the multi-GPU "
+                    "path a one-GPU box can execute; AVSIAM_COMM=rccl selects the C ABI's communicator, AVSIAM_DP_WIRE=bf16 the bf16 wire")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=2, help="steps of the separate single-stream pass that times the other kernel families")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -188,8 +238,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.model == "vit_large":
@@ -214,7 +265,11 @@ def main():
         if args.fp8:
             _engine.FP8 = "1"
     model = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
-    model.set_distributed(world, rank)
+    comm = None
+    if args.force_dp and world == 1:
+        from avsiam_amd.comm import RcclComm, TorchDistComm
+        comm = RcclComm(always=True) if os.environ.get("AVSIAM_COMM", "torch") == "rccl" else TorchDistComm(always=True)
+    model.set_distributed(world, rank, comm)
     model.publish_grads = False
     from avsiam_amd.weights import synth_inputs
     a, v = synth_inputs(cfg, args.batch, 87 + rank)
@@ -222,7 +277,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or args.force_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -260,7 +315,7 @@ def main():
         prof2, ops.prof = ops.prof, None
         _eng.WGRAD_STREAM_MODE = mode
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     losses = [float(x.item()) for x in last]
@@ -274,7 +329,10 @@ def main():
             "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x{cfg.video_tokens} + "
                                    f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
-                       "parallelism": f"dp{world}", "gflop_per_sample": gf, **({"activation_recompute": True} if args.recompute else {})},
+                       "parallelism": f"dp{world}", "gflop_per_sample": gf, **({"activation_recompute": True} if args.recompute else {}),
+                       **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
+                                        "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "allreduce_messages_last_backward": model.last_reduce_messages}}
+                          if args.force_dp else {})},
             "model_tflops": sps * gf / 1e3, "mfu_vs_dense_bf16_peak": sps * gf / 1e3 / (world * PEAK_BF16_TFLOPS),
             "final_losses": {"loss_mae": losses[0], "loss_mae_a": losses[1], "loss_mae_v": losses[2], "loss_c": losses[3], "c_acc": losses[4]},
         }
@@ -288,7 +346,7 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt8_kernel / gemm_nt_kernel (forward + dgrad bf16 MFMA GEMMs, one avs_gemm_nt_bf16 call = one launch)", "achieved": ach,
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args),
-                                "launches": n, "avg_launch_us": 1e3 * ms / n, "flops_per_launch": flops / n,
+                                "pmc": pmc_busy(args), "launches": n, "avg_launch_us": 1e3 * ms / n, "flops_per_launch": flops / n,
                                 "dispatches": nd, "avg_dispatch_us": 1e3 * ms / nd,
                                 "sampling": "all launches" if args.all_kernel_events else "every 5th launch of the timed region"}
             line["kernels"] = {k: {"launches": x["launches"], "total_ms": round(x["total_ms"], 3), "avg_us": round(x["avg_us"], 2),
@@ -296,7 +354,7 @@ def main():
         if prof2 is not None:
             s2 = prof2.summary()
 
-            def fam(keys, bound, peak, unit, kernel, note=None, traffic=None, use_bytes=False):
+            def fam(keys, bound, peak, unit, kernel, note=None, traffic=None, use_bytes=False, pmc=None):
                 ks = [k for k in s2 if k in keys]
                 if not ks:
                     return None
@@ -306,25 +364,30 @@ def main():
                 ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
                 d = {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": traffic,
                      "launches": n, "avg_launch_us": 1e3 * ms / n, "work_per_launch": work / n, "ms_per_step": ms / args.roofline_steps}
+                if pmc:
+                    d["pmc"] = pmc
                 if note:
                     d["note"] = note
                 return d
 
             more = [
                 fam(("gemm_tn",), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s", "gemm_tn8_kernel / gemm_tn_kernel (weight-gradient bf16 MFMA GEMMs, 2*M*N1*N2 FLOP per launch)",
-                    traffic=pmc_traffic(args, "gemm.hip", "gemm_tn")),
+                    traffic=pmc_traffic(args, "gemm.hip", "gemm_tn"), pmc=pmc_busy(args, "gemm.hip", "gemm_tn")),
                 fam(("attn_fwd_hd32", "attn_bwd_hd32"), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s",
-                    "attn_fwd / attn_bwd_dq / attn_bwd_dkv <32> (decoder attention, hd 32; 4 / 10 * sum L^2 * D FLOP per launch)",
+                    "attn_fwd / attn_bwd_* <32> (decoder attention, hd 32; 4 / 8 * sum L^2 * D algorithmic FLOP per forward / backward launch - the "
+                    "backward's recomputation of S is not counted)",
                     note="VALU-bound beside the matrix pipe: one v_exp_f32 (8 issue cycles per wave) per score against 128 FLOP of MFMA work at hd 32 "
-                         "caps these kernels near 0.5 of the MFMA peak before any other VALU work", traffic=pmc_traffic(args, "attention.hip", "attn_hd32")),
+                         "caps these kernels near 0.5 of the MFMA peak before any other VALU work", traffic=pmc_traffic(args, "attention.hip", "attn_hd32"),
+                    pmc=pmc_busy(args, "attention.hip", "attn_hd32")),
                 fam(("attn_fwd_hd64", "attn_bwd_hd64"), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s", "attn_* <64> (encoder attention, hd 64)",
                     note="sequences of 39-196 tokens (618 in the two joint layers): the time follows the ROWS, not the FLOP - see the hbm entry of the same launches",
-                    traffic=pmc_traffic(args, "attention.hip", "attn_hd64")),
+                    traffic=pmc_traffic(args, "attention.hip", "attn_hd64"), pmc=pmc_busy(args, "attention.hip", "attn_hd64")),
                 fam(("attn_fwd_hd64", "attn_bwd_hd64"), "hbm", PEAK_HBM_GBS, "GB/s", "attn_* <64> against the HBM roof: q, k, v, o (and dO, dq, dk, dv) "
                     "once per kernel that needs them = rows*D*2*(4 forward | 12 backward: two kernels) algorithmic bytes per launch",
                     traffic=pmc_traffic(args, "attention.hip", "attn_hd64"), use_bytes=True),
                 fam(("layernorm_bwd",), "hbm", PEAK_HBM_GBS, "GB/s", "ln_bwd_kernel (LayerNorm backward + residual-gradient add + bf16 copy + column sums; "
-                    "rows*D*(2+4+4+4+2) algorithmic bytes per launch)", traffic=pmc_traffic(args, "layernorm.hip", "ln_bwd")),
+                    "algorithmic bytes per launch = rows*D*(dy 2 + x 4 + dres 2 + dx_bf16 2) with the bf16 residual-gradient stream, "
+                    "(2+4+4+4+2) with AVSIAM_GRAD_STREAM=fp32)", traffic=pmc_traffic(args, "layernorm.hip", "ln_bwd")),
                 fam(("layernorm_fwd",), "hbm", PEAK_HBM_GBS, "GB/s", "ln_fwd_kernel (rows*D*(4+2) algorithmic bytes per launch)",
                     traffic=pmc_traffic(args, "layernorm.hip", "ln_fwd")),
             ]
@@ -338,8 +401,10 @@ def main():
             except Exception as e:                                       # the baseline is a report, never a gate
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.barrier()
+        if comm is not None and hasattr(comm, "close"):
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -41,9 +41,11 @@ int avs_layernorm_fwd_q8(const float* x, const float* g0, const float* b0, const
                          int D, float eps, uint8_t* y8, float q8, avs_stream_t stream);
 /* dx = dres + LN'(dy) (dres may be NULL; dx may alias dres); dy is bf16, or fp32 when dy_f32; dx_bf16 (may be NULL) gets a
  * bf16 copy of dx; dg/db are accumulated (+=); dcol (may be NULL) accumulates the column sum of dx, i.e. the bias gradient
- * of the Linear that produced this residual branch; ws: avs_layernorm_ws_floats */
+ * of the Linear that produced this residual branch; ws: avs_layernorm_ws_floats.
+ * dres_bf16 != 0: dres is bf16 (the residual-gradient stream kept in bf16 between blocks - the previous call's dx_bf16);
+ * dx may then be NULL (only dx_bf16 is written); dx_bf16 must not alias a bf16 dres. */
 int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* g0,
-                      const float* g1, const uint8_t* row_mod, const int* out_map, const float* dres, float* dx,
+                      const float* g1, const uint8_t* row_mod, const int* out_map, const void* dres, int dres_bf16, float* dx,
                       avs_bf16* dx_bf16, float* dg0, float* db0, float* dg1, float* db1, float* dcol, float* ws, int rows,
                       int D, avs_stream_t stream);
 
@@ -156,7 +158,11 @@ int avs_mask_plan(const int* seqs, int nseq, const unsigned* tmask_lo, const uns
                   avs_stream_t stream);
 int avs_cast_scale_bf16(const float* x, avs_bf16* y, long long n, float alpha, avs_stream_t stream);
 int avs_scatter_add_rows(const avs_bf16* src, const int* idx, float* dst, int rows, int D, float scale, avs_stream_t stream);
-int avs_colsum_bf16(const avs_bf16* x, float* out, int rows, int C, avs_stream_t stream);
+/* out[c] += sum over rows of x[r][c], c < C (C % 64 == 0); ld: leading dimension of x (a column range of a wider matrix is allowed) */
+int avs_colsum_bf16(const avs_bf16* x, long long ld, float* out, int rows, int C, avs_stream_t stream);
+/* y[n] += alpha * sum_k x[k] * W[k][n]  (x fp32 [K], W bf16 [K, N] / ld, N % 256 == 0, K % 32 == 0): the value third of the qkv bias
+ * gradient = (proj bias gradient) . W_proj, because softmax rows sum to one (Attention, cav_mae_base.py:51,60-77); the key third is 0 */
+int avs_vecmat_bf16(const float* x, const avs_bf16* W, long long ld, float* y, int K, int N, float alpha, avs_stream_t stream);
 
 /* ---- decoder un-shuffle (forward_decoder, cav_mae_base.py:604-626) */
 int avs_unshuffle_fwd(const float* x, const int* src_row, const int* pos_row, const uint8_t* row_mod,

@@ -117,3 +117,4 @@ def test_gradient_matches_finite_difference_at_full_size(setup, which):
         m.mark_weights_changed()
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - gn) <= 0.02 * gn, (fd, gn, vals, out[0].item())
+

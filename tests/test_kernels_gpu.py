@@ -84,6 +84,18 @@ def test_layernorm(D, rows):
     assert rel_err(dx2, dx) < 1e-6
     assert torch.equal(dxb, bf(dx2))
     assert rel_err(dcol, 1 + dx2.double().sum(0)) < 1e-5           # fused column sum (bias gradient), accumulated
+    # bf16 residual-gradient stream (engine.GRAD_STREAM): dres arrives in bf16, only the bf16 copy is written; the sum is formed in
+    # fp32 and rounded once, so the result is the bf16 rounding of the fp32-path sum on the rounded dres
+    dres_b = bf(dres)
+    dxb2 = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    dcol2 = torch.zeros(D, device=DEV)
+    o.layernorm_bwd(dyf, x, mean, rstd, g[0], None, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres_b, dxb2, dcol2)
+    dx3 = torch.empty(rows, D, device=DEV)
+    o.layernorm_bwd(dyf, x, mean, rstd, g[0], dx3, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres_b.float(), None)
+    assert torch.equal(dxb2, bf(dx3))
+    assert rel_err(dcol2, dx3.double().sum(0)) < 1e-5
+    with pytest.raises(AssertionError):                          # in-place on the bf16 stream is refused
+        o.layernorm_bwd(dyf, x, mean, rstd, g[0], None, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres_b, dres_b)
 
 
 @pytest.mark.parametrize("M,N,K", [(333, 256, 768), (1000, 768, 3072), (4099, 2304, 768), (128, 512, 256), (25700, 768, 768)])
@@ -399,6 +411,16 @@ def test_segment_mean_colsum_scatter_cast_transpose():
     cs = torch.zeros(D, device=DEV)
     o.colsum(y, cs, rows)
     assert rel_err(cs, y.double().sum(0)) < 1e-5
+    # a column range of a wider matrix (the query third of the qkv gradient), accumulating
+    cs3 = torch.ones(256, device=DEV)
+    o.colsum(y[:, 256:512], cs3, rows)
+    assert rel_err(cs3, 1 + y[:, 256:512].double().sum(0)) < 1e-5
+    # y += alpha * x . W (the value third of the qkv bias gradient from the proj bias gradient)
+    xk = torch.randn(D, device=DEV)
+    Wk = bf(torch.randn(D, 512, device=DEV) * 0.1)
+    yk = torch.ones(512, device=DEV)
+    o.vecmat(xk, Wk, yk, 0.5)
+    assert rel_err(yk, 1 + 0.5 * (xk.double() @ Wk.double())) < 1e-5
     idx = torch.randint(0, 7, (rows,), device=DEV, dtype=torch.int32)
     dst = torch.zeros(7, D, device=DEV)
     o.scatter_add_rows(y, idx, dst, rows, 2.0)
