@@ -114,6 +114,8 @@ struct AttnArgs {
     float* delta;                               // bwd: rowsum(dO * O) [H][rows_total]
     bf16_t* dqkv;                               // bwd: [rows, 3*D] (ld)
     float scale;                                // hd^-0.5 (q columns of qkv hold q * scale * log2(e))
+    uint8_t* out8; long long ldo8; float* q8;   // fwd, fp8 mode (may be NULL): e4m3 copy of the output for the proj GEMM, scaled by the
+                                                // device record q8 (common.h AVS_Q_*), whose running amax takes the largest |o| written
 };
 
 __device__ __forceinline__ f32x16 splat16(float v) {
@@ -274,20 +276,31 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qq = qw + (lane & 31);
+    const float q8s = a.out8 ? a.q8[AVS_Q_SCALE] : 0.f;
+    float omax = 0.f;
     if (qq < L) {
         bf16_t* orow = a.out + (size_t)(seq0 + qq) * a.ldo + head * HG;
+        uint8_t* orow8 = a.out8 ? a.out8 + (size_t)(seq0 + qq) * a.ldo8 + head * HG : nullptr;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (d * 32 + 8 * t >= HG) continue;                    // columns of the image beyond the real head dim
+                const float v0 = o[d][4 * t + 0] * inv, v1 = o[d][4 * t + 1] * inv, v2 = o[d][4 * t + 2] * inv, v3 = o[d][4 * t + 3] * inv;
                 uint2 w;
-                w.x = pack_bf2(o[d][4 * t + 0] * inv, o[d][4 * t + 1] * inv);
-                w.y = pack_bf2(o[d][4 * t + 2] * inv, o[d][4 * t + 3] * inv);
+                w.x = pack_bf2(v0, v1);
+                w.y = pack_bf2(v2, v3);
                 *reinterpret_cast<uint2*>(orow + d * 32 + 8 * t + 4 * hh) = w;
+                if (orow8) {
+                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+                    int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v0 * q8s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v1 * q8s, -448.f, 448.f), 0, false);
+                    w8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v2 * q8s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v3 * q8s, -448.f, 448.f), w8, true);
+                    *reinterpret_cast<int*>(orow8 + d * 32 + 8 * t + 4 * hh) = w8;
+                }
             }
         if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
+    if (a.out8) q_amax_update(a.q8, omax);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -537,15 +550,18 @@ static int check_common(const char* name, const void* qkv, long long ld, int D, 
     return 0;
 }
 
-extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
-                            const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
-                            hipStream_t stream) {
+// out8 / ldo8 / q8 (all or none): also write e4m3(clamp(out * q8[0], +-448)) - the fp8 operand of the proj GEMM - and fold max |out| into q8[2]
+extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                               const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
+                               uint8_t* out8, long long ldo8, float* q8, hipStream_t stream) {
+    AVS_CHECK_ARG((out8 == nullptr) == (q8 == nullptr) && (!out8 || (ldo8 >= D && (ldo8 % 4) == 0)), "attn_fwd: out8 and q8 go together, ldo8 %% 4 == 0");
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_fwd: tile_rows must be 64 or 128");
     AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_fwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_fwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && lse && (ldo % 4) == 0, "attn_fwd: null output");
-    AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd)};
+    AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd),
+               out8, ldo8, q8};
     dim3 grid(ntiles * H);
     // hd 80 (ViT-H: 1280 / 16 heads): a 96-wide LDS image whose last 16 columns are zero, five contraction steps, 128-row tiles only
     if (hd == 80) attn_fwd_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
@@ -560,6 +576,12 @@ extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const
     return 0;
 }
 
+extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                            const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
+                            hipStream_t stream) {
+    return avs_attn_fwd_q8(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, ldo, lse, rows_total, nullptr, 0, nullptr, stream);
+}
+
 extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                             const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
                             const float* lse, float* delta, int rows_total, bf16_t* dqkv, hipStream_t stream) {
@@ -569,7 +591,7 @@ extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const
     if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, delta, dqkv, 1.0f / sqrtf((float)hd)};
+               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr};
     dim3 grid(ntiles * H);
     if (hd == 80) attn_bwd_dq_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
     else if (tile_rows == 128) {

@@ -108,6 +108,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- fp8 (e4m3) per-tensor quantisation record, on the DEVICE (engine.FP8; delayed scaling): q[0] = scale (x -> x * scale -> e4m3),
+// q[1] = 1 / scale, q[2] = running max |x| of the values quantised since the last avs_fp8_scale_update, q[3] = number of updates that
+// found q[2] * scale > 448 (the tensor saturated under the scale it was quantised with).  Producers of an e4m3 operand read q[0]
+// and fold what they saw into q[2]; nothing on this path ever synchronises with the host.
+#define AVS_Q_SCALE 0
+#define AVS_Q_INV 1
+#define AVS_Q_AMAX 2
+#define AVS_Q_SAT 3
+
+// fold a wave's max |x| (m >= 0, any lane's value; reduced here) into q[AVS_Q_AMAX].  The plain load filters: once the record holds
+// the tensor's typical maximum almost no wave issues the atomic (thousands of waves hitting one address would serialise).
+__device__ __forceinline__ void q_amax_update(float* q, float m) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) {
+        const float cur = __hip_atomic_load(q + AVS_Q_AMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m > cur) atomicMax(reinterpret_cast<int*>(q + AVS_Q_AMAX), __float_as_int(m));      // non-negative floats order like their bits
+    }
+}
+
 // ---- raw inputs: the arithmetic of the reference's dataset (/root/reference/src/dataloader.py:505-513
 // audio, :461-462 + :152-155 frames) applied WHERE THE INPUT IS READ - the patch gather of the embedding and the target gather of
 // the reconstruction loss - instead of in a pass of its own.  Mirrors `avs_input_xf` of include/avsiam_hip.h.

@@ -44,6 +44,10 @@ struct GemmNtArgs {
     int m_split; const bf16_t* B2; const float* bias2; float* colsum2;
     // fp8-forward mode, act 1 only: out8 (may be NULL) receives e4m3(clamp(gelu(x) * out8_scale, +-448)) - the operand of the fc2 GEMM
     uint8_t* out8; long long ldo8; float out8_scale;
+    // fp8 with delayed scaling: device records (common.h AVS_Q_*; all may be NULL -> the host floats above apply).  qa / qw / qw2: the
+    // operands' records - the de-quantisation factor is qa[INV] * qw[INV] (qw2 for rows from m_split); q8: the record of out8 - its
+    // scale is read from it and the largest |gelu(x)| written is folded into its running amax
+    const float* qa; const float* qw; const float* qw2; float* q8;
 };
 
 
@@ -216,6 +220,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         const unsigned raddr = stg_lds + (rq * 68 + cc) * 4, baddr = sbias_lds + cc * 4;      // rows rq and rq + 8: 2176 B apart
         constexpr int AG = EpiPrefetch<MI>::AG, NG = MI / AG;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
+        const float q8s = (Q8 && a.out8) ? (a.q8 ? a.q8[AVS_Q_SCALE] : a.out8_scale) : 0.f;
+        float q8max = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (ACT == 2) epi_load_aux<MI>(a, pf.ax, g, lane, mw0, nw0);
@@ -265,8 +271,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                         gq.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); gq.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
                         NT_STORE(reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n), (u32x4{gq.x, gq.y, gq.z, gq.w}));
                         if (Q8 && a.out8) {
-                            const float q = a.out8_scale;
-                            auto q8 = [&](float x) { return __builtin_amdgcn_fmed3f(gelu_erf(x) * q, -448.f, 448.f); };
+                            const float q = q8s;
+                            auto q8 = [&](float x) { const float gx = gelu_erf(x); q8max = fmaxf(q8max, fabsf(gx)); return __builtin_amdgcn_fmed3f(gx * q, -448.f, 448.f); };
                             int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q8(v0[0]), q8(v0[1]), 0, false);
                             w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q8(v0[2]), q8(v0[3]), w0, true);
                             int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q8(v1[0]), q8(v1[1]), 0, false);
@@ -277,6 +283,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 }
             }
         }
+        if (Q8 && a.out8 && a.q8) q_amax_update(a.q8, q8max);
         if (colsum) {
             // lanes with the same (lane & 7) hold the same 8 columns for different rows: fold the 8 row groups, then one
             // atomic per column and wave (fp32 atomics, like the weight gradients)
@@ -655,10 +662,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
 #else
         if (FP8) {
             // the de-quantisation factor belongs to the product alone (the shared epilogue's alpha also scales bias and residual)
+            const float dq = a.qa ? a.qa[AVS_Q_INV] * (m0 >= a.m_split ? a.qw2 : a.qw)[AVS_Q_INV] : a.alpha;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < MI; ++j) acc[i][j] *= a.alpha;
+                for (int j = 0; j < MI; ++j) acc[i][j] *= dq;
             GemmNtArgs e = a;
             e.alpha = 1.0f;
             nt_epilogue<ACT, MI, true>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
@@ -991,7 +999,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt: the residual add is implemented for fp32 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M,
-                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f};
+                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;
@@ -1074,10 +1082,14 @@ extern "C" int avs_gemm_nt_bf16(const bf16_t* A, long long lda, const bf16_t* B,
 
 // fp8 (OCP e4m3) operands, fp32 accumulation, the epilogues of the bf16 GEMM for act 0 (alpha, bias, fp32 residual, column-range scale,
 // bf16 or fp32 output) and act 1 (GELU pair: out = gelu'(x), out2 = gelu(x), both bf16).
-// x = alpha * (A8 . B8^T) + bias (+ res); alpha carries the product of the two de-quantisation scales.
+// x = alpha * (A8 . B8^T) + bias (+ res); alpha carries the product of the two de-quantisation scales - or, with the device records
+// qa / qw (delayed scaling), qa[1] * qw[1] read by the kernel.  m_split / B2 / bias2 / qw2: a second weight set for rows from m_split
+// (the MAE pass's two towers in one launch, as avs_gemm_nt_bf16_dual); m_split <= 0 or >= M: one set.
 extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long ldb, int M, int N, int K, const float* bias,
                                const float* res, long long ldr, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2, float alpha,
-                               int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale, hipStream_t stream) {
+                               int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale,
+                               const float* qa, const float* qw, float* q8, int m_split, const uint8_t* B2, const float* bias2, const float* qw2,
+                               hipStream_t stream) {
     AVS_CHECK_ARG(!out8 || (act == 1 && (ldo8 % 8) == 0 && ldo8 >= N), "gemm_nt_fp8: the e4m3 copy of gelu(x) goes with act 1");
     AVS_CHECK_ARG(M > 0 && N > 0 && K >= 256 && (N % 256) == 0 && (K % 128) == 0, "gemm_nt_fp8: need N%%256==0, K%%128==0, K>=256 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && (ldo % (out_f32 ? 4 : 8)) == 0,
@@ -1085,6 +1097,10 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt_fp8: the residual add is implemented for fp32 output");
     AVS_CHECK_ARG((act == 0 && !out2) || (act == 1 && out2 && !out_f32 && (ldo2 % 8) == 0), "gemm_nt_fp8: act 0, or act 1 with a bf16 output pair");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt_fp8: scale_cols must be a multiple of 64 within N");
+    AVS_CHECK_ARG((qa == nullptr) == (qw == nullptr), "gemm_nt_fp8: qa and qw go together");
+    const bool dual = m_split > 0 && m_split < M;
+    AVS_CHECK_ARG(!dual || ((m_split % 256) == 0 && B2 && (bias == nullptr) == (bias2 == nullptr) && qa && qw2),
+                  "gemm_nt_fp8: two weight sets need m_split %% 256 == 0, B2, bias2 mirroring bias, and device records (qa, qw, qw2)");
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_nt8_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1097,8 +1113,9 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
     }
     // the fp8 matrices as the bf16 matrices they alias (see gemm_nt8_kernel): half the columns, half the leading dimension
     GemmNtArgs a{reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, M, N, K / 2, bias, res, ldr, nullptr, nullptr, 0,
-                 out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, nullptr, M, 0x7fffffff, nullptr, nullptr, nullptr,
-                 out8, ldo8, out8_scale};
+                 out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, nullptr, M, dual ? m_split : 0x7fffffff,
+                 dual ? reinterpret_cast<const bf16_t*>(B2) : nullptr, dual ? bias2 : nullptr, nullptr,
+                 out8, ldo8, out8_scale, qa, qw, dual ? qw2 : qw, q8};
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;

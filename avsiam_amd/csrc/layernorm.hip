@@ -16,9 +16,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ b1, const uint8_t* __restrict__ row_mod,
                                                      const int* __restrict__ out_map, void* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     int rows, float eps, uint8_t* __restrict__ y8, float q8) {
+                                                     int rows, float eps, uint8_t* __restrict__ y8, float q8_host, float* q8_dev) {
     // y8 (optional, bf16 output only): an OCP e4m3 copy of y * q8 for the fp8 forward GEMM that consumes this LayerNorm (engine.FP8) -
-    // one more byte per element written here instead of a quantising pass that reads two and writes one
+    // one more byte per element written here instead of a quantising pass that reads two and writes one.  q8_dev (device record,
+    // common.h AVS_Q_*; may be NULL): the scale comes from it and the row's max |y| is folded into its running amax (delayed scaling)
+    const float q8 = (y8 && q8_dev) ? q8_dev[AVS_Q_SCALE] : q8_host;
+    float ymax = 0.f;
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             o.y = pack_bf2(r.z, r.w);
             reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + (size_t)orow * D)[i * 64 + lane] = o;
             if (y8) {
+                ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
                 int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r.x * q8, -448.f, 448.f), __builtin_amdgcn_fmed3f(r.y * q8, -448.f, 448.f), 0, false);
                 w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r.z * q8, -448.f, 448.f), __builtin_amdgcn_fmed3f(r.w * q8, -448.f, 448.f), w, true);
                 reinterpret_cast<int*>(y8 + (size_t)orow * D)[i * 64 + lane] = w;
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         mean_out[row] = mean;
         rstd_out[row] = rs;
     }
+    if (!F32IO && y8 && q8_dev) q_amax_update(q8_dev, ymax);
 }
 
 // Backward.  dx = dres + rstd * (gy - mean(gy) - xhat * mean(gy * xhat)),  gy = dy * gamma.
@@ -213,14 +218,14 @@ static int g_ln_rpw = -1;                   // rows per wave of the backward ker
 
 extern "C" int avs_layernorm_fwd_q8(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
                                     const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
-                                    int rows, int D, float eps, uint8_t* y8, float q8, hipStream_t stream) {
+                                    int rows, int D, float eps, uint8_t* y8, float q8, float* q8_dev, hipStream_t stream) {
     AVS_CHECK_ARG(!(y8 && y_f32), "layernorm_fwd: the fp8 copy goes with the bf16 output");
     // D = 1536: the concatenated audio|video feature of the fusion classification head (forward only)
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280 || D == 1536), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(x && g0 && b0 && y && mean && rstd, "layernorm_fwd: null pointer");
     AVS_CHECK_ARG(!row_mod || (g1 && b1), "layernorm_fwd: row_mod given without second affine set");
     dim3 grid(ceil_div(rows, 4)), block(256);
-#define LN_FWD(NV, F) ln_fwd_kernel<NV, F><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps, y8, q8)
+#define LN_FWD(NV, F) ln_fwd_kernel<NV, F><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps, y8, q8, q8_dev)
     if (y_f32) {
         if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else if (D == 1024) LN_FWD(4, true); else if (D == 1280) LN_FWD(5, true); else LN_FWD(6, true);
     } else {
@@ -234,7 +239,7 @@ extern "C" int avs_layernorm_fwd_q8(const float* x, const float* g0, const float
 extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
                                  const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
                                  int rows, int D, float eps, hipStream_t stream) {
-    return avs_layernorm_fwd_q8(x, g0, b0, g1, b1, row_mod, out_map, y, y_f32, mean, rstd, rows, D, eps, nullptr, 1.0f, stream);
+    return avs_layernorm_fwd_q8(x, g0, b0, g1, b1, row_mod, out_map, y, y_f32, mean, rstd, rows, D, eps, nullptr, 1.0f, nullptr, stream);
 }
 
 // dg*/db* are ACCUMULATED into (+=); dx may alias dres; dx_bf16 (optional) receives a bf16 copy of dx; dcol (optional)

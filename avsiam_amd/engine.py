@@ -36,9 +36,14 @@ LN_EPS_BLOCK, LN_EPS_FINAL = 1e-5, 1e-6       # nn.LayerNorm default in Block; t
 # 288 GB (ViT-H at batch 64 x 10 frames); costs about 8/12 of the forward GEMMs plus the attention forward again.
 RECOMPUTE = os.environ.get("AVSIAM_RECOMPUTE", "0")
 # fp8 forward (AVSIAM_FP8=1 / bench.py --fp8; BASELINE configs[4]'s "fp8 MFMA path", never the default): the four forward GEMMs of a
-# block (qkv, proj, fc1, fc2) take OCP e4m3 operands - the bf16 activation and the bf16 weight shadow are quantised right in front of the
-# GEMM with a per-tensor scale fixed at first use (448 / (2 * amax): static scaling with a 2x margin, saturating) - and accumulate in
-# fp32; everything the backward reads is still produced in bf16 and the backward itself is the bf16 one.
+# block (qkv, proj, fc1, fc2) take OCP e4m3 operands with per-tensor DELAYED scaling and accumulate in fp32.  Every quantised tensor has a
+# device record {scale, 1/scale, running amax, saturation events} (ops.Fp8Records): the kernel that produces an operand (the LayerNorm
+# in front of qkv / fc1, the attention epilogue in front of proj, fc1's GELU epilogue in front of fc2, a quantising pass for the
+# weights) reads the scale from the record and folds the |max| it saw into it; once per forward one tiny kernel turns the amax history
+# (16 steps) into the next scales, 448 / (2 * max) - no host synchronisation anywhere, saturation is counted, the state is saved with
+# the checkpoint (CAVMAE_BASE.fp8_state).  The first time a GEMM runs its operands are calibrated on the spot (absmax -> scale, still
+# on the device) and the activation is quantised by a pass.  The MAE pass's two towers run as one stack with two weight sets here too.
+# Everything the backward reads is still produced in bf16 and the backward itself is the bf16 one.
 FP8 = os.environ.get("AVSIAM_FP8", "0")
 # The residual-GRADIENT stream between the blocks of a stack (AVSIAM_GRAD_STREAM=bf16 | fp32).  bf16 (default): a LayerNorm backward
 # reads the upstream residual gradient from the bf16 copy the previous LayerNorm backward wrote for the GEMMs anyway and writes
@@ -101,11 +106,11 @@ class BlockParams:
         self.fc2 = Linear(arena, f"{prefix}.mlp.fc2.weight", f"{prefix}.mlp.fc2.bias")
 
 
-def _ln_fwd(x, norms, y, mean, rstd, rows, eps, row_mod=None, out_map=None, y8=None, q8=1.0):
+def _ln_fwd(x, norms, y, mean, rstd, rows, eps, row_mod=None, out_map=None, y8=None, q8_dev=None):
     n0 = norms[0]
     n1 = norms[1] if len(norms) > 1 else None
     ops.layernorm_fwd(x, n0.g, n0.b, y, mean, rstd, rows, eps, n1.g if n1 else None, n1.b if n1 else None,
-                      row_mod if n1 else None, out_map, y8=y8, q8=q8)
+                      row_mod if n1 else None, out_map, y8=y8, q8_dev=q8_dev)
 
 
 def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None, dcol=None):
@@ -195,11 +200,14 @@ class Stack:
         self.recompute = RECOMPUTE == "1" and not inference
         self.fp8 = FP8 == "1" and D % 256 == 0 and hidden % 256 == 0 and D >= 256     # the fp8 GEMM's tile constraints (N % 256, K % 128)
         if self.fp8:
-            self.a8 = torch.empty((ops.pad_rows(rows, 256), max(D, hidden)), dtype=U8, device=dev)     # the activation in front of a GEMM
-            self.w8 = torch.empty((max(3 * D, hidden) * max(D, hidden),), dtype=U8, device=dev)          # that GEMM's weight
-            self.fp8_scale = {}                                                                          # (block, tensor) -> scale, fixed at first use
-            self.ln8 = torch.zeros((ops.pad_rows(rows, 256), D), dtype=U8, device=dev)                   # e4m3 copy a LayerNorm writes for its GEMM
-            self.act8 = torch.zeros((ops.pad_rows(rows, 256), hidden), dtype=U8, device=dev)             # ... and fc1's GELU epilogue for fc2
+            r8 = ops.pad_rows(rows, 256)
+            self.a8 = torch.zeros((r8, max(D, hidden)), dtype=U8, device=dev)      # calibration step only: an activation quantised by a pass
+            self.w8 = [torch.empty((max(3 * D, hidden) * max(D, hidden),), dtype=U8, device=dev) for _ in range(2)]   # the GEMM's weight (two sets)
+            self.ln8 = torch.zeros((r8, D), dtype=U8, device=dev)                  # e4m3 copy a LayerNorm writes for qkv / fc1
+            self.att8 = torch.zeros((r8, D), dtype=U8, device=dev)                 # ... the attention epilogue for proj
+            self.act8 = torch.zeros((r8, hidden), dtype=U8, device=dev)            # ... and fc1's GELU epilogue for fc2
+            self.f8 = ops.Fp8Records(nblocks * 12, dev)                            # per block: 4 GEMMs x (activation, weight, second weight set)
+            self.f8_seen = set()                                                   # (block, gemm) whose records hold a calibrated scale
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
         # rows per attention workgroup (4 or 2 waves of 32 queries / keys), by the mean sequence length of the stack - measured on the
@@ -255,8 +263,15 @@ class Stack:
         """blocks2 / split: rows [split, rows) run through a SECOND set of blocks (the MAE pass's visual tower next to its
         audio tower, cav_mae_base.py:487,489) in the same launches - every GEMM takes both weight sets
         (ops.gemm_nt(dual=...)), the LayerNorm picks the affine per row (row_mod: 0 below split, 1 from it)."""
+        if self.fp8:
+            self.f8.update()                   # delayed scaling: last forward's amax -> history -> this forward's scales (one launch)
         for i, bp in enumerate(blocks):
             self._block_forward(i, bp, blocks2[i] if blocks2 is not None else None, split)
+
+    _G8 = {"qkv": 0, "proj": 1, "fc1": 2, "fc2": 3}
+
+    def _rec(self, i, name, operand=0):
+        return self.f8.rec((i * 4 + self._G8[name]) * 3 + operand)
 
     def _block_forward(self, i, bp, b2, split, last_gemm=True):
         """Block i: x[i] -> x[i + 1] and everything its backward reads.  last_gemm=False (recompute in front of the backward): x[i + 1]
@@ -265,54 +280,85 @@ class Stack:
         x, st = self.x[i], self.stats[i]
         n1 = bp.n1 if b2 is None else [bp.n1[0], b2.n1[0]]
         n2 = bp.n2 if b2 is None else [bp.n2[0], b2.n2[0]]
+        if self.fp8:
+            return self._block_forward_fp8(i, bp, b2, split, last_gemm, n1, n2)
         dq = dp = d1 = d2 = None
         if b2 is not None:
             dq, dp = (split, b2.qkv.w, b2.qkv.b, None), (split, b2.proj.w, b2.proj.b, None)
             d1, d2 = (split, b2.fc1.w, b2.fc1.b, None), (split, b2.fc2.w, b2.fc2.b, None)
-        f8 = self.fp8 and b2 is None
-        gemm = self._gemm_fp8 if f8 else self._gemm_bf16
-        # once a GEMM's activation scale is fixed (after its first use) the LayerNorm in front of it writes the e4m3 copy itself
-        q_qkv = self.fp8_scale.get((i, "qkv")) if f8 else None
-        q_fc1 = self.fp8_scale.get((i, "fc1")) if f8 else None
-        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod, y8=self.ln8 if q_qkv else None, q8=q_qkv[0] if q_qkv else 1.0)
-        gemm((i, "qkv"), self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq,
-             **({"a8": self.ln8} if q_qkv else {}))
+        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod)
+        ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale, dual=dq)
         ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i])
-        gemm((i, "proj"), self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x, dual=dp)
-        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod, y8=self.ln8 if q_fc1 else None, q8=q_fc1[0] if q_fc1 else 1.0)
-        q_fc2 = self.fp8_scale.get((i, "fc2")) if f8 and last_gemm else None           # ... and fc1's GELU epilogue the copy for fc2
-        gemm((i, "fc1"), self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1,
-             **({"a8": self.ln8} if q_fc1 else {}), **({"out8": self.act8, "out8_scale": q_fc2[0]} if q_fc2 else {}))
+        ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], M, bias=bp.proj.b, res=x, dual=dp)
+        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod)
+        ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], M, bias=bp.fc1.b, out2=self.act[i], act=1, dual=d1)
         if last_gemm:
-            gemm((i, "fc2"), self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2,
-                 **({"a8": self.act8} if q_fc2 else {}))
+            ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], M, bias=bp.fc2.b, res=self.xmid[i], dual=d2)
 
-    @staticmethod
-    def _gemm_bf16(key, A, W, out, M, dual=None, **kw):
-        ops.gemm_nt(A, W, out, M, dual=dual, **kw)
+    def _block_forward_fp8(self, i, bp, b2, split, last_gemm, n1, n2):
+        """The block's forward with e4m3 GEMM operands (module comment at FP8).  Once a GEMM's records are calibrated its activation
+        arrives in e4m3 from the kernel that produces it; before that (first use) it is quantised by a pass."""
+        M = self.rows
+        x, st = self.x[i], self.stats[i]
+        seen = lambda name: (i, name) in self.f8_seen
+        r = lambda name: self._rec(i, name)
+        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod, y8=self.ln8 if seen("qkv") else None,
+                q8_dev=r("qkv") if seen("qkv") else None)
+        self._gemm_fp8(i, "qkv", self.ln1[i], self.ln8, bp.qkv, b2.qkv if b2 else None, split, self.qkv[i], scale_cols=self.D, col_scale=self.q_scale)
+        ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i], **({"out8": self.att8, "q8": r("proj")} if seen("proj") else {}))
+        self._gemm_fp8(i, "proj", self.att[i], self.att8, bp.proj, b2.proj if b2 else None, split, self.xmid[i], res=x)
+        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod, y8=self.ln8 if seen("fc1") else None,
+                q8_dev=r("fc1") if seen("fc1") else None)
+        o8 = {"out8": self.act8, "q8": r("fc2")} if (seen("fc2") and last_gemm) else {}
+        self._gemm_fp8(i, "fc1", self.ln2[i], self.ln8, bp.fc1, b2.fc1 if b2 else None, split, self.fc1[i], out2=self.act[i], act=1, **o8)
+        if last_gemm:
+            self._gemm_fp8(i, "fc2", self.act[i], self.act8, bp.fc2, b2.fc2 if b2 else None, split, self.x[i + 1], res=self.xmid[i])
 
-    def _gemm_fp8(self, key, A, W, out, M, dual=None, a8=None, **kw):
-        """The same forward GEMM on e4m3 copies of its operands (module comment at FP8).  a8: the activation already in e4m3 at this
-        GEMM's scale (written by its producer)."""
-        assert dual is None
-        K, N = A.shape[1], W.shape[0]
-        sc = self.fp8_scale.get(key)
-        if sc is None:                                            # first use: per-tensor amax (synchronises once per tensor)
-            sc = self.fp8_scale[key] = (ops.FP8_MAX / (2.0 * max(ops.absmax(A), 1e-12)), ops.FP8_MAX / (2.0 * max(ops.absmax(W), 1e-12)))
-        w8 = self.w8[:N * K].view(N, K)
-        if a8 is None:
+    def _gemm_fp8(self, i, name, A, a8, lin, lin2, split, out, **kw):
+        """One forward GEMM on e4m3 operands.  a8: where this GEMM's activation lives in e4m3 once its producer writes it."""
+        M = self.rows
+        W, W2 = lin.w, (lin2.w if lin2 is not None else None)
+        N, K = W.shape
+        ra, rw, rw2 = self._rec(i, name, 0), self._rec(i, name, 1), self._rec(i, name, 2)
+        first = (i, name) not in self.f8_seen
+        if first:                                  # calibrate on the spot, on the device: amax -> record -> scale (no host sync)
+            ops.absmax_into(A, ra)
+            ops.absmax_into(W, rw)
+            if W2 is not None:
+                ops.absmax_into(W2, rw2)
+            self.f8.update(first=(i * 4 + self._G8[name]) * 3, count=3)
+            self.f8_seen.add((i, name))
             a8 = self.a8[:A.shape[0], :K] if self.a8.shape[1] == K else self.a8.view(-1)[:A.shape[0] * K].view(A.shape[0], K)
-            ops.quantize_fp8(A, sc[0], out=a8)
-        ops.quantize_fp8(W, sc[1], out=w8)
-        ops.gemm_nt_fp8(a8, w8, out, M, 1.0 / (sc[0] * sc[1]), **kw)
+            ops.quantize_fp8(A, 1.0, out=a8, q=ra)
+        w8 = self.w8[0][:N * K].view(N, K)
+        ops.quantize_fp8(W, 1.0, out=w8, q=rw)
+        dual = None
+        if W2 is not None:
+            w8b = self.w8[1][:N * K].view(N, K)
+            ops.quantize_fp8(W2, 1.0, out=w8b, q=rw2)
+            dual = (split, w8b, lin2.b, rw2)
+        ops.gemm_nt_fp8(a8, w8, out, M, bias=lin.b, qa=ra, qw=rw, dual=dual, **kw)
 
-    def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0, reducer=None):
+    def fp8_state(self):
+        """delayed-scaling state for the checkpoint (None without the fp8 mode)"""
+        if not self.fp8:
+            return None
+        return {**self.f8.state(), "seen": sorted(self.f8_seen)}
+
+    def load_fp8_state(self, st):
+        if self.fp8 and st is not None:
+            self.f8.load(st)
+            self.f8_seen = {tuple(k) for k in st["seen"]}
+
+    def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0, reducer=None, accumulate=False):
         """In: d(out) in self.dxb[0] (bf16) - and in self.dx[0] (fp32) when GRAD_STREAM is "fp32".  Out: d(x[0]) in self.dx[0] (fp32)
         and self.dxb[0].
         reducer (comm.GradReducer, data parallel): told which ranges of the gradient arena are final as the blocks complete.
         Bias gradients of fc2 / proj are column sums of the residual-stream gradient and come out of the LayerNorm
         backward that produces it (`dcol`); `last_fc2_bias_done` says the caller's LN backward already did that for
         the last block.
+        accumulate: the parameter gradients may already hold another pass's contribution (one backward over both passes of a
+        combined forward): quantities derived FROM a parameter gradient then use this backward's increment only.
         blocks2 / split (see forward): the input-gradient GEMMs take both weight sets in one launch; everything that
         reduces over rows into a parameter gradient (weight-gradient GEMMs, bias column sums, LayerNorm backward with its
         gamma/beta/bias sums) runs once per row range on row slices of the same buffers."""
@@ -369,6 +415,8 @@ class Stack:
                 wgrads(i, "dfc1", (self.dfc1, self.ln2[i], "fc1"))
                 side.before_write("dbm")
             for lo, hi, bl in ranges:
+                if accumulate:            # value third of the qkv bias gradient, below: minus what proj.gb holds before this block adds to it
+                    ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * self.D:], -1.0)
                 _ln_bwd(self.dln[lo:], self.xmid[i][lo:], st[2][lo:], st[3][lo:], bl[i].n2, None if g16 else dxm[lo:], self.lnws, hi - lo,
                         None if one else self.row_mod, dres=(dbo if g16 else dxo)[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb)
             # proj
@@ -641,8 +689,9 @@ class ContrastivePass:
         ops.infonce_fwd(self.total, self.nstats, self.nout, weight)
         return self.nout[2:3], self.nout[1:2]
 
-    def backward(self, gout, weight, reducer=None):
-        """gout: [1] fp32 device tensor (d loss / d loss_c_weighted); weight = contrast_loss_weight."""
+    def backward(self, gout, weight, reducer=None, accumulate=False):
+        """gout: [1] fp32 device tensor (d loss / d loss_c_weighted); weight = contrast_loss_weight.
+        accumulate: the gradient arena already holds the other pass's contribution (Stack.backward)."""
         cfg, st = self.cfg, self.stack
         B, W, D, N = self.B, self.world, cfg.embed_dim, self.N
         ops.infonce_dlogits(self.total, self.nstats, gout, weight, self.dtotal)
@@ -659,7 +708,7 @@ class ContrastivePass:
         ops.segment_mean_bwd(self.dreps_slot, self.seg_start, self.yf, 2 * B, float(W))
         _ln_bwd(self.yf, st.out, self.fstat[0], self.fstat[1], self.final, _dx_in(st), st.lnws, self.rows, st.row_mod,
                 dx_bf16=st.dxb[0], dcol=self.blocks[-1].fc2.gb)
-        st.backward(self.blocks, last_fc2_bias_done=True, reducer=reducer)
+        st.backward(self.blocks, last_fc2_bias_done=True, reducer=reducer, accumulate=accumulate)
         self.emb_a.backward(st.dx[0][:self.rows_a])
         self.emb_v.backward(st.dx[0][self.rows_a:])
 
@@ -836,7 +885,7 @@ class MaePass:
                          total=self.losses[2:3], total_init=False, xf=xf[1], stride=cfg.st)               # loss_mae = a + v (:707)
         return self.losses[2:3], self.losses[0:1], self.losses[1:2], self.mask_a, self.mask_v
 
-    def backward(self, gout, reducer=None):
+    def backward(self, gout, reducer=None, accumulate=False):
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         La, Lv, D, Dd = cfg.audio_tokens, cfg.video_tokens, cfg.embed_dim, cfg.dec_dim
         ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a, xf=self.xf[0], stride=cfg.st)
@@ -852,7 +901,7 @@ class MaePass:
         rows_d = B * self.Ltot
         _ln_bwd(self.ddn, sd.out, self.dn_stat[0], self.dn_stat[1], self.dec_norm, _dx_in(sd), sd.lnws, rows_d,
                 out_map=self.dn_map, dx_bf16=sd.dxb[0], dcol=self.blk_dec[-1].fc2.gb)
-        sd.backward(self.blk_dec, last_fc2_bias_done=True, reducer=reducer)
+        sd.backward(self.blk_dec, last_fc2_bias_done=True, reducer=reducer, accumulate=accumulate)
         g = self.gtok
         ops.unshuffle_bwd(sd.dx[0], self.src_row, B, T, La, Lv, self.dde, g["decoder_pos_embed_a"], g["decoder_pos_embed_v"],
                           g["mask_token"], g["decoder_modality_a"], g["decoder_modality_v"])
@@ -866,14 +915,14 @@ class MaePass:
             ops.cast_scale(sm.dx[0], sm.dxb[0], rows_j * D, 1.0)
         ops.gemm_tn(self.dde_b, self.xj_b, self.dec_embed.gw, rows_j)
         ops.colsum(self.dde_b, self.dec_embed.gb, rows_j)
-        sm.backward(self.blk_mm, reducer=reducer)
+        sm.backward(self.blk_mm, reducer=reducer, accumulate=accumulate)
         if self.grouped:
             st, ra = self.st_t, self.rows_a
             for lo, fin, fstat, omap, rows, blks in ((0, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.blk_a),
                                                      (ra, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.blk_v)):
                 _ln_bwd(sm.dx[0], st.out[lo:], fstat[0], fstat[1], fin, None if GRAD_STREAM == "bf16" else st.dx[0][lo:], st.lnws, rows,
                         out_map=omap, dx_bf16=st.dxb[0][lo:], dcol=blks[-1].fc2.gb)
-            st.backward(self.blk_a, last_fc2_bias_done=True, blocks2=self.blk_v, split=ra, reducer=reducer)
+            st.backward(self.blk_a, last_fc2_bias_done=True, blocks2=self.blk_v, split=ra, reducer=reducer, accumulate=accumulate)
             self.emb_a.backward(st.dx[0][:ra])
             self.emb_v.backward(st.dx[0][ra:])
             return
@@ -881,5 +930,5 @@ class MaePass:
                                                       (self.st_v, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.emb_v, self.blk_v)):
             _ln_bwd(sm.dx[0], st.out, fstat[0], fstat[1], fin, _dx_in(st), st.lnws, rows, out_map=omap, dx_bf16=st.dxb[0],
                     dcol=blks[-1].fc2.gb)
-            st.backward(blks, last_fc2_bias_done=True, reducer=reducer)
+            st.backward(blks, last_fc2_bias_done=True, reducer=reducer, accumulate=accumulate)
             emb.backward(st.dx[0])

@@ -110,10 +110,11 @@ class _HotPath(torch.autograd.Function):
                 red[0] = model._make_reducer(arena.range[P1][0], arena.range[P2][1], overlap=False)
             else:
                 red[live] = model._make_reducer(*arena.range[live])
+        both = live == (P1 | P2)                   # the second pass adds to gradients the first has written (shared blocks)
         if live & P2:
-            model._engine("mae", B).backward(g_mae.reshape(1).float().contiguous(), reducer=red.get(P2))
+            model._engine("mae", B).backward(g_mae.reshape(1).float().contiguous(), reducer=red.get(P2), accumulate=both)
         if live & P1:
-            model._engine("contrastive", B).backward(g_c.reshape(1).float().contiguous(), ctx.contrast_w, reducer=red.get(P1))
+            model._engine("contrastive", B).backward(g_c.reshape(1).float().contiguous(), ctx.contrast_w, reducer=red.get(P1), accumulate=both)
         for r in red.values():
             r.finish()
             model.last_reduce_messages = r.messages
@@ -244,7 +245,40 @@ class CAVMAE_BASE(nn.Module):
                 self._engines[key] = MaePass(self.arena, self.cfg, batch, dev)
             else:
                 self._engines[key] = ContrastivePass(self.arena, self.cfg, batch, dev, self._world, self._rank, self._comm)
+            pend = getattr(self, "_fp8_pending", None)
+            if pend:                                    # a restored run continues with the quantisation grids it was saved with
+                for name, st in self._fp8_stacks(which, self._engines[key]):
+                    if f"{which}/{batch}/{name}" in pend:
+                        st.load_fp8_state(pend[f"{which}/{batch}/{name}"])
         return self._engines[key]
+
+    # ---- fp8 mode (engine.FP8): delayed-scaling state travels with the checkpoint ---------------------------------
+    @staticmethod
+    def _fp8_stacks(which, eng):
+        for name in ("stack", "st_t", "st_a", "st_v", "st_mm", "st_dec"):
+            st = getattr(eng, name, None)
+            if st is not None and getattr(st, "fp8", False):
+                yield name, st
+
+    def fp8_state(self):
+        """{'<pass>/<batch>/<stack>': scales, amax history, ring position, calibrated GEMMs} of every engine built so far ({} when the
+        fp8 mode is off).  Saved beside the weights so that a resumed run quantises on the same grids instead of re-calibrating."""
+        out = {}
+        for (which, batch), eng in self._engines.items():
+            for name, st in self._fp8_stacks(which, eng):
+                out[f"{which}/{batch}/{name}"] = st.fp8_state()
+        return out
+
+    def load_fp8_state(self, state):
+        self._fp8_pending = dict(state or {})
+        for (which, batch), eng in self._engines.items():
+            for name, st in self._fp8_stacks(which, eng):
+                if f"{which}/{batch}/{name}" in self._fp8_pending:
+                    st.load_fp8_state(self._fp8_pending[f"{which}/{batch}/{name}"])
+
+    def fp8_saturation_events(self):
+        """(tensor, step) pairs whose values exceeded the e4m3 range of the delayed scale they were quantised with (synchronises)"""
+        return sum(st.f8.saturation_events() for (which, _), eng in self._engines.items() for _, st in self._fp8_stacks(which, eng))
 
     def _sync_shadows(self):
         # an optimizer the model does not know about (the reference loop's torch.optim.Adam, p.data edits, EMA) changes the fp32

@@ -88,7 +88,7 @@ def layernorm_ws(rows, D):
     return _lib.load().avs_layernorm_ws_floats(rows, D)
 
 
-def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod=None, out_map=None, y8=None, q8=1.0):
+def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod=None, out_map=None, y8=None, q8=1.0, q8_dev=None):
     D = x.shape[1]
     _chk(x, F32, "ln.x", 2); _chk(y, y.dtype if y.dtype in (BF16, F32) else BF16, "ln.y", 2); _chk(mean, F32, "ln.mean"); _chk(rstd, F32, "ln.rstd")
     _chk(g0, F32, "ln.g0"); _chk(b0, F32, "ln.b0"); _chk(g1, F32, "ln.g1"); _chk(b1, F32, "ln.b1")
@@ -105,7 +105,7 @@ def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod
         _chk(y8, U8, "ln.y8", 2)
         assert y8.shape[1] == D and y8.shape[0] >= rows and y.dtype == BF16 and out_map is None
     _launch("layernorm_fwd", float(rows) * D * (4 + y.element_size()), "avs_layernorm_fwd_q8", x, g0, b0, g1, b1, row_mod, out_map, y, 1 if y.dtype == F32 else 0, mean, rstd, rows, D,
-              float(eps), y8, float(q8), _stream())
+              float(eps), y8, float(q8), _qrec(q8_dev), _stream())
 
 
 def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=None, db1=None, row_mod=None,
@@ -182,6 +182,53 @@ def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None
 FP8_MAX = 448.0          # largest finite OCP e4m3 value
 
 
+def _qrec(q):
+    """a device quantisation record (fp32 [4]: scale, 1 / scale, running amax, saturation events; csrc/common.h AVS_Q_*) or None"""
+    if q is None:
+        return None
+    if not (q.is_cuda and q.dtype == F32 and q.numel() == 4 and q.is_contiguous()):
+        raise _lib.AvsiamHipError("fp8 record: need a contiguous fp32 GPU tensor of 4 elements")
+    return q
+
+
+class Fp8Records:
+    """Device-resident fp8 quantisation state of `n` tensors with delayed scaling (engine.FP8): records q[n, 4] and an amax history
+    ring hist[nhist, n].  update() is one tiny launch and never synchronises: hist[pos] <- amax since the last update,
+    scale <- 448 / (margin * max(hist)), amax <- 0, saturation counter += (amax * old scale > 448)."""
+
+    def __init__(self, n, dev, nhist=16, margin=2.0):
+        self.n, self.nhist, self.margin, self.pos = n, nhist, margin, 0
+        self.q = torch.zeros((n, 4), dtype=F32, device=dev)
+        self.hist = torch.zeros((nhist, n), dtype=F32, device=dev)
+
+    def rec(self, i):
+        return self.q[i]
+
+    def update(self, first=0, count=None):
+        """count None: the whole table, and the history ring advances (once per forward).  A sub-range (calibration of tensors seen
+        for the first time) is written into the current history slot without advancing."""
+        whole = count is None
+        count = self.n - first if whole else count
+        if count <= 0:
+            return
+        assert 0 <= first and first + count <= self.n
+        _lib.call("avs_fp8_scale_update", self.q, self.hist, self.n, self.nhist, self.pos, float(self.margin), int(first), int(count), _stream())
+        if whole and first == 0:
+            self.pos = (self.pos + 1) % self.nhist
+
+    def state(self):
+        return {"q": self.q.detach().cpu().clone(), "hist": self.hist.detach().cpu().clone(), "pos": self.pos, "margin": self.margin}
+
+    def load(self, st):
+        assert tuple(st["q"].shape) == tuple(self.q.shape) and tuple(st["hist"].shape) == tuple(self.hist.shape), "fp8 state of another shape"
+        self.q.copy_(st["q"]); self.hist.copy_(st["hist"])
+        self.pos, self.margin = int(st["pos"]), float(st["margin"])
+
+    def saturation_events(self):
+        """total number of (tensor, update) pairs that saturated under the scale they were quantised with (synchronises: tests / logs)"""
+        return float(self.q[:, 3].sum().item())
+
+
 def absmax(x):
     """max |x| of a fp32 / bf16 GPU tensor, as a python float (synchronises: calibration / tests; a training loop would keep it on the device)"""
     assert x.is_cuda and x.is_contiguous() and x.dtype in (F32, BF16)
@@ -190,26 +237,42 @@ def absmax(x):
     return float(out.item())
 
 
-def quantize_fp8(x, scale, out=None):
-    """x (fp32 / bf16, contiguous) -> uint8 tensor holding OCP e4m3 of clamp(x * scale, +-448)"""
+def absmax_into(x, q):
+    """fold max |x| into the running amax of the device record q (no synchronisation)"""
+    assert x.is_cuda and x.is_contiguous() and x.dtype in (F32, BF16)
+    _lib.call("avs_absmax", x, 1 if x.dtype == F32 else 0, x.numel(), _qrec(q)[2:3], _stream())
+
+
+def quantize_fp8(x, scale, out=None, q=None):
+    """x (fp32 / bf16, contiguous) -> uint8 tensor holding OCP e4m3 of clamp(x * scale, +-448); with a device record q the scale is q[0]
+    and max |x| is folded into q[2]"""
     assert x.is_cuda and x.is_contiguous() and x.dtype in (F32, BF16) and x.numel() % 4 == 0
     y = out if out is not None else torch.empty(x.shape, dtype=U8, device=x.device)
     assert y.dtype == U8 and y.numel() == x.numel() and y.is_contiguous()
-    _lib.call("avs_quantize_fp8", x, 1 if x.dtype == F32 else 0, y, x.numel(), float(scale), _stream())
+    _lib.call("avs_quantize_fp8", x, 1 if x.dtype == F32 else 0, y, x.numel(), float(scale), _qrec(q), _stream())
     return y
 
 
-def gemm_nt_fp8(A8, B8, out, M, alpha, bias=None, res=None, out2=None, act=0, scale_cols=0, col_scale=1.0, out8=None, out8_scale=1.0):
+def gemm_nt_fp8(A8, B8, out, M, alpha=1.0, bias=None, res=None, out2=None, act=0, scale_cols=0, col_scale=1.0, out8=None, out8_scale=1.0,
+                qa=None, qw=None, q8=None, dual=None):
     """x = alpha * (A8[M, K] @ B8[N, K]^T) + bias (+ res); act 0: out = x; act 1: out = gelu'(x), out2 = gelu(x) (like gemm_nt).
-    A8 / B8: uint8 tensors of e4m3 values (quantize_fp8), alpha = 1 / (scale_A * scale_B)."""
+    A8 / B8: uint8 tensors of e4m3 values (quantize_fp8), alpha = 1 / (scale_A * scale_B) - or the device records qa / qw (delayed
+    scaling: the kernel reads qa[1] * qw[1]); q8: the record of out8.  dual = (m_split, B8_2, bias2, qw2): a second weight set."""
     _chk(A8, U8, "gemm8.A", 2); _chk(B8, U8, "gemm8.B", 2); _chk(bias, F32, "gemm8.bias"); _chk(res, F32, "gemm8.res", 2); _chk(out2, BF16, "gemm8.out2", 2)
     _chk(out8, U8, "gemm8.out8", 2)
     assert out.dtype in (BF16, F32) and out.dim() == 2 and out.is_contiguous()
     N, K = B8.shape
     assert A8.shape[1] == K and A8.shape[0] >= M and out.shape[0] >= M and out.shape[1] == N
+    assert (qa is None) == (qw is None)
+    m_split, B2, bias2, qw2 = dual if dual is not None else (0, None, None, None)
+    if dual is not None:
+        _chk(B2, U8, "gemm8.B2", 2); _chk(bias2, F32, "gemm8.bias2")
+        assert B2.shape == B8.shape and B2.stride(0) == B8.stride(0) and 0 < m_split < M and m_split % 256 == 0 and qa is not None and qw2 is not None
+        assert (bias2 is None) == (bias is None)
     _launch("gemm_nt_fp8", 2.0 * M * N * K, "avs_gemm_nt_fp8", A8, A8.stride(0), B8, B8.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
             out, out.stride(0), 1 if out.dtype == F32 else 0, out2, out2.stride(0) if out2 is not None else 0, float(alpha), int(act), int(scale_cols),
-            float(col_scale), out8, out8.stride(0) if out8 is not None else 0, float(out8_scale), _stream())
+            float(col_scale), out8, out8.stride(0) if out8 is not None else 0, float(out8_scale), _qrec(qa), _qrec(qw), _qrec(q8),
+            int(m_split), B2, bias2, _qrec(qw2), _stream())
 
 
 def gemm_tn(A, B, C, M, splits=0):
@@ -251,15 +314,17 @@ def attn_q_scale(hd):
     return hd ** -0.5 * 1.4426950408889634
 
 
-def attn_fwd(qkv, tiles, H, out, lse):
-    _chk(qkv, BF16, "attn.qkv", 2); _chk(out, BF16, "attn.out", 2); _chk(lse, F32, "attn.lse", 2)
+def attn_fwd(qkv, tiles, H, out, lse, out8=None, q8=None):
+    """out8 / q8 (fp8 mode): also write the e4m3 copy of the output for the proj GEMM, scaled by the device record q8"""
+    _chk(qkv, BF16, "attn.qkv", 2); _chk(out, BF16, "attn.out", 2); _chk(lse, F32, "attn.lse", 2); _chk(out8, U8, "attn.out8", 2)
+    assert (out8 is None) == (q8 is None) and (out8 is None or (out8.shape[0] >= tiles.max_row and out8.shape[1] == out.shape[1]))
     D = qkv.shape[1] // 3
     assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64, 80)
     assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= tiles.max_row
     assert lse.shape[0] == H and lse.shape[1] >= tiles.max_row
     # algorithmic HBM bytes: q, k, v read and o written once per row (bf16), lse written per head and row
-    _launch("attn_fwd_hd%d" % (D // H), (4.0 * tiles.sum_sq * D, tiles.rows * (8.0 * D + 4.0 * H)), "avs_attn_fwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, out.stride(0),
-            lse, lse.shape[1], _stream())
+    _launch("attn_fwd_hd%d" % (D // H), (4.0 * tiles.sum_sq * D, tiles.rows * (8.0 * D + 4.0 * H)), "avs_attn_fwd_q8", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, out.stride(0),
+            lse, lse.shape[1], out8, out8.stride(0) if out8 is not None else 0, _qrec(q8), _stream())
 
 
 def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):

@@ -88,6 +88,9 @@ def _save_checkpoint(audio_model, path):
     can load it."""
     sd = {"module." + k: v.detach().cpu() for k, v in audio_model.state_dict().items()}
     torch.save(sd, path)
+    f8 = audio_model.fp8_state() if hasattr(audio_model, "fp8_state") else {}
+    if f8:                                                  # fp8 mode: the delayed-scaling state, beside the weights (model.load_fp8_state)
+        torch.save(f8, path + ".fp8")
 
 
 def train(audio_model, train_sampler, test_loader, test_sampler, train_loader_linear, args, audio_conf):

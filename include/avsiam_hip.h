@@ -35,10 +35,11 @@ int avs_layernorm_fwd(const float* x, const float* g0, const float* b0, const fl
                       const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd, int rows,
                       int D, float eps, avs_stream_t stream);
 /* the same, also writing y8 = e4m3(clamp(y * q8, +-448)) (bf16 output only; y8 may be NULL): the fp8 operand of the forward GEMM that
- * consumes this LayerNorm in the fp8-forward mode, without a quantising pass of its own */
+ * consumes this LayerNorm in the fp8-forward mode, without a quantising pass of its own.  q8_dev (may be NULL): a device
+ * quantisation record (see avs_fp8_scale_update) - the scale is then read from q8_dev[0] and max |y| folded into q8_dev[2] */
 int avs_layernorm_fwd_q8(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
                          const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd, int rows,
-                         int D, float eps, uint8_t* y8, float q8, avs_stream_t stream);
+                         int D, float eps, uint8_t* y8, float q8, float* q8_dev, avs_stream_t stream);
 /* dx = dres + LN'(dy) (dres may be NULL; dx may alias dres); dy is bf16, or fp32 when dy_f32; dx_bf16 (may be NULL) gets a
  * bf16 copy of dx; dg/db are accumulated (+=); dcol (may be NULL) accumulates the column sum of dx, i.e. the bias gradient
  * of the Linear that produced this residual branch; ws: avs_layernorm_ws_floats.
@@ -67,13 +68,22 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
  * act 1: out = gelu'(x), out2 = gelu(x) (bf16), as in avs_gemm_nt_bf16, and out8 (may be NULL) = e4m3(gelu(x) * out8_scale) for the next fp8 GEMM.
  * fp32 accumulation on v_mfma_f32_16x16x128_f8f6f4,
  * the 8-phase 256x256 kernel of the bf16 GEMM with 128-value K-tiles.  alpha carries 1 / (scale_A * scale_B).  N%256==0, K%128==0,
- * K>=256, leading dimensions multiples of 16.  avs_absmax: out = max(out, max |x|) (caller zeroes out; x fp32 or bf16);
- * avs_quantize_fp8: y = e4m3(clamp(x * scale, +-448)), n%4==0. */
+ * K>=256, leading dimensions multiples of 16.
+ * Delayed scaling (no host synchronisation anywhere): a tensor's quantisation state is a DEVICE record of four floats
+ * q = {scale, 1 / scale, running max |x| since the last update, saturation events}.  Where an entry point takes such a record
+ * (qa / qw / qw2: operands of the GEMM, de-quantisation factor qa[1] * qw[1]; q8: the e4m3 copy a kernel writes - scale q8[0], amax into
+ * q8[2]) it overrides the host float beside it.  avs_fp8_scale_update(q [n][4], hist [nhist][n], n, nhist, pos, margin, first, count): per record
+ * in [first, first + count), hist[pos] = q[2]; scale = 448 / (margin * max over hist); q[2] = 0; q[3] += (q[2] * old scale > 448).
+ * m_split / B2 / bias2 / qw2: a second weight set for rows from m_split (m_split % 256 == 0; needs the records), else m_split = 0.
+ * avs_absmax: out = max(out, max |x|) (caller zeroes out; x fp32 or bf16);
+ * avs_quantize_fp8: y = e4m3(clamp(x * scale, +-448)), n%4==0; with q: scale = q[0], max |x| into q[2]. */
 int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long ldb, int M, int N, int K, const float* bias,
                     const float* res, long long ldr, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
-                    int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale, avs_stream_t stream);
+                    int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale, const float* qa,
+                    const float* qw, float* q8, int m_split, const uint8_t* B2, const float* bias2, const float* qw2, avs_stream_t stream);
 int avs_absmax(const void* x, int is_f32, long long n, float* out, avs_stream_t stream);
-int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, avs_stream_t stream);
+int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, float* q, avs_stream_t stream);
+int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, avs_stream_t stream);
 /* the same GEMM over TWO weight sets in one launch: rows [0, m_split) of A meet B / bias / colsum, rows [m_split, M) meet
  * B2 / bias2 / colsum2 (same shapes and leading dimension; m_split a multiple of 256).  Replaces the two nn.Linear calls the
  * reference makes per layer for its separate audio and visual towers (cav_mae_base.py:487,489: `blk(v, 'v')` on
@@ -108,6 +118,11 @@ int avs_gemm_tn_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
 int avs_attn_fwd(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                  const int* tile_q0, int ntiles, int tile_rows, avs_bf16* out, long long ldo, float* lse, int rows_total,
                  avs_stream_t stream);
+/* the same, also writing out8 = e4m3(clamp(out * q8[0], +-448)) [rows, D] / ldo8 - the fp8 operand of the proj GEMM in the fp8 mode -
+ * and folding max |out| into q8[2] (device quantisation record, see avs_fp8_scale_update); out8 and q8 both NULL = avs_attn_fwd */
+int avs_attn_fwd_q8(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                    const int* tile_q0, int ntiles, int tile_rows, avs_bf16* out, long long ldo, float* lse, int rows_total,
+                    uint8_t* out8, long long ldo8, float* q8, avs_stream_t stream);
 int avs_attn_bwd(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                  const int* tile_q0, int ntiles, int tile_rows, const avs_bf16* out, const avs_bf16* dout, long long ldo,
                  const float* lse, float* delta, int rows_total, avs_bf16* dqkv, avs_stream_t stream);

@@ -627,3 +627,93 @@ def test_gemm_nt_fp8(M, N, K, f32out):
     full = A.double() @ W.to(torch.bfloat16).double().t() + b.double() + (res[:M].double() if f32out else 0)
     e = rel_err(out[:M], full)
     assert 5e-3 < e < 8e-2, e
+
+
+def test_fp8_delayed_scaling_records():
+    """The fp8 mode's device-side quantisation state (ops.Fp8Records, csrc/common.h AVS_Q_*): calibration (absmax -> scale on the device),
+    the producers that write e4m3 operands themselves (quantising pass, LayerNorm, GELU epilogue, attention epilogue) read the scale from the
+    record and fold their |max| into it, the GEMM de-quantises with the two records, two weight sets in one launch, the history ring, the
+    saturation counter.  No call here synchronises except the test's own reads."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    M, N, K = 1024, 768, 768
+    A = torch.randn(M, K, device=DEV, generator=g) * 1.7
+    W = bf(torch.randn(N, K, device=DEV, generator=g) * 0.05)
+    W2 = bf(torch.randn(N, K, device=DEV, generator=g) * 0.11)
+    b, b2 = torch.randn(N, device=DEV, generator=g), torch.randn(N, device=DEV, generator=g)
+    rec = o.Fp8Records(6, DEV, nhist=4, margin=2.0)
+    ra, rw, rw2, r8 = rec.rec(0), rec.rec(1), rec.rec(2), rec.rec(3)
+    o.absmax_into(A, ra); o.absmax_into(W, rw); o.absmax_into(W2, rw2)
+    rec.update(first=0, count=3)
+    q = rec.q.cpu()
+    for i, t in enumerate((A, W, W2)):
+        amax = t.float().abs().max().item()
+        assert abs(q[i, 0].item() - 448.0 / (2 * amax)) <= 1e-5 * q[i, 0].item() and abs(q[i, 0].item() * q[i, 1].item() - 1) < 1e-6 and q[i, 2].item() == 0
+    assert rec.pos == 0 and q[3:].abs().max().item() == 0                 # a partial update neither advances the ring nor touches other records
+    A8 = o.quantize_fp8(A, 123.0, q=ra)                                   # the host scale is ignored beside a record
+    W8, W82 = o.quantize_fp8(W, 1.0, q=rw), o.quantize_fp8(W2, 1.0, q=rw2)
+    sa, sw, sw2 = (rec.q[i, 0].item() for i in range(3))
+    assert torch.equal(A8.view(torch.float8_e4m3fn), (A * sa).clamp(-448, 448).to(torch.float8_e4m3fn))
+    assert rec.q[0, 2].item() == A.abs().max().item()                     # the pass recorded what it saw
+    out = torch.zeros(M, N, device=DEV)
+    o.gemm_nt_fp8(A8, W8, out, M, 77.0, bias=b, qa=ra, qw=rw)
+    want = torch.zeros(M, N, device=DEV)
+    o.gemm_nt_fp8(A8, W8, want, M, 1.0 / (sa * sw), bias=b)
+    assert rel_err(out, want) < 1e-6
+    # two weight sets in one launch == two launches on the row ranges
+    o.gemm_nt_fp8(A8, W8, out, M, bias=b, qa=ra, qw=rw, dual=(512, W82, b2, rw2))
+    o.gemm_nt_fp8(A8[512:].contiguous(), W82, want[512:], M - 512, 1.0 / (sa * sw2), bias=b2)
+    assert rel_err(out, want) < 1e-6 and rel_err(out[512:], want[512:]) < 1e-6
+    # GELU epilogue writing the next GEMM's operand with the record r8 (first calibrated from the bf16 gelu output)
+    dact = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16); act = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm_nt_fp8(A8, W8, dact, M, bias=b, out2=act, act=1, qa=ra, qw=rw)
+    o.absmax_into(act, r8)
+    rec.update(first=3, count=1)
+    act8 = torch.zeros(M, N, device=DEV, dtype=torch.uint8)
+    o.gemm_nt_fp8(A8, W8, dact, M, bias=b, out2=act, act=1, qa=ra, qw=rw, out8=act8, q8=r8)
+    s8 = rec.q[3, 0].item()
+    deq = act8.view(torch.float8_e4m3fn).float() / s8
+    assert float((deq - act.float()).abs().max()) <= 2 ** -4 * act.float().abs().max().item() + 1e-3       # e4m3: 3 mantissa bits
+    assert rel_err(deq, act) < 0.04
+    assert abs(rec.q[3, 2].item() - act.float().abs().max().item()) <= 1e-2 * act.float().abs().max().item()
+    # LayerNorm writing the e4m3 copy with a record
+    D, rows = 768, 777
+    x = torch.randn(rows, D, device=DEV, generator=g) * 3
+    gm, bt = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    y = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16); y8 = torch.zeros(rows, D, device=DEV, dtype=torch.uint8)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    rl = rec.rec(4)
+    o.layernorm_fwd(x, gm, bt, y, mean, rstd, rows, 1e-5)
+    o.absmax_into(y, rl)
+    rec.update(first=4, count=1)
+    o.layernorm_fwd(x, gm, bt, y, mean, rstd, rows, 1e-5, y8=y8, q8_dev=rl)
+    sl = rec.q[4, 0].item()
+    assert rel_err(y8.view(torch.float8_e4m3fn).float() / sl, y) < 0.04
+    assert abs(rec.q[4, 2].item() - y.float().abs().max().item()) <= 1e-2 * y.float().abs().max().item()
+    # attention epilogue writing the proj operand
+    Dm, H, L = 768, 12, 200
+    qkv = bf(torch.randn(2 * L, 3 * Dm, device=DEV, generator=g) * 0.5)
+    tiles = o.AttnTiles([L, L], DEV)
+    att = torch.zeros(o.pad_rows(2 * L), Dm, device=DEV, dtype=torch.bfloat16)
+    att8 = torch.zeros(o.pad_rows(2 * L), Dm, device=DEV, dtype=torch.uint8)
+    lse = torch.zeros(H, o.pad_rows(2 * L), device=DEV)
+    rt = rec.rec(5)
+    o.attn_fwd(qkv, tiles, H, att, lse)
+    ref_att = att.clone()
+    o.absmax_into(att, rt)
+    rec.update(first=5, count=1)
+    o.attn_fwd(qkv, tiles, H, att, lse, out8=att8, q8=rt)
+    assert torch.equal(att, ref_att)                                       # the bf16 output does not change
+    st_ = rec.q[5, 0].item()
+    assert rel_err(att8[:2 * L].view(torch.float8_e4m3fn).float() / st_, att[:2 * L]) < 0.04
+    # the ring: a whole-table update stores the amax, restarts it and advances; a 3x larger tensor saturates under the old scale once
+    o.quantize_fp8(A * 3, 1.0, q=ra)
+    rec.update()
+    q = rec.q.cpu()
+    assert rec.pos == 1 and q[0, 3].item() == 1.0 and q[1, 3].item() == 0.0 and q[0, 2].item() == 0.0
+    assert abs(q[0, 0].item() - 448.0 / (2 * 3 * A.abs().max().item())) <= 1e-5 * q[0, 0].item()
+    assert rec.saturation_events() == 1.0
+    st = rec.state()
+    rec2 = o.Fp8Records(6, DEV, nhist=4, margin=2.0)
+    rec2.load(st)
+    assert torch.equal(rec2.q, rec.q) and torch.equal(rec2.hist, rec.hist) and rec2.pos == rec.pos
