@@ -85,6 +85,11 @@ class RcclComm:
         handle = ctypes.c_void_p()
         _lib.call("avs_comm_init", ctypes.cast(uid, ctypes.c_void_p), self.rank, self.world, ctypes.byref(handle))
         self._h = handle
+        # destroyed at interpreter exit while HIP and RCCL are still loaded (a __del__ during teardown may run after they are gone)
+        import atexit
+        import weakref
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())
 
     def _dtype(self, t):
         if t.dtype == torch.float32:
@@ -116,6 +121,9 @@ class RcclComm:
             self._h = None
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():      # interpreter teardown: HIP / RCCL may already be unloaded - atexit has closed us
+            return
         try:
             self.close()
         except Exception:

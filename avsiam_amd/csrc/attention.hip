@@ -75,16 +75,46 @@ struct TileRegs {
     f32x4 v[PER];
 };
 
-// HG: the head dim in memory when it is not a multiple of 32 (80: ViT-H); the LDS image is HD = 96 wide and its columns HG.. are zero
+// HG: the head dim in memory when it is not a multiple of 32 (80: ViT-H); the LDS image is HD = 96 wide and its columns HG.. are zero.
+// Addressing: a thread's chunk of a [64][HD] tile sits at the same (row, column) of EVERY tile, so its byte offset from the tile's
+// first row is computed once per kernel (TileOff, one 32-bit register per chunk, shared by the K and V - or Q and dO - streams of the
+// same leading dimension); per tile only the wave-uniform tile base moves (scalar arithmetic) and the load takes the
+// scalar-base + 32-bit-vector-offset form.  Recomputed with 64-bit multiplies per load it cost ~70 VALU issue cycles per tile and
+// wave in kernels whose bound IS the VALU issue (decoder attention: ~10 % of it).  Only a sequence's last, partial tile clamps rows.
+template <int HD, int NTH>
+struct TileOff {
+    static constexpr int NCH = HD / 8;
+    static constexpr int PER = 64 * NCH / NTH;
+    unsigned o[PER];
+    __device__ __forceinline__ void init(long long ld, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = i * NTH + tid;
+            o[i] = ((unsigned)(c / NCH) * (unsigned)ld + (unsigned)(c % NCH) * 8u) * 2u;
+        }
+    }
+};
+
 template <int HD, int NTH, int HG = HD>
-__device__ __forceinline__ void tile_load(TileRegs<HD, NTH>& t, const bf16_t* src, long long ld, int row0, int last_row, int tid) {
+__device__ __forceinline__ void tile_load(TileRegs<HD, NTH>& t, const TileOff<HD, NTH>& to, const bf16_t* src, long long ld, int row0, int last_row,
+                                          int tid) {
     constexpr int NCH = HD / 8;
+    const char* base = reinterpret_cast<const char*>(src + (size_t)row0 * ld);       // wave-uniform
+    unsigned off[TileRegs<HD, NTH>::PER];
+#pragma unroll
+    for (int i = 0; i < TileRegs<HD, NTH>::PER; ++i) off[i] = to.o[i];
+    if (row0 + 63 > last_row) {                                // block-uniform: the sequence's last, partial tile clamps its rows
+        asm volatile("; partial tile: clamp rows" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TileRegs<HD, NTH>::PER; ++i) {
+            const int c = i * NTH + tid;
+            off[i] = ((unsigned)min(c / NCH, last_row - row0) * (unsigned)ld + (unsigned)(c % NCH) * 8u) * 2u;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TileRegs<HD, NTH>::PER; ++i) {
-        const int c = i * NTH + tid;
-        const int row = c / NCH, ch = c % NCH;
-        const int gr = min(row0 + row, last_row);
-        if (HG == HD || ch < HG / 8) t.v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gr * ld + ch * 8);
+        const int ch = (i * NTH + tid) % NCH;
+        if (HG == HD || ch < HG / 8) t.v[i] = *reinterpret_cast<const f32x4*>(base + off[i]);
         else t.v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
@@ -163,16 +193,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     f32x16 negm = splat16(0.f);
 
     TileRegs<HD, NTH> rk, rv;
-    tile_load<HD, NTH, HG>(rk, base + a.D, a.ld, 0, L - 1, tid);
-    tile_load<HD, NTH, HG>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
+    TileOff<HD, NTH> toff;
+    toff.init(a.ld, tid);
+    tile_load<HD, NTH, HG>(rk, toff, base + a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rv, toff, base + 2 * a.D, a.ld, 0, L - 1, tid);
     for (int k0 = 0; k0 < L; k0 += 64) {
         __syncthreads();
         tile_store<HD, NTH>(rk, sK, tid);
         tile_store<HD, NTH>(rv, sV, tid);
         __syncthreads();
         if (k0 + 64 < L) {
-            tile_load<HD, NTH, HG>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
-            tile_load<HD, NTH, HG>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rk, toff, base + a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rv, toff, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
         }
         if (!active) continue;
         f32x16 s[2];
@@ -305,8 +337,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // dQ (query-major).  Also produces delta = rowsum(dO * O), reused by the dK/dV kernel.
+// (hd 32, 4 waves: the second launch-bound argument - 4 waves per SIMD - holds the kernel to 128 registers; it needs 132 otherwise and
+//  would run at three waves per SIMD)
 template <int HD, int NW, int HG = HD>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int NTH = 64 * NW;
     constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2];
@@ -350,16 +384,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 
     TileRegs<HD, NTH> rk, rv;
-    tile_load<HD, NTH, HG>(rk, base + a.D, a.ld, 0, L - 1, tid);
-    tile_load<HD, NTH, HG>(rv, base + 2 * a.D, a.ld, 0, L - 1, tid);
+    TileOff<HD, NTH> toff;
+    toff.init(a.ld, tid);
+    tile_load<HD, NTH, HG>(rk, toff, base + a.D, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rv, toff, base + 2 * a.D, a.ld, 0, L - 1, tid);
     for (int k0 = 0; k0 < L; k0 += 64) {
         __syncthreads();
         tile_store<HD, NTH>(rk, sK, tid);
         tile_store<HD, NTH>(rv, sV, tid);
         __syncthreads();
         if (k0 + 64 < L) {
-            tile_load<HD, NTH, HG>(rk, base + a.D, a.ld, k0 + 64, L - 1, tid);
-            tile_load<HD, NTH, HG>(rv, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rk, toff, base + a.D, a.ld, k0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rv, toff, base + 2 * a.D, a.ld, k0 + 64, L - 1, tid);
         }
         if (!active) continue;
         const bool tail_tile = k0 + 64 > L;                 // block-uniform
@@ -457,9 +493,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     const float* lsebase = a.lse + (size_t)head * a.rows_total + seq0;
     const float* delbase = a.delta + (size_t)head * a.rows_total + seq0;
     TileRegs<HD, NTH> rq, rdo;
+    TileOff<HD, NTH> toq, tod;                          // q rows have the qkv matrix's leading dimension, dO rows the output's
+    toq.init(a.ld, tid);
+    tod.init(a.ldo, tid);
     float rl = 0.f, rd = 0.f;
-    tile_load<HD, NTH, HG>(rq, base, a.ld, 0, L - 1, tid);
-    tile_load<HD, NTH, HG>(rdo, dobase, a.ldo, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rq, toq, base, a.ld, 0, L - 1, tid);
+    tile_load<HD, NTH, HG>(rdo, tod, dobase, a.ldo, 0, L - 1, tid);
     if (tid < 64) { rl = lsebase[min(tid, L - 1)]; rd = delbase[min(tid, L - 1)]; }
     for (int q0 = 0; q0 < L; q0 += 64) {
         __syncthreads();
@@ -468,8 +507,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (tid < 64) { sLse[tid] = -rl * 1.4426950408889634f; sDel[tid] = -rd; }    // negated: MFMA C operands
         __syncthreads();
         if (q0 + 64 < L) {
-            tile_load<HD, NTH, HG>(rq, base, a.ld, q0 + 64, L - 1, tid);
-            tile_load<HD, NTH, HG>(rdo, dobase, a.ldo, q0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rq, toq, base, a.ld, q0 + 64, L - 1, tid);
+            tile_load<HD, NTH, HG>(rdo, tod, dobase, a.ldo, q0 + 64, L - 1, tid);
             if (tid < 64) { rl = lsebase[min(q0 + 64 + tid, L - 1)]; rd = delbase[min(q0 + 64 + tid, L - 1)]; }
         }
         if (!active) continue;

@@ -8,11 +8,29 @@
 //     by the communicator's stream) and runs on the communicator's stream, so it overlaps whatever the caller queues next;
 //   * avs_comm_wait(comm, stream) orders `stream` behind every collective issued so far.
 // Nothing synchronises the host.  RCCL is resolved at run time from the copy already in the process (PyTorch loads one) or from
-// the system, so libavsiam_hip.so itself does not link against it and loads on machines without RCCL; avs_comm_* then fail loudly.
+// the system, so libavsiam_hip.so neither links against it nor needs its headers to build: the handful of NCCL-API types and
+// prototypes used here (stable since NCCL 2.x, which RCCL mirrors) are declared below; on a machine without RCCL the library still
+// builds and loads, and avs_comm_* fail loudly.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <string.h>
+
+// ---- the part of the NCCL / RCCL C API this file calls (rccl.h: ncclUniqueId :43, ncclResult_t :50-, ncclRedOp_t :448, ncclDataType_t :466-468)
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat32 = 7, ncclBfloat16 = 9 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclReduceScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
+                               hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+}
 
 extern "C" void avs_set_error(const char* fmt, ...);
 

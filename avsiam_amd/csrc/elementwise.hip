@@ -181,8 +181,10 @@ __global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* 
 // reps[s] = mean_{r in seg s} y[r]
 // grid (segments, D/128): a workgroup owns 32 float4 columns of one segment; its 8 row groups stride the rows and are
 // folded through LDS (one workgroup per segment walking up to 1960 rows serially took 0.85 ms per call).
+// row_map (may be NULL): the mean of segment s goes to reps[row_map[s]] - the contrastive pass's slot order -> sample order
+// (cav_mae_base.py:584-590: the reference's inverse permutation + gather) without a pass of its own
 __global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* __restrict__ y, const int* __restrict__ seg_start,
-                                                               float* __restrict__ reps, int D) {
+                                                               float* __restrict__ reps, int D, const int* __restrict__ row_map) {
     __shared__ float4 part[8][32];
     const int s = blockIdx.x;
     const int r0 = seg_start[s], r1 = seg_start[s + 1];
@@ -203,18 +205,18 @@ __global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* __re
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         const float inv = 1.0f / (float)(r1 - r0);
-        reinterpret_cast<float4*>(reps + (size_t)s * D)[c] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+        reinterpret_cast<float4*>(reps + (size_t)(row_map ? row_map[s] : s) * D)[c] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
     }
 }
 
-// dy[r] = scale * dreps[seg(r)] / len(seg)
+// dy[r] = scale * dreps[row_map ? row_map[seg(r)] : seg(r)] / len(seg)
 __global__ void segment_mean_bwd_kernel(const float* __restrict__ dreps, const int* __restrict__ seg_start, float* __restrict__ dy,
-                                        int D, float scale) {
+                                        int D, float scale, const int* __restrict__ row_map) {
     const int s = blockIdx.x;
     const int r0 = seg_start[s], r1 = seg_start[s + 1];
     const float inv = scale / (float)(r1 - r0);
     for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
-        float4 v = reinterpret_cast<const float4*>(dreps + (size_t)s * D)[c];
+        float4 v = reinterpret_cast<const float4*>(dreps + (size_t)(row_map ? row_map[s] : s) * D)[c];
         v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
         for (int r = r0; r < r1; ++r) reinterpret_cast<float4*>(dy + (size_t)r * D)[c] = v;
     }
@@ -539,17 +541,17 @@ extern "C" int avs_unshuffle_bwd(const float* dout, const int* src_row, int B, i
     return 0;
 }
 
-extern "C" int avs_segment_mean_fwd(const float* y, const int* seg_start, float* reps, int nseg, int D, hipStream_t stream) {
+extern "C" int avs_segment_mean_fwd(const float* y, const int* seg_start, float* reps, int nseg, int D, const int* row_map, hipStream_t stream) {
     AVS_CHECK_ARG(nseg > 0 && (D % 4) == 0, "segment_mean_fwd: bad args");
-    segment_mean_fwd_kernel<<<dim3(nseg, ceil_div(D, 128)), 256, 0, stream>>>(y, seg_start, reps, D);
+    segment_mean_fwd_kernel<<<dim3(nseg, ceil_div(D, 128)), 256, 0, stream>>>(y, seg_start, reps, D, row_map);
     AVS_LAUNCH_CHECK("segment_mean_fwd");
     return 0;
 }
 
-extern "C" int avs_segment_mean_bwd(const float* dreps, const int* seg_start, float* dy, int nseg, int D, float scale,
+extern "C" int avs_segment_mean_bwd(const float* dreps, const int* seg_start, float* dy, int nseg, int D, float scale, const int* row_map,
                                     hipStream_t stream) {
     AVS_CHECK_ARG(nseg > 0 && (D % 4) == 0, "segment_mean_bwd: bad args");
-    segment_mean_bwd_kernel<<<nseg, 256, 0, stream>>>(dreps, seg_start, dy, D, scale);
+    segment_mean_bwd_kernel<<<nseg, 256, 0, stream>>>(dreps, seg_start, dy, D, scale, row_map);
     AVS_LAUNCH_CHECK("segment_mean_bwd");
     return 0;
 }

@@ -459,24 +459,20 @@ class PatchEmbedder:
         self.lin = Linear(arena, pre + ".proj.weight", pre + ".proj.bias", need_t=False)
         pname = "vit_base.pos_embed_a" if audio else "vit_base.pos_embed"
         D = cfg.embed_dim
-        self.pos = arena.view(pname).view(-1, D)
-        self.gpos = arena.gview(pname).view(-1, D) if arena.g is not None else None
+        skip = 0 if audio else 1          # the visual table starts with the cls row (pos_embed[:, 1:, :], cav_mae_base.py:453): token t is row 1 + t
+        self.pos = arena.view(pname).view(-1, D)[skip:]
+        self.gpos = arena.gview(pname).view(-1, D)[skip:] if arena.g is not None else None
         K = cfg.patch * cfg.patch * (1 if audio else cfg.in_chans)
         rp = ops.pad_rows(rows, 128)
         self.cols = _z((rp, K), BF16, dev)
         self.dy = _z((rp, D), BF16, dev)
         # sample (audio) / frame image (video) and token id of each row; may be slices of a buffer the mask-plan kernel fills
         self.row_src = row_src if row_src is not None else _z((rows,), I32, dev)
-        self.row_tok = row_tok if row_tok is not None else _z((rows,), I32, dev)
-        self.row_pos = _z((rows,), I32, dev)     # row of the pos-embed table: tok (audio) / 1 + tok (video, skips cls)
+        self.row_tok = row_tok if row_tok is not None else _z((rows,), I32, dev)      # = row of self.pos / self.gpos
 
     def set_rows(self, row_src, row_tok):
         self.row_src.copy_(row_src, non_blocking=True)
         self.row_tok.copy_(row_tok, non_blocking=True)
-        self.rows_updated()
-
-    def rows_updated(self):
-        torch.add(self.row_tok, 0 if self.audio else 1, out=self.row_pos)
 
     def forward(self, inp, out, xf=None):
         """inp: audio [B,time,mel] / video [NF,3,H,W] fp32 - or the raw input (un-normalised fbank / uint8 frames) with its
@@ -485,7 +481,7 @@ class PatchEmbedder:
             ops.im2col_audio(inp, self.row_src, self.row_tok, self.cols, self.rows, self.cfg.audio_t, xf, stride=self.cfg.st)
         else:
             ops.im2col_video(inp, self.row_src, self.row_tok, self.cols, self.rows, xf, stride=self.cfg.st)
-        ops.gemm_nt(self.cols, self.lin.w, out, self.rows, bias=self.lin.b, res=self.pos, res_idx=self.row_pos, alpha=2.0)
+        ops.gemm_nt(self.cols, self.lin.w, out, self.rows, bias=self.lin.b, res=self.pos, res_idx=self.row_tok, alpha=2.0)
 
     def backward(self, dx):
         """dx: fp32 [rows, D] gradient of the embedding output."""
@@ -493,7 +489,7 @@ class PatchEmbedder:
         ops.cast_scale(dx, self.dy, self.rows * D, 2.0)
         ops.gemm_tn(self.dy, self.cols, self.lin.gw, self.rows)
         ops.colsum(self.dy, self.lin.gb, self.rows)
-        ops.scatter_add_rows(self.dy, self.row_pos, self.gpos, self.rows)
+        ops.scatter_add_rows(self.dy, self.row_tok, self.gpos, self.rows)
 
 
 def _fold_frames(imgs, T):
@@ -563,21 +559,24 @@ class ContrastivePass:
         self.seg_start = torch.tensor(seg, dtype=I32, device=dev)
         self.yf = _z((self.stack.rp, D), F32, dev)
         self.fstat = [_z((self.stack.rp,), F32, dev) for _ in range(2)]
-        self.reps_slot = _z((2 * batch, D), F32, dev)         # [audio slots | video slots]
-        self.slot_to_row = _z((2 * batch,), torch.int64, dev)  # slot -> row of `reps` ([a samples | v samples])
+        # slot (group-major position in the packed stack) -> sample: row 0 maps a slot to its row of `reps` ([a samples | v samples]),
+        # row 1 to its row of `dAV` ([dA of all W*B samples | dV ...]: this rank's slice) - both folded into the token-mean kernels
+        self.slot_maps = _z((2, 2 * batch), I32, dev)
         self.reps = _z((2 * batch, D), F32, dev)
         N = world * batch
         self.N = N
         self.all_reps = _z((world, 2 * batch, D), F32, dev)
-        self.A, self.V = _z((N, D), F32, dev), _z((N, D), F32, dev)
+        if world == 1:
+            self.A, self.V = self.reps[:batch], self.reps[batch:]         # one rank: the embeddings ARE the batch
+        else:
+            self.A, self.V = _z((N, D), F32, dev), _z((N, D), F32, dev)
         self.An, self.Vn = _z((N, D), F32, dev), _z((N, D), F32, dev)
         self.na, self.nv = _z((N,), F32, dev), _z((N,), F32, dev)
         self.total, self.dtotal = _z((N, N), F32, dev), _z((N, N), F32, dev)
         self.nstats, self.nout = _z((N, 4), F32, dev), _z((3,), F32, dev)
         self.dAn, self.dVn = _z((N, D), F32, dev), _z((N, D), F32, dev)
-        self.dA, self.dV = _z((N, D), F32, dev), _z((N, D), F32, dev)
-        self.dreps = _z((2 * batch, D), F32, dev)
-        self.dreps_slot = _z((2 * batch, D), F32, dev)
+        self.dAV = _z((2 * N, D), F32, dev)
+        self.dA, self.dV = self.dAV[:N], self.dAV[N:]
 
     # ---- plan -> index arrays (host, O(rows) ints) --------------------------------------------------
     def _set_plan(self, plan: ContrastivePlan):
@@ -604,8 +603,15 @@ class ContrastivePass:
                 src_v.append(torch.full((ids.numel(),), int(s) * T + t, dtype=torch.int64))
         self.emb_a.set_rows(torch.cat(src_a).to(I32), torch.cat(tok_a).to(I32))
         self.emb_v.set_rows(torch.cat(src_v).to(I32), torch.cat(tok_v).to(I32))
-        s2r = torch.cat([torch.from_numpy(order_a), B + torch.from_numpy(order_v)])
-        self.slot_to_row.copy_(s2r, non_blocking=True)
+        self._set_slot_maps(np.concatenate([order_a, B + order_v]))
+
+    def _set_slot_maps(self, s2r):
+        """s2r[slot] = row of `reps` (a sample below B, B + v sample from B) the slot's sequence(s) belong to"""
+        B, r, N = self.B, self.rank, self.N
+        s2r = np.asarray(s2r, dtype=np.int64)
+        assert s2r.shape == (2 * B,) and sorted(s2r.tolist()) == list(range(2 * B))
+        src = np.where(s2r < B, r * B + s2r, N + r * B + (s2r - B))           # the same sample's row of dAV (this rank's slice)
+        self.slot_maps.copy_(torch.from_numpy(np.stack([s2r, src]).astype(np.int32)), non_blocking=True)
 
     def draw_device(self, seed, nprng):
         """Draw this step's plan on the device (ops.mask_plan): the host only picks the two batch permutations
@@ -637,10 +643,7 @@ class ContrastivePass:
         self.bits_dev.copy_(torch.from_numpy(self.bits_host), non_blocking=True)
         ops.mask_plan(self.desc_dev, d, seed, self.row_src_all, self.row_tok_all, self.bits_dev[0], self.bits_dev[1], self.bits_dev[2],
                       ids_out=self.ids_dev)
-        self.emb_a.rows_updated()
-        self.emb_v.rows_updated()
-        s2r = torch.from_numpy(np.concatenate([perm_a, B + perm_v]))
-        self.slot_to_row.copy_(s2r, non_blocking=True)
+        self._set_slot_maps(np.concatenate([perm_a, B + perm_v]))
         self.last_perm = (perm_a, perm_v)
 
     def last_plan(self):
@@ -672,16 +675,13 @@ class ContrastivePass:
         self.emb_v.forward(_fold_frames(imgs, cfg.frames), x0[self.rows_a:], xf[1])
         st.forward(self.blocks)
         _ln_fwd(st.out, self.final, self.yf, self.fstat[0], self.fstat[1], self.rows, LN_EPS_FINAL, st.row_mod)
-        ops.segment_mean_fwd(self.yf, self.seg_start, self.reps_slot, 2 * self.B)
-        self.reps.index_copy_(0, self.slot_to_row, self.reps_slot)        # slot order -> sample order
         B, W, D = self.B, self.world, cfg.embed_dim
+        ops.segment_mean_fwd(self.yf, self.seg_start, self.reps, 2 * B, row_map=self.slot_maps[0], max_row=2 * B)   # slot -> sample order
         if self.dp:
             self.comm.all_gather(self.all_reps.view(W * 2 * B, D), self.reps)             # c2: one [2,B,D] message per rank (RCCL)
+        if W > 1:
             self.A.copy_(self.all_reps[:, :B].reshape(W * B, D))
             self.V.copy_(self.all_reps[:, B:].reshape(W * B, D))
-        else:
-            self.A.copy_(self.reps[:B])
-            self.V.copy_(self.reps[B:])
         N = self.N
         ops.l2norm_fwd(self.A, self.An, self.na)
         ops.l2norm_fwd(self.V, self.Vn, self.nv)
@@ -699,13 +699,10 @@ class ContrastivePass:
         ops.gemm_f32_small(self.dtotal, self.An, self.dVn, N, D, N, (1, N), (D, 1), 1.0 / cfg.temperature)
         ops.l2norm_bwd(self.dAn, self.An, self.na, self.dA)
         ops.l2norm_bwd(self.dVn, self.Vn, self.nv, self.dV)
-        r = self.rank
         # GatherLayer.backward all-reduces W identical copies and keeps the own slice (gather_layer.py:35-37):
-        # that is W x the own-slice gradient, no collective needed.
-        self.dreps[:B].copy_(self.dA[r * B:(r + 1) * B])
-        self.dreps[B:].copy_(self.dV[r * B:(r + 1) * B])
-        torch.index_select(self.dreps, 0, self.slot_to_row, out=self.dreps_slot)
-        ops.segment_mean_bwd(self.dreps_slot, self.seg_start, self.yf, 2 * B, float(W))
+        # that is W x the own-slice gradient, no collective needed.  The slot's row of this rank's slice of
+        # [dA | dV] comes through the row map.
+        ops.segment_mean_bwd(self.dAV, self.seg_start, self.yf, 2 * B, float(W), row_map=self.slot_maps[1], max_row=2 * N)
         _ln_bwd(self.yf, st.out, self.fstat[0], self.fstat[1], self.final, _dx_in(st), st.lnws, self.rows, st.row_mod,
                 dx_bf16=st.dxb[0], dcol=self.blocks[-1].fc2.gb)
         st.backward(self.blocks, last_fc2_bias_done=True, reducer=reducer, accumulate=accumulate)
@@ -831,8 +828,6 @@ class MaePass:
         """75 % unstructured masks of every audio / video sequence, drawn on the device (one launch)."""
         ops.mask_plan(self.desc_dev, self.desc_host, seed, self.row_src_all, self.row_tok_all, src_row=self.src_row,
                       mask_out=self.mask_all, ids_out=self.ids_dev)
-        self.emb_a.rows_updated()
-        self.emb_v.rows_updated()
 
     def last_plan(self):
         """Rebuild the MaePlan the device drew (tests / debugging; synchronises)."""

@@ -121,7 +121,7 @@ class _HotPath(torch.autograd.Function):
         if red:
             for w in (P1, P2):
                 if live & w:
-                    model._grad_scale[w] = 1.0 / model._world          # the SUM is in the arena; DDP's mean is still owed
+                    model._owe(w, 1.0 / model._world)                  # the SUM is in the arena; DDP's mean is still owed
                     model._reduced[w] = True
             if model.publish_grads:                                    # an external optimizer reads .grad: deliver the mean now
                 for w in (P1, P2):
@@ -161,7 +161,9 @@ class CAVMAE_BASE(nn.Module):
         self._comm, self._dp = None, False
         self.reduce_in_backward = True             # data parallel: loss.backward() all-reduces, like DDP (False: call allreduce_grads)
         self._reduced = {P1: False, P2: False}     # this pass's gradients in the arena are already summed over the ranks
-        self._grad_scale = {P1: 1.0, P2: 1.0}      # factor the arena's gradients still owe (1/W after a SUM all-reduce)
+        # factor the arena's gradients still owe (1/W after a SUM all-reduce), per SEGMENT of the arena: the live ranges of the two
+        # passes overlap in the shared parameters, and a factor applied per pass would hit that middle segment twice
+        self._grad_scale = {"p1": 1.0, "shared": 1.0, "p2": 1.0}
         self._versions = None
         self.last_reduce_messages = 0
         self._gen = None
@@ -216,18 +218,25 @@ class CAVMAE_BASE(nn.Module):
         self._wire_staging = r.staging               # the bf16 wire buffer (AVSIAM_DP_WIRE=bf16) is kept across steps
         return r
 
+    def _segments(self, which):
+        """(name, lo, hi) of the arena segments pass `which` is live in: [P1 only | shared | P2 only]"""
+        b1, b2 = self.arena.range[P1]
+        b12, end = self.arena.range[P2]
+        return {P1: (("p1", b1, b12), ("shared", b12, b2)), P2: (("shared", b12, b2), ("p2", b2, end))}[which]
+
+    def _owe(self, which, factor):
+        for name, _, _ in self._segments(which):
+            self._grad_scale[name] = factor
+
     def _average(self, which, live=None):
-        """Apply the factor the gradients of pass `which` still owe (DDP's 1/W).  With both passes live in one backward the
-        two ranges share the middle of the arena: the union is scaled once."""
-        s = self._grad_scale[which]
-        if s == 1.0:
-            return
-        lo, hi = self.arena.range[which]
-        if live == (P1 | P2):
-            lo, hi = self.arena.range[P1][0], self.arena.range[P2][1]
-            self._grad_scale[P1] = self._grad_scale[P2] = 1.0
-        self.arena.g[lo:hi].mul_(s)
-        self._grad_scale[which] = 1.0
+        """Apply the factor the gradients of pass `which` still owe (DDP's 1/W).  The factor is tracked per arena segment, so the
+        parameters both passes share are scaled once however the calls for the two passes are ordered."""
+        for w in ((P1, P2) if live == (P1 | P2) else (which,)):
+            for name, lo, hi in self._segments(w):
+                s = self._grad_scale[name]
+                if s != 1.0 and hi > lo:
+                    self.arena.g[lo:hi].mul_(s)
+                self._grad_scale[name] = 1.0
 
     # ---- engines ---------------------------------------------------------------------------------------------
     def _require_gpu(self):
@@ -404,7 +413,7 @@ class CAVMAE_BASE(nn.Module):
         if not already_reduced:
             r = self._make_reducer(*self.arena.range[which], overlap=False)
             r.finish()
-            self._grad_scale[which] = 1.0 / self._world
+            self._owe(which, 1.0 / self._world)
             self._reduced[which] = True
         if average:
             self._average(which)
@@ -420,9 +429,14 @@ class CAVMAE_BASE(nn.Module):
             st = {"m": torch.zeros(hi - lo, device=a.p.device), "v": torch.zeros(hi - lo, device=a.p.device), "step": 0}
             self._opt_state[which] = st
         st["step"] += 1
+        owed = {self._grad_scale[name] for name, slo, shi in self._segments(which) if shi > slo}
+        if len(owed) > 1:                          # the pass's two segments owe different factors (mixed use): settle them first
+            self._average(which)
+            owed = {1.0}
         ops.adam(a.p[lo:hi], a.g[lo:hi], st["m"], st["v"], a.pb[lo:hi], hi - lo, lr, st["step"], beta1, beta2, eps,
-                 weight_decay, self._grad_scale[which])
-        self._grad_scale[which] = 1.0
+                 weight_decay, owed.pop() if owed else 1.0)
+        for name, _, _ in self._segments(which):
+            self._grad_scale[name] = 1.0
         a.refresh_shadows(which, cast=False)
 
     # ---- optimizer state in torch.optim.Adam's format (best_optim_state.pth, traintest_cavmae_base.py:230) -----------

@@ -350,6 +350,8 @@ class InputXf(ctypes.Structure):
     def audio(cls, mean, std, shift=None, amp=None, seed=0):
         """un-normalised fp32 fbank: (x - mean) / std [+ amp_b * U, rolled by shift_b] (dataloader.py:505-513)"""
         x = cls(1, (ctypes.c_float * 3)(float(mean), 0, 0), (ctypes.c_float * 3)(float(std), 1, 1), None, None, int(seed) & 0xFFFFFFFFFFFFFFFF)
+        if (shift is None) != (amp is None):
+            raise _lib.AvsiamHipError("InputXf.audio: shift and amp go together (the loader's noise augmentation draws both per sample)")
         if shift is not None:
             _chk(shift, I32, "xf.shift"); _chk(amp, F32, "xf.amp")
             x.shift, x.amp = shift.data_ptr(), amp.data_ptr()
@@ -470,16 +472,19 @@ def unshuffle_bwd(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a
     _lib.call("avs_unshuffle_bwd", dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, _stream())
 
 
-def segment_mean_fwd(y, seg_start, reps, nseg):
-    _chk(y, F32, "segmean.y", 2); _chk(seg_start, I32, "segmean.seg"); _chk(reps, F32, "segmean.reps", 2)
-    assert seg_start.numel() >= nseg + 1 and reps.shape[0] >= nseg and reps.shape[1] == y.shape[1]
-    _lib.call("avs_segment_mean_fwd", y, seg_start, reps, nseg, y.shape[1], _stream())
+def segment_mean_fwd(y, seg_start, reps, nseg, row_map=None, max_row=None):
+    """row_map (int32 [nseg], values < max_row <= reps rows; validated by the caller who built it): segment s -> reps[row_map[s]]"""
+    _chk(y, F32, "segmean.y", 2); _chk(seg_start, I32, "segmean.seg"); _chk(reps, F32, "segmean.reps", 2); _chk(row_map, I32, "segmean.map")
+    assert seg_start.numel() >= nseg + 1 and reps.shape[0] >= (nseg if row_map is None else max_row) and reps.shape[1] == y.shape[1]
+    assert row_map is None or (row_map.numel() >= nseg and max_row is not None)
+    _lib.call("avs_segment_mean_fwd", y, seg_start, reps, nseg, y.shape[1], row_map, _stream())
 
 
-def segment_mean_bwd(dreps, seg_start, dy, nseg, scale=1.0):
-    _chk(dy, F32, "segmeanb.dy", 2); _chk(seg_start, I32, "segmeanb.seg"); _chk(dreps, F32, "segmeanb.dreps", 2)
-    assert seg_start.numel() >= nseg + 1 and dreps.shape[0] >= nseg and dreps.shape[1] == dy.shape[1]
-    _lib.call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], float(scale), _stream())
+def segment_mean_bwd(dreps, seg_start, dy, nseg, scale=1.0, row_map=None, max_row=None):
+    _chk(dy, F32, "segmeanb.dy", 2); _chk(seg_start, I32, "segmeanb.seg"); _chk(dreps, F32, "segmeanb.dreps", 2); _chk(row_map, I32, "segmeanb.map")
+    assert seg_start.numel() >= nseg + 1 and dreps.shape[0] >= (nseg if row_map is None else max_row) and dreps.shape[1] == dy.shape[1]
+    assert row_map is None or (row_map.numel() >= nseg and max_row is not None)
+    _lib.call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], float(scale), row_map, _stream())
 
 
 def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, total_init=True, xf=None, stride=16):

@@ -82,7 +82,8 @@ def make_input_xf(args, device):
     import numpy as np
     import torch
     from .ops import InputXf
-    rng = np.random.default_rng(87 + getattr(args, "local_rank", 0))
+    rank = getattr(args, "rank", getattr(args, "local_rank", 0)) or 0
+    rng = np.random.default_rng(87 + rank)
     count = [0]
     frames = InputXf.frames()
 
@@ -91,7 +92,8 @@ def make_input_xf(args, device):
         if bool(args.noise) and train:
             amp = torch.from_numpy((rng.random(batch) / 10).astype(np.float32)).to(device)
             shift = torch.from_numpy(rng.integers(-args.target_length, args.target_length, batch).astype(np.int32)).to(device)
-            return InputXf.audio(args.dataset_mean, args.dataset_std, shift, amp, seed=(87 << 32) | count[0]), frames
+            return InputXf.audio(args.dataset_mean, args.dataset_std, shift, amp, seed=((87 + rank) << 32) | count[0]), frames    # the rank in the Philox key: every
+            # data-parallel rank draws its own noise field (the reference: independent torch.rand per sample and worker)
         return InputXf.audio(args.dataset_mean, args.dataset_std), frames
     return make
 

@@ -186,9 +186,10 @@ int avs_unshuffle_fwd(const float* x, const int* src_row, const int* pos_row, co
 int avs_unshuffle_bwd(const float* dout, const int* src_row, int B, int T, int La, int Lv, float* dx, float* dpos_a,
                       float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D, avs_stream_t stream);
 
-/* ---- token mean per packed sequence (.mean(dim=1), cav_mae_base.py:563,566) */
-int avs_segment_mean_fwd(const float* y, const int* seg_start, float* reps, int nseg, int D, avs_stream_t stream);
-int avs_segment_mean_bwd(const float* dreps, const int* seg_start, float* dy, int nseg, int D, float scale,
+/* ---- token mean per packed sequence (.mean(dim=1), cav_mae_base.py:563,566).  row_map (may be NULL): segment s is row row_map[s]
+ * of reps / dreps - the mixed encoder's inverse permutation (:584-590) folded into the reduction */
+int avs_segment_mean_fwd(const float* y, const int* seg_start, float* reps, int nseg, int D, const int* row_map, avs_stream_t stream);
+int avs_segment_mean_bwd(const float* dreps, const int* seg_start, float* dy, int nseg, int D, float scale, const int* row_map,
                          avs_stream_t stream);
 
 /* ---- masked-MSE with patchify on the fly (patchify + forward_mae_loss, cav_mae_base.py:343-351,663-683) */

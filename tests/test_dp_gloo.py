@@ -124,12 +124,23 @@ def _dp_worker(rank, world, port, q):
         # range and, with average=True, DDP's mean (the fused training step keeps the 1/W for the Adam kernel instead)
         model.allreduce_grads(P1, average=True, already_reduced=False)
         lo, hi = arena.range[P1]
-        assert sum(comm.messages) == hi - lo and model._grad_scale[P1] == 1.0
+        assert sum(comm.messages) == hi - lo and all(f == 1.0 for f in model._grad_scale.values())
         for k, w in want.items():
             got = arena.gview(k)
             assert torch.allclose(got, w, rtol=2e-4, atol=1e-7), (k, float((got - w).abs().max()))
         # parameters outside the pass-1 live range were not touched by the collective
         assert float(g[hi:].abs().max()) == 0.0
+        # One backward over BOTH passes leaves the SUM in the union of the two live ranges and owes DDP's 1/W everywhere; settling
+        # it pass by pass must scale the parameters the passes share ONCE (the factor is tracked per arena segment)
+        from avsiam_amd.param_spec import P2
+        lo1, hi2 = arena.range[P1][0], arena.range[P2][1]
+        g[lo1:hi2] = float(world)
+        model._reduced = {P1: True, P2: True}
+        model._owe(P1, 1.0 / world)
+        model._owe(P2, 1.0 / world)
+        model.allreduce_grads(P1)
+        model.allreduce_grads(P2)
+        assert torch.equal(g[lo1:hi2], torch.ones(hi2 - lo1)), (float(g[lo1:hi2].min()), float(g[lo1:hi2].max()))
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback
