@@ -125,12 +125,12 @@ class ParamArena:
         return self.wt[o:o + n].view(n // s.shape[0], s.shape[0])
 
     # ----- shadows / optimizer -------------------------------------------------------------------
-    def _transpose_table(self, which):
+    def _transpose_table(self, which, span=None):
         """Descriptor table (built once per device placement) for the batched transpose of every [N,K] -> [K,N] copy
-        in the live range of pass `which`."""
-        key = which
+        in the live range of pass `which` (or in the explicit element range `span`)."""
+        key = which if span is None else ("span",) + tuple(span)
         if key not in self._tr_tables:
-            lo, hi = (self.range[P1][0], self.live_end) if which is None else self.range[which]
+            lo, hi = span if span is not None else ((self.range[P1][0], self.live_end) if which is None else self.range[which])
             rows, tmap, t0 = [], [], 0
             for i, name in enumerate(n for n in self.t_offset if lo <= self.offset[n] < hi):
                 src, dst = self.wb(name), self.wtb(name)
@@ -144,14 +144,14 @@ class ParamArena:
             self._tr_tables[key] = (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(tmap, dtype=torch.int32, device=dev), t0)
         return self._tr_tables[key]
 
-    def refresh_shadows(self, which=None, cast=True):
+    def refresh_shadows(self, which=None, cast=True, span=None):
         """fp32 master -> bf16 shadow (+ transposed copies, ONE batched launch) for the live range of pass `which`
-        (None: all)."""
+        (None: all), or for the element range `span` of the arena (whole tensors)."""
         from . import ops
-        lo, hi = (self.range[P1][0], self.live_end) if which is None else self.range[which]
+        lo, hi = span if span is not None else ((self.range[P1][0], self.live_end) if which is None else self.range[which])
         if cast:
             ops.cast_bf16(self.p[lo:hi], self.pb[lo:hi], hi - lo)
-        desc, tmap, ntiles = self._transpose_table(which)
+        desc, tmap, ntiles = self._transpose_table(which, span)
         if ntiles:
             ops.transpose_batched(desc, tmap, ntiles)
 

@@ -154,8 +154,12 @@ class GradReducer:
     is waited for (the local gradients and everything downstream - Adam moments, master weights - stay fp32).
     """
 
-    def __init__(self, comm, g, lo, hi, min_elems=16 << 20, overlap=None, wire=None, staging=None):
+    def __init__(self, comm, g, lo, hi, min_elems=16 << 20, overlap=None, wire=None, staging=None, boundary=None):
+        """boundary: an offset inside (lo, hi) no message may straddle - finish(defer_from=boundary) can then leave the messages
+        above it in flight (the MAE-only parameters, whose all-reduce need not end before the next contrastive pass)."""
         self.comm, self.g, self.lo, self.hi = comm, g, lo, hi
+        self.boundary = boundary if boundary is not None and lo < boundary < hi else None
+        self.deferred = []
         self.min_elems = min_elems
         if overlap is None:
             overlap = os.environ.get("AVSIAM_DP_OVERLAP", "1") != "0"
@@ -173,6 +177,10 @@ class GradReducer:
         self.messages = 0
 
     def _send(self, a, b):
+        if self.boundary is not None and a < self.boundary < b:
+            self._send(a, self.boundary)
+            self._send(self.boundary, b)
+            return
         if self.wire == "bf16":
             st = self.staging[a - self.lo:b - self.lo]
             st.copy_(self.g[a:b])                                    # round to nearest even, on the stream the gradients were written on
@@ -207,17 +215,29 @@ class GradReducer:
             self.sent.append((a, b))
         self.pending = []
 
-    def finish(self):
+    def _wait(self, handles):
+        for h, a, b in handles:
+            h.wait()
+            if self.wire == "bf16":
+                self.g[a:b].copy_(self.staging[a - self.lo:b - self.lo])
+
+    def finish(self, defer_from=None):
+        """Send what was never declared, then wait.  defer_from (= the reducer's boundary): messages at or above it stay in flight;
+        wait_deferred() orders the caller's stream behind them later."""
         if not self.active:
             return
+        assert defer_from is None or defer_from == self.boundary, "defer_from must be the boundary the messages were split at"
         self._flush()
         cur = self.lo
         for a, b in self._merge(self.sent) + [(self.hi, self.hi)]:
             if a > cur:
                 self._send(cur, a)
             cur = max(cur, b)
-        for h, a, b in self.handles:
-            h.wait()
-            if self.wire == "bf16":
-                self.g[a:b].copy_(self.staging[a - self.lo:b - self.lo])
+        now = [x for x in self.handles if defer_from is None or x[1] < defer_from]
+        self.deferred = [x for x in self.handles if not (defer_from is None or x[1] < defer_from)]
+        self._wait(now)
         self.handles, self.sent = [], []
+
+    def wait_deferred(self):
+        self._wait(self.deferred)
+        self.deferred = []

@@ -579,6 +579,161 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused backward for sequences that fit ONE workgroup (L <= R = 32 * NW rows; the encoder's 39 - 128-token sequences): dQ, dK and dV
+// from ONE read of q, k, v, dO, o and ONE evaluation of S and its exponentials - 20 MFMA products per 32 x 32 score tile instead of
+// the 28 of the two-kernel form, half the v_exp, a third of the bytes, one launch.
+//   phase 1 (as attn_bwd_dkv): wave w owns keys 32w.. (the lane), walks the query blocks; S and dP come out of the MFMAs with the
+//     query on the accumulator rows and -lse / -delta as their initial values; dK^T, dV^T accumulate in registers.  The dS tile also
+//     goes into an LDS image [key row][query column] (bf16, the rounding the dQ product applies anyway);
+//   phase 2 (as attn_bwd_dq): wave w owns queries 32w..: dQ^T += K^T . dS^T with BOTH operands read transposed from LDS (K image
+//     written from the key fragments the wave already holds, into the space of the Q image; the dS image written in phase 1).
+// No atomics, no second pass; per (sequence, head) the arithmetic and its order equal the two-kernel form's.
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs a) {
+    constexpr int R = 32 * NW;                            // rows (queries = keys) a workgroup holds
+    constexpr int NKK = HD / 16, NDB = HD / 32;
+    constexpr int IMG = R * HD * 2;                       // bytes of a [R][HD] bf16 image
+    __shared__ __attribute__((aligned(16))) char smem[2 * IMG + R * R * 2 + 2 * R * 4];
+    char* sQ = smem;                                      // phase 2: the K image
+    char* sDO = smem + IMG;
+    char* sDS = smem + 2 * IMG;                           // [key][query] bf16, Img<R>
+    float* sLse = reinterpret_cast<float*>(smem + 2 * IMG + R * R * 2);
+    float* sDel = sLse + R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int head = blockIdx.x / a.ntiles, tix = blockIdx.x - head * a.ntiles;
+    const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int rl = 32 * wave + (lane & 31);               // this lane's row of the images: its key (phase 1) and its query (phase 2)
+    const int row = min(rl, L - 1);
+    const bool active = 32 * wave < L;
+    const bf16_t* qp = a.qkv + (size_t)(seq0 + row) * a.ld + head * HD;
+    const bf16_t* dop = a.dout + (size_t)(seq0 + row) * a.ldo + head * HD;
+    const bf16_t* op = a.out + (size_t)(seq0 + row) * a.ldo + head * HD;
+
+    bf16x8 kf[NKK], vf[NKK];
+    {
+        bf16x8 qv[NKK], dov[NKK], ov[NKK];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int c = (2 * kk + hh) * 8;
+            qv[kk] = *reinterpret_cast<const bf16x8*>(qp + c);
+            kf[kk] = *reinterpret_cast<const bf16x8*>(qp + a.D + c);
+            vf[kk] = *reinterpret_cast<const bf16x8*>(qp + 2 * a.D + c);
+            dov[kk] = *reinterpret_cast<const bf16x8*>(dop + c);
+            ov[kk] = *reinterpret_cast<const bf16x8*>(op + c);
+        }
+        float dpart = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            *reinterpret_cast<bf16x8*>(sQ + Img<HD>::off(rl, 2 * kk + hh)) = qv[kk];
+            *reinterpret_cast<bf16x8*>(sDO + Img<HD>::off(rl, 2 * kk + hh)) = dov[kk];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dpart += bf2f((bf16_t)dov[kk][j]) * bf2f((bf16_t)ov[kk][j]);
+        }
+        const float delta = dpart + __shfl_xor(dpart, 32, 64);
+        if (hh == 0) {
+            sLse[rl] = -a.lse[(size_t)head * a.rows_total + seq0 + row] * 1.4426950408889634f;       // negated: MFMA C operands
+            sDel[rl] = -delta;
+        }
+    }
+    __syncthreads();
+
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+    if (active) {
+        const bool key_tail = 32 * wave + 32 > L;          // wave-uniform: some of this wave's keys lie beyond the sequence
+        const bool key_dead = rl >= L;
+        for (int qb = 0; qb * 32 < L; ++qb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rb = qb * 32 + 8 * t + 4 * hh;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + rb);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + rb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[4 * t + j] = l4[j]; dp[4 * t + j] = d4[j]; }
+            }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, qb * 32, kk, lane), kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sDO, qb * 32, kk, lane), vf[kk], dp, 0, 0, 0);
+            }
+            if (qb * 32 + 32 > L || key_tail) {
+                // real branch (the empty asm blocks if-conversion): only blocks touching the end of the sequence pay for masking
+                asm volatile("; sequence end: mask" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key_dead || qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -INFINITY;      // -> p = exp2(-inf) = 0
+            }
+            float p[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = fast_exp2(s[r]);
+                ds[r] = p[r] * dp[r];
+            }
+            // dS for phase 2: rows 8t + 4hh .. +3 of this query block are 4 consecutive columns of the lane's key row
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = pack_bf2(ds[4 * t + 0], ds[4 * t + 1]);
+                w.y = pack_bf2(ds[4 * t + 2], ds[4 * t + 3]);
+                *reinterpret_cast<uint2*>(sDS + Img<R>::off(rl, qb * 4 + t) + 8 * hh) = w;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const bf16x8 pf = acc_frag(&p[8 * st]);
+                const bf16x8 dsf = acc_frag(&ds[8 * st]);
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) {
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sDO, qb * 32 + 16 * st, d, lane), pf, dv[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, qb * 32 + 16 * st, d, lane), dsf, dk[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();                                       // every dS tile is written, nobody reads the Q image any more
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) *reinterpret_cast<bf16x8*>(sQ + Img<HD>::off(rl, 2 * kk + hh)) = kf[kk];      // K image over the Q image
+    __syncthreads();
+    if (!active) return;
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+    for (int ks = 0; ks * 16 < L; ++ks) {
+        const bf16x8 dsf = tr_frag<R>(sDS, 16 * ks, wave, lane);        // B operand: k = keys 16ks.., n = this wave's queries
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+            dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 16 * ks, d, lane), dsf, dq[d], 0, 0, 0);
+    }
+    if (rl < L) {
+        bf16_t* qrow = a.dqkv + (size_t)(seq0 + rl) * a.ld + head * HD;
+        bf16_t* krow = qrow + a.D;
+        bf16_t* vrow = krow + a.D;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint2 w;
+                w.x = pack_bf2(dq[d][4 * t + 0] * a.scale, dq[d][4 * t + 1] * a.scale);
+                w.y = pack_bf2(dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale);
+                *reinterpret_cast<uint2*>(qrow + d * 32 + 8 * t + 4 * hh) = w;
+                // dK = dS^T . (q * scale) and the staged q is q * scale * log2(e)
+                w.x = pack_bf2(dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2);
+                w.y = pack_bf2(dk[d][4 * t + 2] * LN2, dk[d][4 * t + 3] * LN2);
+                *reinterpret_cast<uint2*>(krow + d * 32 + 8 * t + 4 * hh) = w;
+                w.x = pack_bf2(dv[d][4 * t + 0], dv[d][4 * t + 1]);
+                w.y = pack_bf2(dv[d][4 * t + 2], dv[d][4 * t + 3]);
+                *reinterpret_cast<uint2*>(vrow + d * 32 + 8 * t + 4 * hh) = w;
+            }
+    }
+}
+
 // ===================================================================================================
 static int check_common(const char* name, const void* qkv, long long ld, int D, int H, int hd, const int* ts, const int* tl,
                         const int* tq, int ntiles) {
@@ -650,5 +805,28 @@ extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const
         else attn_bwd_dkv_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
     }
     AVS_LAUNCH_CHECK("attn_bwd_dkv");
+    return 0;
+}
+
+// One workgroup per (sequence, head) for sequences of at most `rows_per_wg` (64 or 128) tokens: seq_start / seq_len [nseq].
+extern "C" int avs_attn_bwd_fused(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
+                                  int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
+                                  bf16_t* dqkv, hipStream_t stream) {
+    AVS_CHECK_ARG(rows_per_wg == 64 || rows_per_wg == 128, "attn_bwd_fused: rows_per_wg must be 64 or 128");
+    const int hd = H > 0 ? D / H : 0;
+    AVS_CHECK_ARG(qkv && seq_start && seq_len && nseq > 0 && H > 0 && (hd == 32 || hd == 64) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0,
+                  "attn_bwd_fused: bad arguments (D=%d H=%d hd=%d ld=%lld nseq=%d)", D, H, hd, ld, nseq);
+    AVS_CHECK_ARG(out && dout && lse && dqkv && (ldo % 8) == 0, "attn_bwd_fused: null pointer");
+    AttnArgs a{qkv, ld, D, seq_start, seq_len, nullptr, nseq, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
+               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr};
+    dim3 grid(nseq * H);
+    if (rows_per_wg == 128) {
+        if (hd == 64) attn_bwd_fused_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
+        else attn_bwd_fused_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
+    } else {
+        if (hd == 64) attn_bwd_fused_kernel<64, 2><<<grid, 128, 0, stream>>>(a);
+        else attn_bwd_fused_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
+    }
+    AVS_LAUNCH_CHECK("attn_bwd_fused");
     return 0;
 }

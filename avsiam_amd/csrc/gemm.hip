@@ -222,19 +222,29 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
         const float q8s = (Q8 && a.out8) ? (a.q8 ? a.q8[AVS_Q_SCALE] : a.out8_scale) : 0.f;
         float q8max = 0.f;
+        // The transposition of row block mi + 1 (4 patch writes + 4 reads back) is put in flight before row block mi is processed
+        // and stored: the LDS round trip - a dependent write -> read -> wait chain per 16 rows that nothing else in this one-workgroup-
+        // per-CU kernel covers - then runs under the previous block's VALU work and store issue.  One patch serves both: block
+        // mi + 1 is written only after the reads of block mi have returned (lgkmcnt(0)), the wave's LDS operations execute in order.
+        f32x4 tqs[2][2][2], bq[2];                                     // [stage][row half][column half]
+        epi_lds_r128<0>(bq[0], baddr); epi_lds_r128<16>(bq[1], baddr);   // the lane's 8 bias values: once per tile
+#define EPI_TRANSPOSE(MI_, ST_)                                                                                     \
+    do {                                                                                                            \
+        epi_lds_w128<0>(waddr, acc[0][MI_]); epi_lds_w128<64>(waddr, acc[1][MI_]);                                  \
+        epi_lds_w128<128>(waddr, acc[2][MI_]); epi_lds_w128<192>(waddr, acc[3][MI_]);                               \
+        epi_lds_r128<0>(tqs[ST_][0][0], raddr); epi_lds_r128<16>(tqs[ST_][0][1], raddr);                            \
+        epi_lds_r128<2176>(tqs[ST_][1][0], raddr); epi_lds_r128<2176 + 16>(tqs[ST_][1][1], raddr);                  \
+    } while (0)
+        EPI_TRANSPOSE(0, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (ACT == 2) epi_load_aux<MI>(a, pf.ax, g, lane, mw0, nw0);
 #pragma unroll
             for (int mj = 0; mj < AG; ++mj) {
                 const int mi = g * AG + mj;
-                epi_lds_w128<0>(waddr, acc[0][mi]); epi_lds_w128<64>(waddr, acc[1][mi]);
-                epi_lds_w128<128>(waddr, acc[2][mi]); epi_lds_w128<192>(waddr, acc[3][mi]);
-                f32x4 tq[2][2], bq[2];
-                epi_lds_r128<0>(tq[0][0], raddr); epi_lds_r128<16>(tq[0][1], raddr);
-                epi_lds_r128<2176>(tq[1][0], raddr); epi_lds_r128<2176 + 16>(tq[1][1], raddr);
-                epi_lds_r128<0>(bq[0], baddr); epi_lds_r128<16>(bq[1], baddr);
-                epi_lds_wait();
+                epi_lds_wait();                                        // block mi is in stage mi & 1
+                if (mi + 1 < MI) EPI_TRANSPOSE(mi + 1 < MI ? mi + 1 : 0, (mi + 1) & 1);
+                f32x4 (&tq)[2][2] = tqs[mi & 1];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int rr = i * 8 + rq;
@@ -283,6 +293,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 }
             }
         }
+#undef EPI_TRANSPOSE
         if (Q8 && a.out8 && a.q8) q_amax_update(a.q8, q8max);
         if (colsum) {
             // lanes with the same (lane & 7) hold the same 8 columns for different rows: fold the 8 row groups, then one

@@ -218,7 +218,19 @@ class Stack:
         if D // H == 80:
             force = 128                                                       # the hd-80 instantiation (ViT-H) exists for 128-row workgroups only
         self.tiles = ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_len < 64 else 128))
-        self.tiles_bwd = self.tiles if inference else ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_len < 256 else 128))
+        # backward: sequences that fit one workgroup (<= 64 / <= 128 tokens: the encoder's video sequences, the MAE towers) take the
+        # fused kernel (one read of q, k, v, o, dO and one S / exp evaluation for dq, dk and dv; ops.attn_bwd_fused), the longer ones the
+        # two-kernel form.  AVSIAM_ATTN_FUSED=0: everything through the two kernels (A/B).
+        self.fused_bwd = []
+        if inference:
+            self.tiles_bwd = self.tiles
+        else:
+            cut = 128 if (os.environ.get("AVSIAM_ATTN_FUSED", "1") != "0" and D // H in (32, 64)) else 0
+            if cut:
+                self.fused_bwd = [sq for sq in (ops.AttnSeqs(seq_lens, dev, 0, 64), ops.AttnSeqs(seq_lens, dev, 64, 128)) if sq.nseq]
+            long_lens = [L for L in seq_lens if L > cut]
+            mean_long = sum(long_lens) / max(1, len(long_lens))
+            self.tiles_bwd = ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_long < 256 else 128), min_len=cut)
         self.q_scale = ops.attn_q_scale(D // H)          # q leaves the qkv GEMM ready for the attention kernels
 
         def per_block(shape, dtype):
@@ -426,7 +438,10 @@ class Stack:
             else:
                 wgrads(i, "dbm", (dbm, self.att[i], "proj"))
                 side.before_write("dqkv")
-            ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
+            if self.tiles_bwd.ntiles:
+                ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
+            for sq in self.fused_bwd:
+                ops.attn_bwd_fused(self.qkv[i], sq, self.H, self.att[i], self.datt, self.lse[i], self.dqkv)
             # qkv
             if excl:
                 side.join()

@@ -105,19 +105,26 @@ class _HotPath(torch.autograd.Function):
         # the flat arena are reduced as soon as the schedule declares them final (comm.GradReducer).  A backward with BOTH
         # passes live accumulates two passes into the shared range, so it is reduced once, at the end.
         red = {}
+        defer = False
         if model._dp and model.reduce_in_backward:
             if live == (P1 | P2):
                 red[0] = model._make_reducer(arena.range[P1][0], arena.range[P2][1], overlap=False)
             else:
-                red[live] = model._make_reducer(*arena.range[live])
+                # AVSIAM_DP_DEFER=1: the MAE pass's all-reduce is split at the end of the shared parameters; the messages of the
+                # MAE-ONLY parameters (audio tower, joint layers, decoder: 126 M of the 212 M) stay in flight after backward and
+                # their Adam update is postponed (adam_step) - both run under the NEXT step's contrastive pass, which reads none of them
+                defer = live == P2 and model.defer_p2 and not model.publish_grads
+                red[live] = model._make_reducer(*arena.range[live], boundary=arena.range[P1][1] if defer else None)
         both = live == (P1 | P2)                   # the second pass adds to gradients the first has written (shared blocks)
         if live & P2:
             model._engine("mae", B).backward(g_mae.reshape(1).float().contiguous(), reducer=red.get(P2), accumulate=both)
         if live & P1:
             model._engine("contrastive", B).backward(g_c.reshape(1).float().contiguous(), ctx.contrast_w, reducer=red.get(P1), accumulate=both)
         for r in red.values():
-            r.finish()
+            r.finish(defer_from=r.boundary if defer else None)
             model.last_reduce_messages = r.messages
+            if defer and r.boundary is not None:
+                model._deferred = {"reducer": r}
         if red:
             for w in (P1, P2):
                 if live & w:
@@ -160,6 +167,8 @@ class CAVMAE_BASE(nn.Module):
         self._world, self._rank = 1, 0
         self._comm, self._dp = None, False
         self.reduce_in_backward = True             # data parallel: loss.backward() all-reduces, like DDP (False: call allreduce_grads)
+        self.defer_p2 = __import__("os").environ.get("AVSIAM_DP_DEFER", "0") == "1"      # see _HotPath.backward
+        self._deferred = None                      # {"reducer": in-flight all-reduce of the MAE-only gradients, "adam": its postponed update}
         self._reduced = {P1: False, P2: False}     # this pass's gradients in the arena are already summed over the ranks
         # factor the arena's gradients still owe (1/W after a SUM all-reduce), per SEGMENT of the arena: the live ranges of the two
         # passes overlap in the shared parameters, and a factor applied per pass would hit that middle segment twice
@@ -187,6 +196,7 @@ class CAVMAE_BASE(nn.Module):
         return self
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
+        self.flush_deferred()
         out = super().load_state_dict(state_dict, strict=strict)
         self._shadow_dirty = True
         return out
@@ -212,9 +222,10 @@ class CAVMAE_BASE(nn.Module):
         self._dp = getattr(self._comm, "active", world > 1)        # collectives on the path (always at world > 1)
         self._engines.clear()
 
-    def _make_reducer(self, lo, hi, overlap=None):
+    def _make_reducer(self, lo, hi, overlap=None, boundary=None):
         from ..comm import GradReducer
-        r = GradReducer(self._comm, self.arena.ensure_grads(), lo, hi, overlap=overlap, staging=getattr(self, "_wire_staging", None))
+        r = GradReducer(self._comm, self.arena.ensure_grads(), lo, hi, overlap=overlap, staging=getattr(self, "_wire_staging", None),
+                        boundary=boundary)
         self._wire_staging = r.staging               # the bf16 wire buffer (AVSIAM_DP_WIRE=bf16) is kept across steps
         return r
 
@@ -375,6 +386,8 @@ class CAVMAE_BASE(nn.Module):
         else:
             imgs = imgs.to(self.arena.p.device, torch.float32).contiguous()
         do_m, do_c = mae_loss_weight != 0, contrast_loss_weight != 0
+        if do_m:
+            self.flush_deferred()                            # the MAE pass reads the parameters a deferred update still owes
         plan_m = plan_c = None
         if isinstance(mask_plan, dict):
             plan_m, plan_c = mask_plan.get("mae"), mask_plan.get("contrastive")
@@ -420,7 +433,9 @@ class CAVMAE_BASE(nn.Module):
 
     def adam_step(self, which, lr, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=5e-7):
         """torch.optim.Adam(lr, weight_decay=5e-7, betas=(0.95, 0.999)) of the reference loop (:64-66) on the pass's
-        live range; each pass has its own moments and step count, like the reference's two optimizers."""
+        live range; each pass has its own moments and step count, like the reference's two optimizers.
+        With a deferred all-reduce pending (AVSIAM_DP_DEFER) the MAE pass's update covers the shared parameters now and the
+        MAE-only parameters in flush_deferred(), with the same step count and hyper-parameters - element for element the same update."""
         from .. import ops
         a = self.arena
         lo, hi = a.range[which]
@@ -428,21 +443,54 @@ class CAVMAE_BASE(nn.Module):
         if st is None:
             st = {"m": torch.zeros(hi - lo, device=a.p.device), "v": torch.zeros(hi - lo, device=a.p.device), "step": 0}
             self._opt_state[which] = st
+        if which == P2 and self._deferred is not None and "adam" in self._deferred:
+            self.flush_deferred()                                      # a second update before the first was applied: settle it
         st["step"] += 1
         owed = {self._grad_scale[name] for name, slo, shi in self._segments(which) if shi > slo}
         if len(owed) > 1:                          # the pass's two segments owe different factors (mixed use): settle them first
             self._average(which)
             owed = {1.0}
-        ops.adam(a.p[lo:hi], a.g[lo:hi], st["m"], st["v"], a.pb[lo:hi], hi - lo, lr, st["step"], beta1, beta2, eps,
-                 weight_decay, owed.pop() if owed else 1.0)
+        scale = owed.pop() if owed else 1.0
+        end = hi
+        if which == P2 and self._deferred is not None:
+            end = a.range[P1][1]                                       # the shared parameters now; [end, hi) when the all-reduce has landed
+            self._deferred["adam"] = (end, hi, lr, st["step"], beta1, beta2, eps, weight_decay, scale)
+        if end > lo:
+            ops.adam(a.p[lo:end], a.g[lo:end], st["m"][:end - lo], st["v"][:end - lo], a.pb[lo:end], end - lo, lr, st["step"], beta1, beta2, eps,
+                     weight_decay, scale)
         for name, _, _ in self._segments(which):
             self._grad_scale[name] = 1.0
-        a.refresh_shadows(which, cast=False)
+        if end == hi:
+            a.refresh_shadows(which, cast=False)
+        elif end > lo:
+            a.refresh_shadows(which, cast=False, span=(lo, end))
+
+    def flush_deferred(self):
+        """Complete a deferred MAE-only update (AVSIAM_DP_DEFER): order the stream behind the all-reduce messages still in flight,
+        then apply the postponed Adam update and refresh the weight shadows.  Called before anything reads those parameters or
+        overwrites their gradients: the next MAE forward, state_dict(), the optimizer state, another update."""
+        d, self._deferred = self._deferred, None
+        if d is None:
+            return
+        from .. import ops
+        d["reducer"].wait_deferred()
+        if "adam" in d:
+            a = self.arena
+            lo = a.range[P2][0]
+            b, hi, lr, step, beta1, beta2, eps, wd, scale = d["adam"]
+            st = self._opt_state[P2]
+            ops.adam(a.p[b:hi], a.g[b:hi], st["m"][b - lo:hi - lo], st["v"][b - lo:hi - lo], a.pb[b:hi], hi - b, lr, step, beta1, beta2, eps, wd, scale)
+            a.refresh_shadows(P2, cast=False, span=(b, hi))
+
+    def state_dict(self, *args, **kwargs):
+        self.flush_deferred()
+        return super().state_dict(*args, **kwargs)
 
     # ---- optimizer state in torch.optim.Adam's format (best_optim_state.pth, traintest_cavmae_base.py:230) -----------
     def optimizer_state_dict(self, which, lr, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=5e-7):
         """State of the pass's Adam as ``torch.optim.Adam(trainables, ...).state_dict()`` would hold it: parameters indexed in
         ``parameters()`` order; parameters the pass never touched (grad None) have no state, as in torch."""
+        self.flush_deferred()
         a = self.arena
         lo, hi = a.range[which]
         st = self._opt_state.get(which)

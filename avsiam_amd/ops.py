@@ -289,24 +289,28 @@ def gemm_tn(A, B, C, M, splits=0):
 class AttnTiles:
     """(sequence start, length, q0) per tile of `tile_rows` (128 or 64) rows for a packed batch of sequences."""
 
-    def __init__(self, seq_lens, device, start_row=0, tile_rows=None):
+    def __init__(self, seq_lens, device, start_row=0, tile_rows=None, min_len=0):
+        """min_len: only sequences LONGER than this get tiles (the shorter ones go to attn_bwd_fused); rows are still counted"""
         starts, lens, q0s = [], [], []
         row = start_row
         if tile_rows is None:      # 128-row (4-wave) workgroups measured faster than 64-row ones at every length (tools/bench_attn.py)
             tile_rows = 128
         assert tile_rows in (64, 128)
         self.tile_rows = tile_rows
+        taken = []
         for L in seq_lens:
-            for q0 in range(0, L, tile_rows):
-                starts.append(row); lens.append(L); q0s.append(q0)
+            if L > min_len:
+                taken.append(L)
+                for q0 in range(0, L, tile_rows):
+                    starts.append(row); lens.append(L); q0s.append(q0)
             row += L
-        self.rows = row - start_row
+        self.rows = float(sum(taken))
         self.ntiles = len(starts)
         self.start = torch.tensor(starts, dtype=I32, device=device)
         self.len = torch.tensor(lens, dtype=I32, device=device)
         self.q0 = torch.tensor(q0s, dtype=I32, device=device)
         self.max_row = row
-        self.sum_sq = float(sum(L * L for L in seq_lens))        # sum of L^2: attention FLOPs = 4 * sum_sq * D
+        self.sum_sq = float(sum(L * L for L in taken))           # sum of L^2: attention FLOPs = 4 * sum_sq * D
 
 
 def attn_q_scale(hd):
@@ -338,6 +342,36 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
     # reads q, k, v, o, dO and writes dq (+ delta); dK/dV reads q, k, v, dO and writes dk, dv
     _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
             out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
+
+
+class AttnSeqs:
+    """(start row, length) of the sequences of a packed batch that the fused backward takes: min_len < L <= max_len"""
+
+    def __init__(self, seq_lens, device, min_len, max_len):
+        starts, lens, row = [], [], 0
+        for L in seq_lens:
+            if min_len < L <= max_len:
+                starts.append(row); lens.append(L)
+            row += L
+        self.nseq, self.max_len, self.max_row = len(starts), max_len, row
+        self.start = torch.tensor(starts, dtype=I32, device=device)
+        self.len = torch.tensor(lens, dtype=I32, device=device)
+        self.rows = float(sum(lens))
+        self.sum_sq = float(sum(L * L for L in lens))
+
+
+def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv):
+    """dq, dk, dv of the sequences in `seqs` (each at most seqs.max_len = 64 | 128 tokens) in one kernel: one read of q, k, v, o, dO and
+    one evaluation of S per (sequence, head).  Rows of other sequences are not touched."""
+    _chk(qkv, BF16, "attnf.qkv", 2); _chk(out, BF16, "attnf.out", 2); _chk(dout, BF16, "attnf.dout", 2)
+    _chk(lse, F32, "attnf.lse", 2); _chk(dqkv, BF16, "attnf.dqkv", 2)
+    D = qkv.shape[1] // 3
+    assert seqs.nseq > 0 and seqs.max_len in (64, 128) and D // H in (32, 64) and D % H == 0
+    assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape
+    assert qkv.shape[0] >= seqs.max_row and out.shape[0] >= seqs.max_row and lse.shape[0] == H and lse.shape[1] >= seqs.max_row
+    # algorithmic work: 8 * sum L^2 * D FLOP; q, k, v, o, dO read and dq, dk, dv written once (bf16), lse read
+    _launch("attn_bwd_hd%d" % (D // H), (8.0 * seqs.sum_sq * D, seqs.rows * (16.0 * D + 4.0 * H)), "avs_attn_bwd_fused", qkv, qkv.stride(0), D, H, seqs.start,
+            seqs.len, seqs.nseq, seqs.max_len, out, dout, out.stride(0), lse, lse.shape[1], dqkv, _stream())
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -219,6 +219,11 @@ def main():
                     help="HIP-event timing of every kernel family (default: the dominant kernel, gemm_nt, only - each timed "
                          "launch costs the stream ~5 us)")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: whatever libraries print on the way (RCCL's version banner when a process group
+    # forms, ...) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     from avsiam_amd import _lib, ops
     from avsiam_amd.config import AVSiamConfig
@@ -400,7 +405,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:                                       # the baseline is a report, never a gate
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or args.force_dp:
         dist.barrier()
         if comm is not None and hasattr(comm, "close"):

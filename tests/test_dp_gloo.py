@@ -198,6 +198,21 @@ def _reducer_worker(rank, world, port, q):
         err = (g3[lo:hi] - exact[lo:hi]).abs().max().item()
         assert err <= 2.0 ** -7 * world * exact[lo:hi].abs().max().item(), err             # bf16 rounding of inputs and of the partial sums
         assert torch.dot(g3[lo:hi], exact[lo:hi]) / (g3[lo:hi].norm() * exact[lo:hi].norm()) > 0.99999
+        # deferral (AVSIAM_DP_DEFER): no message straddles the boundary; finish(defer_from=boundary) waits for the messages below it
+        # and leaves the ones above pending until wait_deferred(); the result equals one all-reduce of the range
+        g4 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        bnd = 4500
+        dfr = GradReducer(comm, g4, lo, hi, min_elems=1500, overlap=True, boundary=bnd)
+        for a, b in ((8000, 8500), (7000, 8000), (4000, 5000), (3000, 4000)):          # (4000, 5000) straddles: sent as two messages
+            dfr.ready(a, b)
+        dfr.finish(defer_from=bnd)
+        assert dfr.deferred and all(a >= bnd for _, a, _ in dfr.deferred) and not dfr.handles
+        below = sum(1 for _, a, _ in dfr.deferred)
+        assert 1 <= below < dfr.messages
+        dfr.wait_deferred()
+        assert not dfr.deferred and torch.equal(g4, want), float((g4 - want).abs().max())
+        with pytest.raises(AssertionError):
+            GradReducer(comm, g4.clone(), lo, hi, boundary=bnd).finish(defer_from=bnd + 1)
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback

@@ -86,3 +86,66 @@ def test_two_ranks_on_one_gpu_match_reference_w2_golden():
         p.join(timeout=120)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _defer_worker(rank, world, port, q):
+    """AVSIAM_DP_DEFER: the MAE-only parameters' all-reduce stays in flight after backward and their Adam update is applied before
+    the next MAE forward - N training steps must leave the same weights as the undeferred schedule (the same per-element updates;
+    run-to-run only the order of the weight-gradient atomics differs), and both ranks must hold bit-identical weights."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from avsiam_amd.models import CAVMAE_BASE
+        from avsiam_amd.param_spec import P1, P2
+        from avsiam_amd.traintest_cavmae_base import train_step
+        from tests.helpers import HostStagedComm
+        cfg = AVSiamConfig(audio_tokens=128)
+        B = 3
+        a, v = synth_inputs(cfg, B, 50 + rank)
+        a, v = a.cuda(), v.cuda()
+        finals = []
+        for defer in (False, True):
+            m = CAVMAE_BASE(cfg=cfg, init_seed=3, init_mode="random", verbose=False, plan_seed=77 + rank).cuda()
+            m.publish_grads = False
+            m.defer_p2 = defer
+            comm = HostStagedComm()
+            m.set_distributed(world, rank, comm)
+            for step in range(3):
+                train_step(m, a, v, 1e-3)
+                if defer:
+                    assert m._deferred is not None and "adam" in m._deferred          # the MAE-only update is pending between steps
+            lo, b = m.arena.range[P2][0], m.arena.range[P1][1]
+            sd = m.state_dict()                                                        # flushes the pending update
+            assert m._deferred is None
+            if defer:
+                assert any(n > 0 for n in comm.messages) and m.last_reduce_messages >= 2
+            w = m.arena.p[:m.arena.live_end].detach().cpu().clone()
+            other = [torch.empty_like(w) for _ in range(world)]
+            dist.all_gather(other, w)
+            assert torch.equal(other[0], other[1]), "ranks diverged"
+            finals.append(w)
+            assert len(sd) == 963
+            del m
+        d = (finals[0].double() - finals[1].double())
+        rel = float(d.norm() / finals[0].double().norm())
+        assert rel < 1e-5, rel
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_deferred_mae_only_update_leaves_the_same_weights():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_defer_worker, args=(r, 2, 29765, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

@@ -295,6 +295,60 @@ def test_attention_fwd_bwd(H, hd, lens, tile_rows):
     assert dqkv[rows:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("H,hd", [(12, 64), (4, 32)])
+def test_attention_bwd_fused_matches_two_kernel_form(H, hd):
+    """avs_attn_bwd_fused (sequences of at most 64 / 128 tokens: dq, dk, dv from one read and one S / exp evaluation per (sequence,
+    head)) against the fp64 reference AND against the two-kernel backward on the same inputs - the same products in the same order, so
+    the two agree to the last bf16 digit or two; rows of the longer sequences are left alone."""
+    o = ops()
+    D = H * hd
+    lens = [39, 200, 49, 64, 65, 1, 128, 300, 33, 100, 117, 78, 127, 2]
+    rows = sum(lens)
+    rp = o.pad_rows(rows)
+    qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(rows, 3 * D, device=DEV)
+    x[:, :D] *= o.attn_q_scale(hd)
+    qkv[:rows] = bf(x)
+    tiles = o.AttnTiles(lens, DEV, tile_rows=64)
+    out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(H, rp, device=DEV)
+    o.attn_fwd(qkv, tiles, H, out, lse)
+    dout = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    dout[:rows] = bf(torch.randn(rows, D, device=DEV))
+    want = torch.zeros_like(qkv)
+    delta = torch.zeros_like(lse)
+    o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, want)
+    got = torch.full_like(qkv, 7.0)
+    for lo, hi in ((0, 64), (64, 128)):
+        sq = o.AttnSeqs(lens, DEV, lo, hi)
+        assert sq.nseq == sum(1 for L in lens if lo < L <= hi)
+        o.attn_bwd_fused(qkv, sq, H, out, dout, lse, got)
+    r0 = 0
+    for L in lens:
+        blk = slice(r0, r0 + L)
+        if L <= 128:
+            for i, name in enumerate("qkv"):
+                e = rel_err(got[blk, i * D:(i + 1) * D], want[blk, i * D:(i + 1) * D])
+                assert e < 2e-3, (L, name, e)
+        else:
+            assert float((got[blk].float() - 7.0).abs().max()) == 0.0, L          # not this kernel's rows
+        r0 += L
+    assert float((got[rows:].float() - 7.0).abs().max()) == 0.0
+    # and against the fp64 formula, like test_attention_fwd_bwd
+    qr = qkv[:rows].double()
+    qr[:, :D] /= o.attn_q_scale(hd)
+    qr.requires_grad_(True)
+    ref = _attn_ref(qr, lens, H)
+    (ref * dout[:rows].double()).sum().backward()
+    r0 = 0
+    for L in lens:
+        if L <= 128:
+            for i, name in enumerate("qkv"):
+                e = rel_err(got[r0:r0 + L, i * D:(i + 1) * D], qr.grad[r0:r0 + L, i * D:(i + 1) * D])
+                assert e < 1.5e-2, (L, name, e)
+        r0 += L
+
+
 @pytest.mark.parametrize("H,hd,L,spike", [(2, 64, 200, 8.0), (2, 64, 200, 2.5), (4, 32, 300, 40.0), (4, 32, 300, 4.0)])
 def test_attention_spiked_scores(H, hd, L, spike):
     """Large score spread: the forward keeps the first key tile's row max as its reference and moves it only when a later

@@ -39,6 +39,19 @@ def run_case(name, H, hd, lens, dev, tile_rows=(128, 64)):
         tb = timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv), 10)
         msg += (f"  [tile {tr}] fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF/s {rows*8.0*D/tf/1e9:6.0f} GB/s"
                 f"  bwd {tb*1e6:7.1f} us {2.5*fl/tb/1e12:6.1f} TF/s {rows*24.0*D/tb/1e9:6.0f} GB/s")
+    if hd in (32, 64) and min(lens) <= 128:
+        # the backward as the engine runs it: sequences of at most 128 tokens through the fused kernel, the rest through the two kernels
+        f = [sq for sq in (ops.AttnSeqs(lens, dev, 0, 64), ops.AttnSeqs(lens, dev, 64, 128)) if sq.nseq]
+        long_lens = [L for L in lens if L > 128]
+        tl = ops.AttnTiles(lens, dev, tile_rows=64 if sum(long_lens) / max(1, len(long_lens)) < 256 else 128, min_len=128)
+
+        def mixed():
+            if tl.ntiles:
+                ops.attn_bwd(qkv, tl, H, out, dout, lse, delta, dqkv)
+            for sq in f:
+                ops.attn_bwd_fused(qkv, sq, H, out, dout, lse, dqkv)
+        tm = timeit(mixed, 10)
+        msg += f"  [fused<=128] bwd {tm*1e6:7.1f} us"
     print(msg, flush=True)
 
 
