@@ -222,29 +222,19 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
         const float q8s = (Q8 && a.out8) ? (a.q8 ? a.q8[AVS_Q_SCALE] : a.out8_scale) : 0.f;
         float q8max = 0.f;
-        // The transposition of row block mi + 1 (4 patch writes + 4 reads back) is put in flight before row block mi is processed
-        // and stored: the LDS round trip - a dependent write -> read -> wait chain per 16 rows that nothing else in this one-workgroup-
-        // per-CU kernel covers - then runs under the previous block's VALU work and store issue.  One patch serves both: block
-        // mi + 1 is written only after the reads of block mi have returned (lgkmcnt(0)), the wave's LDS operations execute in order.
-        f32x4 tqs[2][2][2], bq[2];                                     // [stage][row half][column half]
-        epi_lds_r128<0>(bq[0], baddr); epi_lds_r128<16>(bq[1], baddr);   // the lane's 8 bias values: once per tile
-#define EPI_TRANSPOSE(MI_, ST_)                                                                                     \
-    do {                                                                                                            \
-        epi_lds_w128<0>(waddr, acc[0][MI_]); epi_lds_w128<64>(waddr, acc[1][MI_]);                                  \
-        epi_lds_w128<128>(waddr, acc[2][MI_]); epi_lds_w128<192>(waddr, acc[3][MI_]);                               \
-        epi_lds_r128<0>(tqs[ST_][0][0], raddr); epi_lds_r128<16>(tqs[ST_][0][1], raddr);                            \
-        epi_lds_r128<2176>(tqs[ST_][1][0], raddr); epi_lds_r128<2176 + 16>(tqs[ST_][1][1], raddr);                  \
-    } while (0)
-        EPI_TRANSPOSE(0, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (ACT == 2) epi_load_aux<MI>(a, pf.ax, g, lane, mw0, nw0);
 #pragma unroll
             for (int mj = 0; mj < AG; ++mj) {
                 const int mi = g * AG + mj;
-                epi_lds_wait();                                        // block mi is in stage mi & 1
-                if (mi + 1 < MI) EPI_TRANSPOSE(mi + 1 < MI ? mi + 1 : 0, (mi + 1) & 1);
-                f32x4 (&tq)[2][2] = tqs[mi & 1];
+                epi_lds_w128<0>(waddr, acc[0][mi]); epi_lds_w128<64>(waddr, acc[1][mi]);
+                epi_lds_w128<128>(waddr, acc[2][mi]); epi_lds_w128<192>(waddr, acc[3][mi]);
+                f32x4 tq[2][2], bq[2];
+                epi_lds_r128<0>(tq[0][0], raddr); epi_lds_r128<16>(tq[0][1], raddr);
+                epi_lds_r128<2176>(tq[1][0], raddr); epi_lds_r128<2176 + 16>(tq[1][1], raddr);
+                epi_lds_r128<0>(bq[0], baddr); epi_lds_r128<16>(bq[1], baddr);
+                epi_lds_wait();
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int rr = i * 8 + rq;
@@ -293,7 +283,6 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 }
             }
         }
-#undef EPI_TRANSPOSE
         if (Q8 && a.out8 && a.q8) q_amax_update(a.q8, q8max);
         if (colsum) {
             // lanes with the same (lane & 7) hold the same 8 columns for different rows: fold the 8 row groups, then one
@@ -714,6 +703,22 @@ struct GemmTnArgs {
     int stages_per_split;
 };
 
+// Up to three weight gradients over the SAME token rows in one launch of the 8-phase kernel (avs_gemm_tn_bf16_group3: a block's fc2,
+// fc1 and proj gradients, whose operands all exist when the attention backward starts).  Every workgroup adds one 256 x 256 fp32 tile
+// with atomics, so a launch costs (workgroups x 256 KiB) of atomic traffic whatever its shape - 64 MB when a single 9 - 36-tile
+// gradient is split 7 - 28 ways to fill the chip.  Together the three have 81 tiles (ViT-B), need 3 splits instead of 7 + 7 + 14, and the
+// atomic bytes of the three fall from ~158 MB to ~62 MB.  Tiles [tile0[i], tile0[i + 1]) of the launch belong to problem i.
+struct TnProb {
+    const bf16_t* A; long long lda;
+    const bf16_t* B; long long ldb;
+    float* C; long long ldc;
+    int N1, N2, tile0;
+};
+struct GemmTnGroupArgs {
+    TnProb p[3];
+    int nprob, tiles, M, stages_per_split;
+};
+
 // The transposing reads are issued through inline asm: hipcc (ROCm 7.2) cannot disambiguate the ds_read_tr builtin from
 // the LDS-DMA loads still in flight for the NEXT slab and puts an s_waitcnt vmcnt(0) in front of the first read of every
 // stage - which serialises load and compute completely (measured: matrix pipe 21 % busy).  An asm statement is opaque to
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(128 * NWC) void gemm_tn_kernel(GemmTnArgs a) {
 // the rows of the stage two ahead: granules are issued in reading order, six phases before they are read, and the wait
 // in front of every barrier is the constant vmcnt(10) (five younger granules stay in flight).
 template <int DUMMY>
-__global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTnArgs a) {
+__global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTnGroupArgs g) {
     constexpr int T1 = 256, T2 = 256, MI = 4;
     constexpr int RA = T1 * 2, RB = T2 * 2;                 // LDS row bytes of the staged [64 rows][256] tiles
     constexpr int A_BYTES = 64 * RA, BUF_BYTES = 2 * A_BYTES;
@@ -876,13 +881,19 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int tiles2 = a.N2 / T2, tiles = (a.N1 / T1) * tiles2;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = lid / tiles, tile = lid % tiles;
+    const int split = lid / g.tiles;
+    int tile = lid % g.tiles;
+    // which of the launch's (up to three) gradients this tile belongs to: block-uniform, scalar
+    const int pi = (g.nprob > 2 && tile >= g.p[2].tile0) ? 2 : (g.nprob > 1 && tile >= g.p[1].tile0) ? 1 : 0;
+    struct { const bf16_t* A; long long lda; const bf16_t* B; long long ldb; float* C; long long ldc; int M; } a
+        = {g.p[pi].A, g.p[pi].lda, g.p[pi].B, g.p[pi].ldb, g.p[pi].C, g.p[pi].ldc, g.M};
+    tile -= g.p[pi].tile0;
+    const int tiles2 = g.p[pi].N2 / T2;
     const int n2_0 = (tile % tiles2) * T2, n1_0 = (tile / tiles2) * T1;
     const int nstages = (a.M + BK - 1) / BK;
-    const int s_begin = split * a.stages_per_split;
-    const int nst = min(nstages, s_begin + a.stages_per_split) - s_begin;      // stages of this workgroup
+    const int s_begin = split * g.stages_per_split;
+    const int nst = min(nstages, s_begin + g.stages_per_split) - s_begin;      // stages of this workgroup
     if (nst <= 0) return;
 
     // granule (stage t, quarter q) = token rows s*64 + q*16 .. +15: 16 rows x 32 chunks = one 16-B chunk per thread
@@ -1195,9 +1206,71 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     const int per = ceil_div(nstages, splits);
     splits = ceil_div(nstages, per);
     GemmTnArgs a{A, lda, B, ldb, C, ldc, M, N1, N2, per};
-    if (big && g_nt8 >= 1) gemm_tn8_kernel<0><<<tiles * splits, 512, 131072, stream>>>(a);
+    if (big && g_nt8 >= 1) {
+        GemmTnGroupArgs g{};
+        g.p[0] = TnProb{A, lda, B, ldb, C, ldc, N1, N2, 0};
+        g.nprob = 1; g.tiles = tiles; g.M = M; g.stages_per_split = per;
+        gemm_tn8_kernel<0><<<tiles * splits, 512, 131072, stream>>>(g);
+    }
     else if (big) gemm_tn_kernel<4, 4><<<tiles * splits, 512, 131072, stream>>>(a);
     else gemm_tn_kernel<2, 2><<<tiles * splits, 256, 65536, stream>>>(a);
     AVS_LAUNCH_CHECK("gemm_tn");
+    return 0;
+}
+
+// Up to three weight gradients over the same M token rows in ONE launch (problem i absent when Ai is NULL; problem 0 must exist):
+// Ci[N1i, N2i] += Ai[M, N1i]^T . Bi[M, N2i].  8-phase 256 x 256 kernel only: every N1i, N2i a multiple of 256 and M >= 512.
+// Shapes that do not qualify (or the 8-phase kernels switched off) are issued as one avs_gemm_tn_bf16 launch per problem.
+extern "C" int avs_gemm_tn_bf16_group3(const bf16_t* A0, long long lda0, const bf16_t* B0, long long ldb0, float* C0, int N1_0, int N2_0,
+                                       const bf16_t* A1, long long lda1, const bf16_t* B1, long long ldb1, float* C1, int N1_1, int N2_1,
+                                       const bf16_t* A2, long long lda2, const bf16_t* B2, long long ldb2, float* C2, int N1_2, int N2_2,
+                                       int M, hipStream_t stream) {
+    const bf16_t* As[3] = {A0, A1, A2};
+    const bf16_t* Bs[3] = {B0, B1, B2};
+    float* Cs[3] = {C0, C1, C2};
+    const long long las[3] = {lda0, lda1, lda2}, lbs[3] = {ldb0, ldb1, ldb2};
+    const int n1s[3] = {N1_0, N1_1, N1_2}, n2s[3] = {N2_0, N2_1, N2_2};
+    AVS_CHECK_ARG(A0 && M > 0, "gemm_tn_group3: the first problem must exist");
+    if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
+    if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
+    GemmTnGroupArgs g{};
+    int n = 0, tiles = 0;
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {
+        if (!As[i]) continue;
+        AVS_CHECK_ARG(Bs[i] && Cs[i] && n1s[i] > 0 && n2s[i] > 0 && (las[i] % 8) == 0 && (lbs[i] % 8) == 0, "gemm_tn_group3: bad operands of problem %d", i);
+        if ((n1s[i] % 256) || (n2s[i] % 256)) ok = false;
+        g.p[n] = TnProb{As[i], las[i], Bs[i], lbs[i], Cs[i], (long long)n2s[i], n1s[i], n2s[i], tiles};
+        tiles += (n1s[i] / 256) * (n2s[i] / 256);
+        ++n;
+    }
+    const int nstages = ceil_div(M, BK);
+    if (!ok || g_nt8 < 1 || g_force_tile == 128 || n < 2 || nstages < 8) {
+        for (int i = 0; i < 3; ++i)
+            if (As[i])
+                if (int e = avs_gemm_tn_bf16(As[i], las[i], Bs[i], lbs[i], Cs[i], n2s[i], M, n1s[i], n2s[i], 0, stream)) return e;
+        return 0;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_tn8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) {
+            avs_set_error("gemm_tn_group3: hipFuncSetAttribute failed");
+            return -1;
+        }
+        attr_done = true;
+    }
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    int splits = ncu / tiles;                              // one resident round, rounded DOWN (see avs_gemm_tn_bf16)
+    if (splits < 1) splits = 1;
+    if (splits > nstages / 2) splits = nstages / 2 > 0 ? nstages / 2 : 1;
+    const int per = ceil_div(nstages, splits);
+    splits = ceil_div(nstages, per);
+    g.nprob = n; g.tiles = tiles; g.M = M; g.stages_per_split = per;
+    gemm_tn8_kernel<0><<<tiles * splits, 512, 131072, stream>>>(g);
+    AVS_LAUNCH_CHECK("gemm_tn_group3");
     return 0;
 }

@@ -396,10 +396,9 @@ class Stack:
                             reducer.ready(a, b)
 
         def wgrads(blk, key, *jobs):
-            def fn():
-                for a, b, name in jobs:
-                    for lo, hi, bl in ranges:
-                        ops.gemm_tn(a[lo:], b[lo:], getattr(bl[blk], name).gw, hi - lo)
+            def fn():      # the jobs of one call share their token rows: one grouped launch per row range (ops.gemm_tn_group)
+                for lo, hi, bl in ranges:
+                    ops.gemm_tn_group([(a[lo:], b[lo:], getattr(bl[blk], name).gw) for a, b, name in jobs], hi - lo)
             side.run(key, fn)
 
         for i in reversed(range(self.nblocks)):

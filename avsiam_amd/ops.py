@@ -285,6 +285,25 @@ def gemm_tn(A, B, C, M, splits=0):
     _launch("gemm_tn", 2.0 * M * N1 * N2, "avs_gemm_tn_bf16", A, A.stride(0), B, B.stride(0), C, N2, M, N1, N2, splits, _stream())
 
 
+def gemm_tn_group(jobs, M):
+    """jobs: 1-3 triples (A[M,N1], B[M,N2], C[N1*N2]) over the same M token rows: C += A^T @ B, in ONE launch when the shapes allow
+    (avs_gemm_tn_bf16_group3: fewer splits of the token rows, i.e. less fp32 atomic traffic, than one launch each)."""
+    assert 1 <= len(jobs) <= 3
+    if len(jobs) == 1:
+        return gemm_tn(jobs[0][0], jobs[0][1], jobs[0][2], M)
+    need = pad_rows(M, 64)
+    args, flops = [], 0.0
+    for A, B, C in jobs:
+        _chk(A, BF16, "wgrad.A", 2); _chk(B, BF16, "wgrad.B", 2); _chk(C, F32, "wgrad.C")
+        N1, N2 = A.shape[1], B.shape[1]
+        assert A.shape[0] >= need and B.shape[0] >= need, "wgrad operands must be allocated (zero) to a multiple of 64 rows"
+        assert C.numel() == N1 * N2 and N1 % 128 == 0 and N2 % 128 == 0
+        args += [A, A.stride(0), B, B.stride(0), C, N1, N2]
+        flops += 2.0 * M * N1 * N2
+    args += [None, 0, None, 0, None, 0, 0] * (3 - len(jobs))
+    _launch("gemm_tn", flops, "avs_gemm_tn_bf16_group3", *args, M, _stream())
+
+
 # ---------------------------------------------------------------------------------------------------
 class AttnTiles:
     """(sequence start, length, q0) per tile of `tile_rows` (128 or 64) rows for a packed batch of sequences."""

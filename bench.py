@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0       # dense fp8 MFMA peak, same table (fp8 launches are priced against THIS, never against the bf16 peak)
 PEAK_HBM_GBS = 8000.0          # HBM3E peak, same table (6.3 TB/s is what a float4 copy achieves)
 
 
@@ -343,7 +344,7 @@ def main():
         }
         if prof is not None:
             s = prof.summary()
-            mm = [k for k in s if k.startswith("gemm_nt")]
+            mm = [k for k in s if k.startswith("gemm_nt") and k != "gemm_nt_fp8"]      # the bf16 launches (all of them without --fp8)
             flops = sum(s[k]["work"] for k in mm)
             ms = sum(s[k]["total_ms"] for k in mm)
             n = sum(s[k]["launches"] for k in mm)
@@ -354,6 +355,13 @@ def main():
                                 "pmc": pmc_busy(args), "launches": n, "avg_launch_us": 1e3 * ms / n, "flops_per_launch": flops / n,
                                 "dispatches": nd, "avg_dispatch_us": 1e3 * ms / nd,
                                 "sampling": "all launches" if args.all_kernel_events else "every 5th launch of the timed region"}
+            if "gemm_nt_fp8" in s:              # --fp8: the e4m3 forward GEMMs are a kernel family of their own, against the fp8 peak
+                x = s["gemm_nt_fp8"]
+                a8 = x["rate"] / 1e12
+                line["roofline_fp8"] = {"bound": "mfma", "kernel": "gemm_nt8_kernel<., FP8> (forward GEMMs on e4m3 operands, v_mfma_f32_16x16x128_f8f6f4)",
+                                        "achieved": a8, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": a8 / PEAK_FP8_TFLOPS, "traffic": None,
+                                        "launches": x["launches"], "avg_launch_us": x["avg_us"], "flops_per_launch": x["work"] / x["launches"]}
+                line["roofline"]["kernel"] += " - the bf16 launches of the fp8 mode (backward; forward GEMMs without an fp8 instantiation)"
             line["kernels"] = {k: {"launches": x["launches"], "total_ms": round(x["total_ms"], 3), "avg_us": round(x["avg_us"], 2),
                                    "rate_T_per_s": round(x["rate"] / 1e12, 3)} for k, x in sorted(s.items())}
         if prof2 is not None:

@@ -110,6 +110,14 @@ int avs_gemm_set_nt8(int on);
  * next multiple of 64 rows; N1%128==0, N2%128==0; splits<=0 picks a split of the contraction that fills the chip. */
 int avs_gemm_tn_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, float* C, long long ldc, int M,
                      int N1, int N2, int splits, avs_stream_t stream);
+/* up to three weight gradients over the SAME M token rows in one launch: Ci[N1_i, N2_i] (contiguous) += Ai^T . Bi; problem i is absent
+ * when Ai is NULL (problem 0 must exist).  A block's fc2 / fc1 / proj gradients (timm Mlp + Attention.proj, cav_mae_base.py:77,138-143)
+ * exist at the same time; together they fill the chip with 3 splits of the token rows instead of 7 + 7 + 14, i.e. with 40 % of the fp32
+ * atomic traffic.  When every N is a multiple of 256 the 8-phase 256 x 256 kernel takes all tiles; otherwise one launch per problem. */
+int avs_gemm_tn_bf16_group3(const avs_bf16* A0, long long lda0, const avs_bf16* B0, long long ldb0, float* C0, int N1_0, int N2_0,
+                            const avs_bf16* A1, long long lda1, const avs_bf16* B1, long long ldb1, float* C1, int N1_1, int N2_1,
+                            const avs_bf16* A2, long long lda2, const avs_bf16* B2, long long ldb2, float* C2, int N1_2, int N2_2,
+                            int M, avs_stream_t stream);
 
 /* ---- varlen attention (F.scaled_dot_product_attention in Attention.forward, cav_mae_base.py:60-68) on the packed
  * qkv matrix [rows, 3*D] (q|k|v, head h at columns h*hd); one (tile_start, tile_len, tile_q0) triple per tile of
