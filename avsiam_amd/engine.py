@@ -163,6 +163,7 @@ class _SideStream:
 
 
 WGRAD_STREAM_MODE = os.environ.get("AVSIAM_WGRAD_STREAM", "2")     # read once (A/B runs set it before the import)
+WGRAD_GROUP = os.environ.get("AVSIAM_WGRAD_GROUP", "1") != "0"      # a block's fc2 / fc1 / proj weight gradients in one launch (0: A/B)
 _side_streams = {}
 
 
@@ -398,7 +399,12 @@ class Stack:
         def wgrads(blk, key, *jobs):
             def fn():      # the jobs of one call share their token rows: one grouped launch per row range (ops.gemm_tn_group)
                 for lo, hi, bl in ranges:
-                    ops.gemm_tn_group([(a[lo:], b[lo:], getattr(bl[blk], name).gw) for a, b, name in jobs], hi - lo)
+                    trip = [(a[lo:], b[lo:], getattr(bl[blk], name).gw) for a, b, name in jobs]
+                    if WGRAD_GROUP:
+                        ops.gemm_tn_group(trip, hi - lo)
+                    else:
+                        for A, B, C in trip:
+                            ops.gemm_tn(A, B, C, hi - lo)
             side.run(key, fn)
 
         for i in reversed(range(self.nblocks)):
