@@ -386,6 +386,8 @@ class Stack:
         mode = "0" if self.recompute else WGRAD_STREAM_MODE
         side = _side_stream(dxo.device) if mode in ("1", "2") else _Inline()
         excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
+        grp = excl or mode == "0"     # the block's fc2 / fc1 / proj weight gradients are issued together (one grouped launch); mode 1
+                                      # issues each as early as its operands exist
         g16 = GRAD_STREAM == "bf16"   # the residual gradient travels between the LayerNorm backwards in bf16 only
 
         def block_done(j):
@@ -421,14 +423,14 @@ class Stack:
                 side.before_write("dfc1")
             ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
                         dual=(split, b2.fc2.wt, None, b2.fc1.gb) if b2 is not None else None)
-            if not excl:
+            if not grp:
                 wgrads(i, "dbo", (dbo, self.act[i], "fc2"))
             if i == self.nblocks - 1 and not last_fc2_bias_done:
                 for lo, hi, bl in ranges:
                     ops.colsum(dbo[lo:], bl[i].fc2.gb, hi - lo)
             # fc1
             ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M, dual=(split, b2.fc1.wt, None, None) if b2 is not None else None)
-            if not excl:
+            if not grp:
                 wgrads(i, "dfc1", (self.dfc1, self.ln2[i], "fc1"))
                 side.before_write("dbm")
             for lo, hi, bl in ranges:
@@ -438,7 +440,7 @@ class Stack:
                         None if one else self.row_mod, dres=(dbo if g16 else dxo)[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb)
             # proj
             ops.gemm_nt(dbm, bp.proj.wt, self.datt, M, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
-            if excl:                  # the three wgrads whose operands exist now run beside the attention backward
+            if grp:                   # the three wgrads whose operands exist now run beside the attention backward
                 wgrads(i, "blockA", (dbo, self.act[i], "fc2"), (self.dfc1, self.ln2[i], "fc1"), (dbm, self.att[i], "proj"))
             else:
                 wgrads(i, "dbm", (dbm, self.att[i], "proj"))
