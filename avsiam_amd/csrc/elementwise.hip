@@ -415,7 +415,7 @@ __global__ void absmax_kernel(const void* __restrict__ x, int is_f32, size_t n8,
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));      // non-negative floats order like their bit patterns
 }
 
-__global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint8_t* __restrict__ y, size_t n4, float scale_host, float* q) {
+__global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint8_t* __restrict__ y, size_t n4, float scale_host, float* q, int e5m2) {
     // q (device record, common.h AVS_Q_*; may be NULL): the scale comes from q[0] and the largest |x| seen is folded into q[2]
     const float scale = q ? q[AVS_Q_SCALE] : scale_host;
     float m = 0.f;
@@ -430,10 +430,17 @@ __global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint
             v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
         }
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        const float lim = e5m2 ? 57344.0f : 448.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * scale, -448.0f, 448.0f);
-        int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * scale, -lim, lim);
+        int w;
+        if (e5m2) {
+            w = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w, true);
+        } else {
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+        }
         reinterpret_cast<int*>(y)[i] = w;
     }
     if (q) q_amax_update(q, m);
@@ -442,17 +449,17 @@ __global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint
 // Delayed scaling (engine.FP8): per record s in [0, n): the amax gathered since the last update goes into the history ring
 // hist[pos][s], the scale becomes 448 / (margin * max over the ring), the running amax restarts at 0, and the saturation counter
 // advances when the values just quantised exceeded the range of the scale they were quantised with.  One thread per record.
-__global__ void fp8_scale_update_kernel(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count) {
+__global__ void fp8_scale_update_kernel(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax) {
     const int s = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= first + count) return;
     float* r = q + 4 * (size_t)s;
     const float a = r[AVS_Q_AMAX], sc = r[AVS_Q_SCALE];
-    if (sc > 0.f && a * sc > 448.0f) r[AVS_Q_SAT] += 1.0f;
+    if (sc > 0.f && a * sc > fmax) r[AVS_Q_SAT] += 1.0f;
     hist[(size_t)pos * n + s] = a;
     float m = 0.f;
     for (int h = 0; h < nhist; ++h) m = fmaxf(m, hist[(size_t)h * n + s]);
     if (m > 0.f) {
-        const float ns = 448.0f / (margin * m);
+        const float ns = fmax / (margin * m);
         r[AVS_Q_SCALE] = ns;
         r[AVS_Q_INV] = 1.0f / ns;
     }
@@ -468,19 +475,20 @@ extern "C" int avs_absmax(const void* x, int is_f32, long long n, float* out, hi
     return 0;
 }
 
-extern "C" int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, float* q, hipStream_t stream) {
+extern "C" int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, float* q, int e5m2, hipStream_t stream) {
     AVS_CHECK_ARG(x && y && n > 0 && (n % 4) == 0, "quantize_fp8: n must be a multiple of 4");
     const size_t n4 = (size_t)n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    quantize_fp8_kernel<<<blocks, 256, 0, stream>>>(x, is_f32, y, n4, scale, q);
+    quantize_fp8_kernel<<<blocks, 256, 0, stream>>>(x, is_f32, y, n4, scale, q, e5m2);
     AVS_LAUNCH_CHECK("quantize_fp8");
     return 0;
 }
 
-extern "C" int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, hipStream_t stream) {
+extern "C" int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax, hipStream_t stream) {
+    AVS_CHECK_ARG(fmax == 448.0f || fmax == 57344.0f, "fp8_scale_update: fmax is 448 (e4m3) or 57344 (e5m2)");
     AVS_CHECK_ARG(q && hist && n > 0 && nhist > 0 && pos >= 0 && pos < nhist && margin >= 1.0f && first >= 0 && count > 0 && first + count <= n,
                   "fp8_scale_update: bad args (n=%d nhist=%d pos=%d first=%d count=%d)", n, nhist, pos, first, count);
-    fp8_scale_update_kernel<<<ceil_div(count, 256), 256, 0, stream>>>(q, hist, n, nhist, pos, margin, first, count);
+    fp8_scale_update_kernel<<<ceil_div(count, 256), 256, 0, stream>>>(q, hist, n, nhist, pos, margin, first, count, fmax);
     AVS_LAUNCH_CHECK("fp8_scale_update");
     return 0;
 }

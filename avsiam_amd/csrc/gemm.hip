@@ -170,7 +170,8 @@ __device__ __forceinline__ void nt_epilogue_stage_bias(const GemmNtArgs& a, char
     sbias[lane] = bias ? bias[nw0 + lane] : 0.f;
 }
 
-template <int ACT, int MI, bool Q8 = false>
+// Q8: 0 no fp8 copy | 1 forward fp8 GEMM: ACT 1 also writes out8 = e4m3(gelu(x)) | 2 backward fp8 GEMM: out8 = e5m2(out) (ACT 0 / 2)
+template <int ACT, int MI, int Q8 = 0>
 __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], EpiPrefetch<MI>& pf, char* smem, int wave, int lane,
                                             int mw0, int nw0) {
     const int fr = lane & 15, fq = lane >> 4;
@@ -220,7 +221,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         const unsigned raddr = stg_lds + (rq * 68 + cc) * 4, baddr = sbias_lds + cc * 4;      // rows rq and rq + 8: 2176 B apart
         constexpr int AG = EpiPrefetch<MI>::AG, NG = MI / AG;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
-        const float q8s = (Q8 && a.out8) ? (a.q8 ? a.q8[AVS_Q_SCALE] : a.out8_scale) : 0.f;
+        const float q8s = (Q8 != 0 && a.out8) ? (a.q8 ? a.q8[AVS_Q_SCALE] : a.out8_scale) : 0.f;
         float q8max = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -265,12 +266,21 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                         o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
                     }
                     NT_STORE(reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n), (u32x4{o.x, o.y, o.z, o.w}));
+                    if (Q8 == 2 && ACT != 1 && a.out8) {
+                        // fp8 backward: the e5m2 copy of this output gradient, the operand of the next input-gradient GEMM
+                        auto c8 = [&](float x) { q8max = fmaxf(q8max, fabsf(x)); return __builtin_amdgcn_fmed3f(x * q8s, -57344.f, 57344.f); };
+                        int w0 = __builtin_amdgcn_cvt_pk_bf8_f32(c8(v0[0]), c8(v0[1]), 0, false);
+                        w0 = __builtin_amdgcn_cvt_pk_bf8_f32(c8(v0[2]), c8(v0[3]), w0, true);
+                        int w1 = __builtin_amdgcn_cvt_pk_bf8_f32(c8(v1[0]), c8(v1[1]), 0, false);
+                        w1 = __builtin_amdgcn_cvt_pk_bf8_f32(c8(v1[2]), c8(v1[3]), w1, true);
+                        *reinterpret_cast<uint2*>(a.out8 + (size_t)m * a.ldo8 + n) = make_uint2((unsigned)w0, (unsigned)w1);
+                    }
                     if (ACT == 1) {
                         uint4 gq;
                         gq.x = pack_bf2(gelu_erf(v0[0]), gelu_erf(v0[1])); gq.y = pack_bf2(gelu_erf(v0[2]), gelu_erf(v0[3]));
                         gq.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); gq.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
                         NT_STORE(reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n), (u32x4{gq.x, gq.y, gq.z, gq.w}));
-                        if (Q8 && a.out8) {
+                        if (Q8 == 1 && a.out8) {
                             const float q = q8s;
                             auto q8 = [&](float x) { const float gx = gelu_erf(x); q8max = fmaxf(q8max, fabsf(gx)); return __builtin_amdgcn_fmed3f(gx * q, -448.f, 448.f); };
                             int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q8(v0[0]), q8(v0[1]), 0, false);
@@ -283,7 +293,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 }
             }
         }
-        if (Q8 && a.out8 && a.q8) q_amax_update(a.q8, q8max);
+        if (Q8 != 0 && a.out8 && a.q8) q_amax_update(a.q8, q8max);
         if (colsum) {
             // lanes with the same (lane & 7) hold the same 8 columns for different rows: fold the 8 row groups, then one
             // atomic per column and wave (fp32 atomics, like the weight gradients)
@@ -456,7 +466,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("" ::: "memory");
 }
 
-// FP8 = 1 (avs_gemm_nt_fp8): the operands are OCP fp8 (e4m3) instead of bf16.  Byte for byte the kernel is the same - an fp8
+// FP8 = 1 (avs_gemm_nt_fp8): the operands are OCP fp8 (e4m3) instead of bf16; FP8 = 2: the A operand (activation side) is e5m2 - a gradient.  Byte for byte the kernel is the same - an fp8
 // matrix [M, K8] with leading dimension lda8 is handed over as the bf16 matrix [M, K8 / 2] / lda8 / 2 it aliases, so tiles, DMA
 // granules, waits and the epilogue do not change; a 128-byte K-tile row then holds 128 contraction values instead of 64, each
 // lane's two 16-byte fragment chunks are the ADJACENT chunks 2g, 2g + 1 of its row (lane group g: 32 consecutive values) instead of
@@ -585,9 +595,10 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
                             const i32x4 x0 = __builtin_bit_cast(i32x4, xf[mi][0]), x1 = __builtin_bit_cast(i32x4, xf[mi][1]);
                             const i32x8 wv = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
                             const i32x8 xv = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                            // cbsz = blgp = 0: both operands e4m3; scale selectors 0 = the unscaled instruction
+                            // cbsz (first operand: the weight) = 0: e4m3; blgp (second operand: the activation side) = 0: e4m3 (forward),
+                            // 1: e5m2 (FP8 == 2: the gradient operand of an input-gradient GEMM); scale selectors 0 = the unscaled instruction
                             acc[bh * 2 + ni][ah * 4 + mi] =
-                                __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv, acc[bh * 2 + ni][ah * 4 + mi], 0, 0, 0, 0, 0, 0);
+                                __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, xv, acc[bh * 2 + ni][ah * 4 + mi], 0, FP8 == 2 ? 1 : 0, 0, 0, 0, 0);
                         }
                 } else {
 #pragma unroll
@@ -669,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
                 for (int j = 0; j < MI; ++j) acc[i][j] *= dq;
             GemmNtArgs e = a;
             e.alpha = 1.0f;
-            nt_epilogue<ACT, MI, true>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
+            nt_epilogue<ACT, MI, FP8>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
         } else {
             nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
         }
@@ -1111,32 +1122,38 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
                                const float* res, long long ldr, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2, float alpha,
                                int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale,
                                const float* qa, const float* qw, float* q8, int m_split, const uint8_t* B2, const float* bias2, const float* qw2,
-                               hipStream_t stream) {
-    AVS_CHECK_ARG(!out8 || (act == 1 && (ldo8 % 8) == 0 && ldo8 >= N), "gemm_nt_fp8: the e4m3 copy of gelu(x) goes with act 1");
+                               int a_e5m2, const bf16_t* aux, long long ldaux, float* colsum, float* colsum2, hipStream_t stream) {
+    // a_e5m2 != 0: the INPUT-GRADIENT form - A holds e5m2 gradients (B stays e4m3: the transposed weight copy); act 0, or act 2 with aux =
+    // the saved gelu'(x) (bf16) and colsum (fc1 bias gradient) as in avs_gemm_nt_bf16; out8 then receives e5m2(out) for the next such GEMM
+    AVS_CHECK_ARG(!out8 || ((ldo8 % 8) == 0 && ldo8 >= N && (a_e5m2 ? act != 1 : act == 1)),
+                  "gemm_nt_fp8: out8 = e4m3(gelu(x)) goes with act 1, out8 = e5m2(out) with the input-gradient form");
     AVS_CHECK_ARG(M > 0 && N > 0 && K >= 256 && (N % 256) == 0 && (K % 128) == 0, "gemm_nt_fp8: need N%%256==0, K%%128==0, K>=256 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && (ldo % (out_f32 ? 4 : 8)) == 0,
                   "gemm_nt_fp8: operands must keep 16-byte alignment");
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt_fp8: the residual add is implemented for fp32 output");
-    AVS_CHECK_ARG((act == 0 && !out2) || (act == 1 && out2 && !out_f32 && (ldo2 % 8) == 0), "gemm_nt_fp8: act 0, or act 1 with a bf16 output pair");
+    AVS_CHECK_ARG((act == 0 && !out2) || (act == 1 && out2 && !out_f32 && (ldo2 % 8) == 0 && !a_e5m2) ||
+                  (act == 2 && a_e5m2 && aux && !out2 && !out_f32 && (ldaux % 8) == 0),
+                  "gemm_nt_fp8: act 0; act 1 with a bf16 output pair (forward); act 2 with aux (input-gradient form)");
+    AVS_CHECK_ARG(!colsum || (!out_f32 && a_e5m2), "gemm_nt_fp8: the fused column sum goes with the bf16 output of the input-gradient form");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt_fp8: scale_cols must be a multiple of 64 within N");
     AVS_CHECK_ARG((qa == nullptr) == (qw == nullptr), "gemm_nt_fp8: qa and qw go together");
     const bool dual = m_split > 0 && m_split < M;
-    AVS_CHECK_ARG(!dual || ((m_split % 256) == 0 && B2 && (bias == nullptr) == (bias2 == nullptr) && qa && qw2),
-                  "gemm_nt_fp8: two weight sets need m_split %% 256 == 0, B2, bias2 mirroring bias, and device records (qa, qw, qw2)");
+    AVS_CHECK_ARG(!dual || ((m_split % 256) == 0 && B2 && (bias == nullptr) == (bias2 == nullptr) && qa && qw2 && (colsum == nullptr) == (colsum2 == nullptr)),
+                  "gemm_nt_fp8: two weight sets need m_split %% 256 == 0, B2, bias2 / colsum2 mirroring bias / colsum, and device records (qa, qw, qw2)");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt8_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt8_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) {
-            avs_set_error("gemm_nt_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return -1;
-        }
+        const void* ks[4] = {(const void*)gemm_nt8_kernel<0, 1>, (const void*)gemm_nt8_kernel<1, 1>, (const void*)gemm_nt8_kernel<0, 2>, (const void*)gemm_nt8_kernel<2, 2>};
+        for (int i = 0; i < 4; ++i)
+            if (hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) {
+                avs_set_error("gemm_nt_fp8: hipFuncSetAttribute failed");
+                return -1;
+            }
         attr_done = true;
     }
     // the fp8 matrices as the bf16 matrices they alias (see gemm_nt8_kernel): half the columns, half the leading dimension
-    GemmNtArgs a{reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, M, N, K / 2, bias, res, ldr, nullptr, nullptr, 0,
-                 out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, nullptr, M, dual ? m_split : 0x7fffffff,
-                 dual ? reinterpret_cast<const bf16_t*>(B2) : nullptr, dual ? bias2 : nullptr, nullptr,
+    GemmNtArgs a{reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, M, N, K / 2, bias, res, ldr, nullptr, aux, ldaux,
+                 out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M, dual ? m_split : 0x7fffffff,
+                 dual ? reinterpret_cast<const bf16_t*>(B2) : nullptr, dual ? bias2 : nullptr, dual ? colsum2 : nullptr,
                  out8, ldo8, out8_scale, qa, qw, dual ? qw2 : qw, q8};
     static int ncu = 0;
     if (ncu == 0) {
@@ -1145,8 +1162,13 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
     }
     const int tiles = ceil_div(M, 256) * (N / 256);
     const int grid = tiles < ncu ? tiles : ncu;
-    if (act == 0) gemm_nt8_kernel<0, 1><<<grid, 512, 131072, stream>>>(a);
-    else gemm_nt8_kernel<1, 1><<<grid, 512, 131072, stream>>>(a);
+    if (a_e5m2) {
+        if (act == 0) gemm_nt8_kernel<0, 2><<<grid, 512, 131072, stream>>>(a);
+        else gemm_nt8_kernel<2, 2><<<grid, 512, 131072, stream>>>(a);
+    } else {
+        if (act == 0) gemm_nt8_kernel<0, 1><<<grid, 512, 131072, stream>>>(a);
+        else gemm_nt8_kernel<1, 1><<<grid, 512, 131072, stream>>>(a);
+    }
     AVS_LAUNCH_CHECK("gemm_nt_fp8");
     return 0;
 }

@@ -93,8 +93,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ g0, const float* __restrict__ g1,
                                                      const uint8_t* __restrict__ row_mod, const int* __restrict__ out_map,
                                                      const void* dres, float* dx, bf16_t* __restrict__ dx_bf16,
-                                                     float* __restrict__ ws, int rows) {
+                                                     float* __restrict__ ws, int rows, uint8_t* __restrict__ dx8, float* q8) {
+    // dx8 / q8 (fp8 backward, may be NULL): an OCP e5m2 copy of dx * q8[0] - the gradient operand of the fp8 input-gradient GEMM that
+    // consumes dx - with max |dx| folded into the device record q8 (common.h AVS_Q_*)
     constexpr int D = NV * 256;
+    const float q8s = dx8 ? q8[AVS_Q_SCALE] : 0.f;
+    float dmax = 0.f;
     constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
     __shared__ float red[4][D];
     const int lane = threadIdx.x & 63;
@@ -178,8 +182,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 ob.y = pack_bf2(o.z, o.w);
                 reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * D)[i * 64 + lane] = ob;
             }
+            if (dx8) {
+                dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+                int w = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(o.x * q8s, -57344.f, 57344.f), __builtin_amdgcn_fmed3f(o.y * q8s, -57344.f, 57344.f), 0, false);
+                w = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(o.z * q8s, -57344.f, 57344.f), __builtin_amdgcn_fmed3f(o.w * q8s, -57344.f, 57344.f), w, true);
+                reinterpret_cast<int*>(dx8 + (size_t)row * D)[i * 64 + lane] = w;
+            }
         }
     }
+    if (dx8) q_amax_update(q8, dmax);
     // cross-wave reduction of the five accumulator sets, one set at a time through LDS
     float* slab = ws + (size_t)blockIdx.x * LN_SETS * D;
 #pragma unroll
@@ -250,7 +261,8 @@ extern "C" int avs_layernorm_fwd(const float* x, const float* g0, const float* b
 extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd,
                                  const float* g0, const float* g1, const uint8_t* row_mod, const int* out_map,
                                  const void* dres, int dres_bf16, float* dx, bf16_t* dx_bf16, float* dg0, float* db0, float* dg1,
-                                 float* db1, float* dcol, float* ws, int rows, int D, hipStream_t stream) {
+                                 float* db1, float* dcol, float* ws, int rows, int D, uint8_t* dx8, float* q8, hipStream_t stream) {
+    AVS_CHECK_ARG((dx8 == nullptr) == (q8 == nullptr), "layernorm_bwd: dx8 and its record go together");
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(dy && x && mean && rstd && g0 && (dx || dx_bf16) && ws, "layernorm_bwd: null pointer");
     AVS_CHECK_ARG(!(dres && dres_bf16 && (const void*)dx_bf16 == dres), "layernorm_bwd: dx_bf16 must not alias a bf16 dres");
@@ -263,9 +275,9 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
     dim3 grid(nblocks), block(256);
 #define LN_BWD_R(NV, F, R)                                                                                                                     \
     do {                                                                                                                                       \
-        if (dres && dres_bf16) ln_bwd_kernel<NV, F, 2, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);   \
-        else if (dres) ln_bwd_kernel<NV, F, 1, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);   \
-        else ln_bwd_kernel<NV, F, 0, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows);       \
+        if (dres && dres_bf16) ln_bwd_kernel<NV, F, 2, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows, dx8, q8);   \
+        else if (dres) ln_bwd_kernel<NV, F, 1, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows, dx8, q8);   \
+        else ln_bwd_kernel<NV, F, 0, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows, dx8, q8);       \
     } while (0)
 #define LN_BWD(NV, F)                                                                                                                          \
     do {                                                                                                                                       \

@@ -43,7 +43,11 @@ RECOMPUTE = os.environ.get("AVSIAM_RECOMPUTE", "0")
 # (16 steps) into the next scales, 448 / (2 * max) - no host synchronisation anywhere, saturation is counted, the state is saved with
 # the checkpoint (CAVMAE_BASE.fp8_state).  The first time a GEMM runs its operands are calibrated on the spot (absmax -> scale, still
 # on the device) and the activation is quantised by a pass.  The MAE pass's two towers run as one stack with two weight sets here too.
-# Everything the backward reads is still produced in bf16 and the backward itself is the bf16 one.
+# Everything the backward reads is still produced in bf16.  AVSIAM_FP8=2 (bench.py --fp8 --fp8-dgrad) extends the mode into the backward:
+# the input-gradient GEMMs of fc2 (with its GELU' epilogue), fc1 and proj run on e5m2 gradient operands - written, beside the bf16
+# gradient the weight-gradient GEMMs and LayerNorm still read, by the LayerNorm backward that produces the residual gradient and by the
+# fc2 input-gradient epilogue; own records, fmax 57344 - against the e4m3 copy of the transposed weight (the forward's weight scale).
+# The qkv input gradient and all weight gradients stay bf16.
 FP8 = os.environ.get("AVSIAM_FP8", "0")
 # The residual-GRADIENT stream between the blocks of a stack (AVSIAM_GRAD_STREAM=bf16 | fp32).  bf16 (default): a LayerNorm backward
 # reads the upstream residual gradient from the bf16 copy the previous LayerNorm backward wrote for the GEMMs anyway and writes
@@ -113,12 +117,13 @@ def _ln_fwd(x, norms, y, mean, rstd, rows, eps, row_mod=None, out_map=None, y8=N
                       row_mod if n1 else None, out_map, y8=y8, q8_dev=q8_dev)
 
 
-def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None, dcol=None):
-    """dcol: bias gradient of the Linear whose output gradient is the dx produced here (column sum fused in-kernel)."""
+def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None, dcol=None, dx8=None, q8=None):
+    """dcol: bias gradient of the Linear whose output gradient is the dx produced here (column sum fused in-kernel).
+    dx8 / q8: e5m2 copy of dx for an fp8 input-gradient GEMM and its device record."""
     n0 = norms[0]
     n1 = norms[1] if len(norms) > 1 else None
     ops.layernorm_bwd(dy, x, mean, rstd, n0.g, dx, n0.dg, n0.db, ws, rows, n1.g if n1 else None, n1.dg if n1 else None,
-                      n1.db if n1 else None, row_mod if n1 else None, out_map, dres, dx_bf16, dcol)
+                      n1.db if n1 else None, row_mod if n1 else None, out_map, dres, dx_bf16, dcol, dx8=dx8, q8=q8)
 
 
 def _dx_in(stack):
@@ -199,7 +204,8 @@ class Stack:
         self.row_mod = row_mod
         self.inference = inference
         self.recompute = RECOMPUTE == "1" and not inference
-        self.fp8 = FP8 == "1" and D % 256 == 0 and hidden % 256 == 0 and D >= 256     # the fp8 GEMM's tile constraints (N % 256, K % 128)
+        self.fp8 = FP8 in ("1", "2") and D % 256 == 0 and hidden % 256 == 0 and D >= 256     # the fp8 GEMM's tile constraints (N % 256, K % 128)
+        self.fp8_bwd = self.fp8 and FP8 == "2" and not inference
         if self.fp8:
             r8 = ops.pad_rows(rows, 256)
             self.a8 = torch.zeros((r8, max(D, hidden)), dtype=U8, device=dev)      # calibration step only: an activation quantised by a pass
@@ -209,6 +215,12 @@ class Stack:
             self.act8 = torch.zeros((r8, hidden), dtype=U8, device=dev)            # ... and fc1's GELU epilogue for fc2
             self.f8 = ops.Fp8Records(nblocks * 12, dev)                            # per block: 4 GEMMs x (activation, weight, second weight set)
             self.f8_seen = set()                                                   # (block, gemm) whose records hold a calibrated scale
+        if self.fp8_bwd:
+            self.g8 = ops.Fp8Records(nblocks * 4, dev, fmax=ops.BF8_MAX)           # per block: the e5m2 operands dbo (fc2), dfc1 (fc1), dbm (proj)
+            self.g8_seen, self.g8_have = set(), set()
+            self.dx8 = [torch.zeros((r8, D), dtype=U8, device=dev) for _ in range(2)]      # e5m2 copies of dbo / dbm
+            self.dfc1_8 = torch.zeros((r8, hidden), dtype=U8, device=dev)
+            self.wt8 = [torch.empty((hidden * D,), dtype=U8, device=dev) for _ in range(2)]
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
         # rows per attention workgroup (4 or 2 waves of 32 queries / keys), by the mean sequence length of the stack - measured on the
@@ -352,16 +364,48 @@ class Stack:
             dual = (split, w8b, lin2.b, rw2)
         ops.gemm_nt_fp8(a8, w8, out, M, bias=lin.b, qa=ra, qw=rw, dual=dual, **kw)
 
+    def _dgrad_fp8(self, i, gname, wname, A, a8, lin, lin2, split, out, colsum2=None, **kw):
+        """One input-gradient GEMM on an e5m2 gradient operand (A: its bf16 form, a8: where its e5m2 copy lives - written by the
+        producer when (i, gname) is in g8_have, else by a pass here) and the e4m3 copy of the transposed weight, quantised with the
+        scale of the forward's weight record (the same tensor)."""
+        M = self.rows
+        G8 = {"dbo": 0, "dfc1": 1, "dbm": 2}
+        idx = i * 4 + G8[gname]
+        rec = self.g8.rec(idx)
+        if (i, gname) not in self.g8_seen:            # first use: calibrate on the device
+            ops.absmax_into(A, rec)
+            self.g8.update(first=idx, count=1)
+            self.g8_seen.add((i, gname))
+        if (i, gname) not in self.g8_have:
+            ops.quantize_fp8(A, 1.0, out=a8[:A.shape[0]], q=rec, e5m2=True)
+        Wt = lin.wt
+        N, K = Wt.shape
+        rw, rw2 = self._rec(i, wname, 1), self._rec(i, wname, 2)
+        w8 = self.wt8[0][:N * K].view(N, K)
+        ops.quantize_fp8(Wt, 1.0, out=w8, q=rw)
+        dual = None
+        if lin2 is not None:
+            w8b = self.wt8[1][:N * K].view(N, K)
+            ops.quantize_fp8(lin2.wt, 1.0, out=w8b, q=rw2)
+            dual = (split, w8b, None, rw2, colsum2)
+        ops.gemm_nt_fp8(a8, w8, out, M, qa=rec, qw=rw, grad=True, dual=dual, **kw)
+
     def fp8_state(self):
         """delayed-scaling state for the checkpoint (None without the fp8 mode)"""
         if not self.fp8:
             return None
-        return {**self.f8.state(), "seen": sorted(self.f8_seen)}
+        st = {**self.f8.state(), "seen": sorted(self.f8_seen)}
+        if self.fp8_bwd:
+            st["grad"] = {**self.g8.state(), "seen": sorted(self.g8_seen)}
+        return st
 
     def load_fp8_state(self, st):
         if self.fp8 and st is not None:
             self.f8.load(st)
             self.f8_seen = {tuple(k) for k in st["seen"]}
+            if self.fp8_bwd and "grad" in st:
+                self.g8.load(st["grad"])
+                self.g8_seen = {tuple(k) for k in st["grad"]["seen"]}
 
     def backward(self, blocks, last_fc2_bias_done=False, blocks2=None, split=0, reducer=None, accumulate=False):
         """In: d(out) in self.dxb[0] (bf16) - and in self.dx[0] (fp32) when GRAD_STREAM is "fp32".  Out: d(x[0]) in self.dx[0] (fp32)
@@ -409,6 +453,18 @@ class Stack:
                             ops.gemm_tn(A, B, C, hi - lo)
             side.run(key, fn)
 
+        f8b = self.fp8_bwd
+        if f8b:
+            self.g8.update()                   # delayed scaling of the gradient operands: last backward's amax -> this backward's scales
+            self.g8_have = set()               # (block, operand) whose e5m2 copy a producer has written in this backward
+        G8 = {"dbo": 0, "dfc1": 1, "dbm": 2}
+
+        def g8rec(blk, name):                  # (e5m2 buffer, record) of a gradient operand once calibrated, else (None, None)
+            if not f8b or blk < 0 or (blk, name) not in self.g8_seen:
+                return None, None
+            self.g8_have.add((blk, name))
+            return {"dbo": self.dx8[0], "dbm": self.dx8[1], "dfc1": self.dfc1_8}[name], self.g8.rec(blk * 4 + G8[name])
+
         for i in reversed(range(self.nblocks)):
             bp, st = blocks[i], self.stats[i]
             b2 = blocks2[i] if blocks2 is not None else None
@@ -421,25 +477,38 @@ class Stack:
                     block_done(i + 1)          # its last wgrad (qkv) was the side stream's tail; fc2's bias came from this LN backward
             else:
                 side.before_write("dfc1")
-            ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
-                        dual=(split, b2.fc2.wt, None, b2.fc1.gb) if b2 is not None else None)
+            if f8b:
+                o8, r8_ = g8rec(i, "dfc1")
+                self._dgrad_fp8(i, "dbo", "fc2", dbo, self.dx8[0], bp.fc2, b2.fc2 if b2 else None, split, self.dfc1, act=2, aux=self.fc1[i],
+                                colsum=bp.fc1.gb, colsum2=b2.fc1.gb if b2 else None, **({"out8": o8, "q8": r8_} if o8 is not None else {}))
+            else:
+                ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
+                            dual=(split, b2.fc2.wt, None, b2.fc1.gb) if b2 is not None else None)
             if not grp:
                 wgrads(i, "dbo", (dbo, self.act[i], "fc2"))
             if i == self.nblocks - 1 and not last_fc2_bias_done:
                 for lo, hi, bl in ranges:
                     ops.colsum(dbo[lo:], bl[i].fc2.gb, hi - lo)
             # fc1
-            ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M, dual=(split, b2.fc1.wt, None, None) if b2 is not None else None)
+            if f8b:
+                self._dgrad_fp8(i, "dfc1", "fc1", self.dfc1, self.dfc1_8, bp.fc1, b2.fc1 if b2 else None, split, self.dln)
+            else:
+                ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M, dual=(split, b2.fc1.wt, None, None) if b2 is not None else None)
             if not grp:
                 wgrads(i, "dfc1", (self.dfc1, self.ln2[i], "fc1"))
                 side.before_write("dbm")
             for lo, hi, bl in ranges:
                 if accumulate:            # value third of the qkv bias gradient, below: minus what proj.gb holds before this block adds to it
                     ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * self.D:], -1.0)
+                d8, q8_ = g8rec(i, "dbm")
                 _ln_bwd(self.dln[lo:], self.xmid[i][lo:], st[2][lo:], st[3][lo:], bl[i].n2, None if g16 else dxm[lo:], self.lnws, hi - lo,
-                        None if one else self.row_mod, dres=(dbo if g16 else dxo)[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb)
+                        None if one else self.row_mod, dres=(dbo if g16 else dxo)[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb,
+                        dx8=d8[lo:] if d8 is not None else None, q8=q8_)
             # proj
-            ops.gemm_nt(dbm, bp.proj.wt, self.datt, M, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
+            if f8b:
+                self._dgrad_fp8(i, "dbm", "proj", dbm, self.dx8[1], bp.proj, b2.proj if b2 else None, split, self.datt)
+            else:
+                ops.gemm_nt(dbm, bp.proj.wt, self.datt, M, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
             if grp:                   # the three wgrads whose operands exist now run beside the attention backward
                 wgrads(i, "blockA", (dbo, self.act[i], "fc2"), (self.dfc1, self.ln2[i], "fc1"), (dbm, self.att[i], "proj"))
             else:
@@ -462,9 +531,10 @@ class Stack:
                 D = self.D
                 ops.colsum(self.dqkv[lo:, :D], bl[i].qkv.gb[:D], hi - lo)
                 ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * D:])
+                d8, q8_ = g8rec(i - 1, "dbo")          # the block below reads this gradient through its fc2 input-gradient GEMM
                 _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, None if g16 and i > 0 else dxo[lo:], self.lnws,
                         hi - lo, None if one else self.row_mod, dres=(dbm if g16 else dxm)[lo:], dx_bf16=dbo[lo:],
-                        dcol=bl[i - 1].fc2.gb if i > 0 else None)
+                        dcol=bl[i - 1].fc2.gb if i > 0 else None, dx8=d8[lo:] if d8 is not None else None, q8=q8_)
         side.join()
         if reducer is not None:
             for j in ([0] if excl else reversed(range(self.nblocks))):

@@ -109,7 +109,7 @@ def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod
 
 
 def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=None, db1=None, row_mod=None,
-                  out_map=None, dres=None, dx_bf16=None, dcol=None):
+                  out_map=None, dres=None, dx_bf16=None, dcol=None, dx8=None, q8=None):
     """dres: fp32, or bf16 (the residual-gradient stream kept in bf16: the previous call's dx_bf16); dx (fp32) may be None when
     dx_bf16 is given."""
     D = x.shape[1]
@@ -118,6 +118,8 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
     _chk(dx_bf16, BF16, "lnb.dx_bf16", 2); _chk(dcol, F32, "lnb.dcol")
     assert dcol is None or dcol.numel() == D
     assert dx is not None or dx_bf16 is not None
+    _chk(dx8, U8, "lnb.dx8", 2)
+    assert (dx8 is None) == (q8 is None) and (dx8 is None or (dx8.shape[0] >= rows and dx8.shape[1] == D))
     if dx_bf16 is not None:
         assert dx_bf16.shape[0] >= rows and dx_bf16.shape[1] == D
         assert dres is None or dres.dtype != BF16 or dres.data_ptr() != dx_bf16.data_ptr(), "dx_bf16 must not alias a bf16 dres"
@@ -133,7 +135,7 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
     nbytes = dy.element_size() + 4 + (4 if dx is not None else 0) + (dres.element_size() if dres is not None else 0) + (2 if dx_bf16 is not None else 0)
     _launch("layernorm_bwd", float(rows) * D * nbytes,
             "avs_layernorm_bwd", dy, 1 if dy.dtype == F32 else 0, x, mean, rstd, g0, g1, row_mod, out_map, dres,
-            1 if dres is not None and dres.dtype == BF16 else 0, dx, dx_bf16, dg0, db0, dg1, db1, dcol, ws, rows, D, _stream())
+            1 if dres is not None and dres.dtype == BF16 else 0, dx, dx_bf16, dg0, db0, dg1, db1, dcol, ws, rows, D, dx8, _qrec(q8), _stream())
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -180,6 +182,7 @@ def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None
 
 
 FP8_MAX = 448.0          # largest finite OCP e4m3 value
+BF8_MAX = 57344.0        # ... and OCP e5m2 (the gradient operands of the fp8 input-gradient GEMMs)
 
 
 def _qrec(q):
@@ -196,8 +199,9 @@ class Fp8Records:
     ring hist[nhist, n].  update() is one tiny launch and never synchronises: hist[pos] <- amax since the last update,
     scale <- 448 / (margin * max(hist)), amax <- 0, saturation counter += (amax * old scale > 448)."""
 
-    def __init__(self, n, dev, nhist=16, margin=2.0):
-        self.n, self.nhist, self.margin, self.pos = n, nhist, margin, 0
+    def __init__(self, n, dev, nhist=16, margin=2.0, fmax=FP8_MAX):
+        """fmax: largest finite value of the format these tensors are quantised to - 448 (e4m3) or 57344 (e5m2, gradients)"""
+        self.n, self.nhist, self.margin, self.pos, self.fmax = n, nhist, margin, 0, float(fmax)
         self.q = torch.zeros((n, 4), dtype=F32, device=dev)
         self.hist = torch.zeros((nhist, n), dtype=F32, device=dev)
 
@@ -212,7 +216,7 @@ class Fp8Records:
         if count <= 0:
             return
         assert 0 <= first and first + count <= self.n
-        _lib.call("avs_fp8_scale_update", self.q, self.hist, self.n, self.nhist, self.pos, float(self.margin), int(first), int(count), _stream())
+        _lib.call("avs_fp8_scale_update", self.q, self.hist, self.n, self.nhist, self.pos, float(self.margin), int(first), int(count), self.fmax, _stream())
         if whole and first == 0:
             self.pos = (self.pos + 1) % self.nhist
 
@@ -243,36 +247,41 @@ def absmax_into(x, q):
     _lib.call("avs_absmax", x, 1 if x.dtype == F32 else 0, x.numel(), _qrec(q)[2:3], _stream())
 
 
-def quantize_fp8(x, scale, out=None, q=None):
-    """x (fp32 / bf16, contiguous) -> uint8 tensor holding OCP e4m3 of clamp(x * scale, +-448); with a device record q the scale is q[0]
-    and max |x| is folded into q[2]"""
+def quantize_fp8(x, scale, out=None, q=None, e5m2=False):
+    """x (fp32 / bf16, contiguous) -> uint8 tensor holding OCP e4m3 of clamp(x * scale, +-448) (e5m2: +-57344); with a device record q the
+    scale is q[0] and max |x| is folded into q[2]"""
     assert x.is_cuda and x.is_contiguous() and x.dtype in (F32, BF16) and x.numel() % 4 == 0
     y = out if out is not None else torch.empty(x.shape, dtype=U8, device=x.device)
     assert y.dtype == U8 and y.numel() == x.numel() and y.is_contiguous()
-    _lib.call("avs_quantize_fp8", x, 1 if x.dtype == F32 else 0, y, x.numel(), float(scale), _qrec(q), _stream())
+    _lib.call("avs_quantize_fp8", x, 1 if x.dtype == F32 else 0, y, x.numel(), float(scale), _qrec(q), 1 if e5m2 else 0, _stream())
     return y
 
 
 def gemm_nt_fp8(A8, B8, out, M, alpha=1.0, bias=None, res=None, out2=None, act=0, scale_cols=0, col_scale=1.0, out8=None, out8_scale=1.0,
-                qa=None, qw=None, q8=None, dual=None):
+                qa=None, qw=None, q8=None, dual=None, grad=False, aux=None, colsum=None):
     """x = alpha * (A8[M, K] @ B8[N, K]^T) + bias (+ res); act 0: out = x; act 1: out = gelu'(x), out2 = gelu(x) (like gemm_nt).
     A8 / B8: uint8 tensors of e4m3 values (quantize_fp8), alpha = 1 / (scale_A * scale_B) - or the device records qa / qw (delayed
-    scaling: the kernel reads qa[1] * qw[1]); q8: the record of out8.  dual = (m_split, B8_2, bias2, qw2): a second weight set."""
+    scaling: the kernel reads qa[1] * qw[1]); q8: the record of out8.  dual = (m_split, B8_2, bias2, qw2[, colsum2]): a second weight set.
+    grad=True: the input-gradient form - A8 holds e5m2 gradients; act 0 or 2 (aux = saved gelu'(x), colsum = fc1 bias gradient); out8
+    then receives e5m2(out) for the next input-gradient GEMM."""
     _chk(A8, U8, "gemm8.A", 2); _chk(B8, U8, "gemm8.B", 2); _chk(bias, F32, "gemm8.bias"); _chk(res, F32, "gemm8.res", 2); _chk(out2, BF16, "gemm8.out2", 2)
-    _chk(out8, U8, "gemm8.out8", 2)
+    _chk(out8, U8, "gemm8.out8", 2); _chk(aux, BF16, "gemm8.aux", 2); _chk(colsum, F32, "gemm8.colsum")
     assert out.dtype in (BF16, F32) and out.dim() == 2 and out.is_contiguous()
     N, K = B8.shape
     assert A8.shape[1] == K and A8.shape[0] >= M and out.shape[0] >= M and out.shape[1] == N
     assert (qa is None) == (qw is None)
-    m_split, B2, bias2, qw2 = dual if dual is not None else (0, None, None, None)
+    assert act in (0, 1, 2) and (act != 2 or (grad and aux is not None and aux.shape[0] >= M and aux.shape[1] == N)) and (act != 1 or not grad)
+    assert colsum is None or (grad and colsum.numel() == N and out.dtype == BF16)
+    assert out8 is None or (out8.shape[0] >= M and out8.shape[1] == N)
+    m_split, B2, bias2, qw2, colsum2 = (tuple(dual) + (None,))[:5] if dual is not None else (0, None, None, None, None)
     if dual is not None:
-        _chk(B2, U8, "gemm8.B2", 2); _chk(bias2, F32, "gemm8.bias2")
+        _chk(B2, U8, "gemm8.B2", 2); _chk(bias2, F32, "gemm8.bias2"); _chk(colsum2, F32, "gemm8.colsum2")
         assert B2.shape == B8.shape and B2.stride(0) == B8.stride(0) and 0 < m_split < M and m_split % 256 == 0 and qa is not None and qw2 is not None
-        assert (bias2 is None) == (bias is None)
+        assert (bias2 is None) == (bias is None) and (colsum2 is None) == (colsum is None)
     _launch("gemm_nt_fp8", 2.0 * M * N * K, "avs_gemm_nt_fp8", A8, A8.stride(0), B8, B8.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
             out, out.stride(0), 1 if out.dtype == F32 else 0, out2, out2.stride(0) if out2 is not None else 0, float(alpha), int(act), int(scale_cols),
             float(col_scale), out8, out8.stride(0) if out8 is not None else 0, float(out8_scale), _qrec(qa), _qrec(qw), _qrec(q8),
-            int(m_split), B2, bias2, _qrec(qw2), _stream())
+            int(m_split), B2, bias2, _qrec(qw2), 1 if grad else 0, aux, aux.stride(0) if aux is not None else 0, colsum, colsum2, _stream())
 
 
 def gemm_tn(A, B, C, M, splits=0):

@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) forward GEMMs (engine.FP8): configs[4]'s fp8 MFMA path as an extra data point; "
                     "the line then says dtype fp8-forward/bf16-backward and is NOT the headline metric")
+    ap.add_argument("--fp8-dgrad", action="store_true", help="with --fp8: the fc2 / fc1 / proj input-gradient GEMMs on e5m2 gradient operands too (engine.FP8 = 2)")
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved "
                     "activations do not fit the GPU, e.g. --model vit_huge at batch 64; never for the headline metric")
     ap.add_argument("--force-dp", action="store_true", help="form the RCCL process group and issue EVERY collective of the data-parallel step "
@@ -269,7 +270,7 @@ def main():
         if args.recompute:
             _engine.RECOMPUTE = "1"
         if args.fp8:
-            _engine.FP8 = "1"
+            _engine.FP8 = "2" if args.fp8_dgrad else "1"
     model = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
     comm = None
     if args.force_dp and world == 1:
@@ -331,7 +332,7 @@ def main():
         line = {
             "metric": f"AV pretrain samples/sec ({mname}, 75% mask)", "value": sps, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "fp8(e4m3)-forward/bf16-backward" if args.fp8 else "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("fp8(e4m3)-forward/fp8(e5m2 x e4m3)-input-gradients/bf16-weight-gradients" if args.fp8_dgrad else "fp8(e4m3)-forward/bf16-backward") if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x{cfg.video_tokens} + "
                                    f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,

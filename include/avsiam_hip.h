@@ -44,11 +44,13 @@ int avs_layernorm_fwd_q8(const float* x, const float* g0, const float* b0, const
  * bf16 copy of dx; dg/db are accumulated (+=); dcol (may be NULL) accumulates the column sum of dx, i.e. the bias gradient
  * of the Linear that produced this residual branch; ws: avs_layernorm_ws_floats.
  * dres_bf16 != 0: dres is bf16 (the residual-gradient stream kept in bf16 between blocks - the previous call's dx_bf16);
- * dx may then be NULL (only dx_bf16 is written); dx_bf16 must not alias a bf16 dres. */
+ * dx may then be NULL (only dx_bf16 is written); dx_bf16 must not alias a bf16 dres.
+ * dx8 / q8 (fp8 backward; both or neither): also dx8 = e5m2(clamp(dx * q8[0])) - the gradient operand of an fp8 input-gradient GEMM -
+ * with max |dx| folded into the device record q8 (avs_fp8_scale_update) */
 int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* mean, const float* rstd, const float* g0,
                       const float* g1, const uint8_t* row_mod, const int* out_map, const void* dres, int dres_bf16, float* dx,
                       avs_bf16* dx_bf16, float* dg0, float* db0, float* dg1, float* db1, float* dcol, float* ws, int rows,
-                      int D, avs_stream_t stream);
+                      int D, uint8_t* dx8, float* q8, avs_stream_t stream);
 
 /* ---- bf16 MFMA GEMMs (nn.Linear / PatchEmbed.proj and their backward: cav_mae_base.py:51,55,60,77,96-99,138-143,
  * 600,634-635).  nt: x = alpha*(A[M,K].B[N,K]^T + bias [*aux] + res[res_idx? res_idx[m] : m]); act 0: out = x;
@@ -72,18 +74,22 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
  * Delayed scaling (no host synchronisation anywhere): a tensor's quantisation state is a DEVICE record of four floats
  * q = {scale, 1 / scale, running max |x| since the last update, saturation events}.  Where an entry point takes such a record
  * (qa / qw / qw2: operands of the GEMM, de-quantisation factor qa[1] * qw[1]; q8: the e4m3 copy a kernel writes - scale q8[0], amax into
- * q8[2]) it overrides the host float beside it.  avs_fp8_scale_update(q [n][4], hist [nhist][n], n, nhist, pos, margin, first, count): per record
- * in [first, first + count), hist[pos] = q[2]; scale = 448 / (margin * max over hist); q[2] = 0; q[3] += (q[2] * old scale > 448).
+ * q8[2]) it overrides the host float beside it.  avs_fp8_scale_update(q [n][4], hist [nhist][n], n, nhist, pos, margin, first, count, fmax): per
+ * record in [first, first + count), hist[pos] = q[2]; scale = fmax / (margin * max over hist); q[2] = 0; q[3] += (q[2] * old scale > fmax);
+ * fmax = 448 (e4m3 tensors) or 57344 (e5m2: the gradient operands of the input-gradient form).
+ * Input-gradient form (a_e5m2 != 0; BASELINE configs[4]'s fp8 path in the backward): A holds e5m2 gradients, B the e4m3 transposed weight;
+ * act 0, or act 2 with aux / colsum as in avs_gemm_nt_bf16 (fc2 input gradient); out8 (may be NULL) = e5m2(out * q8[0]) for the next one.
  * m_split / B2 / bias2 / qw2: a second weight set for rows from m_split (m_split % 256 == 0; needs the records), else m_split = 0.
  * avs_absmax: out = max(out, max |x|) (caller zeroes out; x fp32 or bf16);
- * avs_quantize_fp8: y = e4m3(clamp(x * scale, +-448)), n%4==0; with q: scale = q[0], max |x| into q[2]. */
+ * avs_quantize_fp8: y = e4m3(clamp(x * scale, +-448)) (e5m2 != 0: e5m2, +-57344), n%4==0; with q: scale = q[0], max |x| into q[2]. */
 int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long ldb, int M, int N, int K, const float* bias,
                     const float* res, long long ldr, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,
                     int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale, const float* qa,
-                    const float* qw, float* q8, int m_split, const uint8_t* B2, const float* bias2, const float* qw2, avs_stream_t stream);
+                    const float* qw, float* q8, int m_split, const uint8_t* B2, const float* bias2, const float* qw2, int a_e5m2,
+                    const avs_bf16* aux, long long ldaux, float* colsum, float* colsum2, avs_stream_t stream);
 int avs_absmax(const void* x, int is_f32, long long n, float* out, avs_stream_t stream);
-int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, float* q, avs_stream_t stream);
-int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, avs_stream_t stream);
+int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, float* q, int e5m2, avs_stream_t stream);
+int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax, avs_stream_t stream);
 /* the same GEMM over TWO weight sets in one launch: rows [0, m_split) of A meet B / bias / colsum, rows [m_split, M) meet
  * B2 / bias2 / colsum2 (same shapes and leading dimension; m_split a multiple of 256).  Replaces the two nn.Linear calls the
  * reference makes per layer for its separate audio and visual towers (cav_mae_base.py:487,489: `blk(v, 'v')` on

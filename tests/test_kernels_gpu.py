@@ -787,6 +787,47 @@ def test_fp8_delayed_scaling_records():
     assert torch.equal(att, ref_att)                                       # the bf16 output does not change
     st_ = rec.q[5, 0].item()
     assert rel_err(att8[:2 * L].view(torch.float8_e4m3fn).float() / st_, att[:2 * L]) < 0.04
+    # ---- input-gradient form (engine.FP8 = "2"): e5m2 gradient operand x e4m3 transposed weight, records with fmax 57344
+    grec = o.Fp8Records(3, DEV, nhist=4, margin=2.0, fmax=o.BF8_MAX)
+    rg, rg2 = grec.rec(0), grec.rec(1)
+    dY = torch.randn(M, K, device=DEV, generator=g) * 1e-3                 # gradients are small: the scale moves them into e5m2's range
+    dYb = bf(dY)
+    o.absmax_into(dYb, rg)
+    grec.update(first=0, count=1)
+    sg = grec.q[0, 0].item()
+    assert abs(sg - 57344.0 / (2 * dYb.float().abs().max().item())) <= 1e-5 * sg
+    dY8 = o.quantize_fp8(dYb, 1.0, q=rg, e5m2=True)
+    assert torch.equal(dY8.view(torch.float8_e5m2), (dYb.float() * sg).clamp(-57344, 57344).to(torch.float8_e5m2))
+    dYd = dY8.view(torch.float8_e5m2).double() / sg
+    Wd = W8.view(torch.float8_e4m3fn).double() / sw
+    dX = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm_nt_fp8(dY8, W8, dX, M, qa=rg, qw=rw, grad=True)
+    assert rel_err(dX, dYd @ Wd.t()) < 3e-3                                  # exact product of the de-quantised operands, bf16 output
+    assert 5e-3 < rel_err(dX, dYb.double() @ W.double().t()) < 0.12           # e5m2 keeps 2 mantissa bits: ~7 % on random operands
+    # act 2: x saved gelu'(x), fused column sum, and the e5m2 copy of the result for the next input-gradient GEMM
+    aux = bf(torch.rand(M, N, device=DEV, generator=g))
+    cs = torch.ones(N, device=DEV)
+    want2 = (dYd @ Wd.t()) * aux.double()
+    o.absmax_into(bf(want2.float()), rg2)
+    grec.update(first=1, count=1)
+    out8g = torch.zeros(M, N, device=DEV, dtype=torch.uint8)
+    o.gemm_nt_fp8(dY8, W8, dX, M, qa=rg, qw=rw, grad=True, act=2, aux=aux, colsum=cs, out8=out8g, q8=rg2)
+    assert rel_err(dX, want2) < 3e-3 and rel_err(cs, 1 + want2.sum(0)) < 2e-3
+    s2 = grec.q[1, 0].item()
+    assert rel_err(out8g.view(torch.float8_e5m2).float() / s2, want2) < 0.08
+    # LayerNorm backward writing the e5m2 copy of dx
+    dyl = bf(torch.randn(rows, D, device=DEV, generator=g) * 1e-2)
+    dxb_ = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    dx8_ = torch.zeros(rows, D, device=DEV, dtype=torch.uint8)
+    wsl = torch.empty(o.layernorm_ws(rows, D), device=DEV)
+    dgl, dbl = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    rl8 = grec.rec(2)
+    o.layernorm_bwd(dyl, x, mean, rstd, gm, None, dgl, dbl, wsl, rows, dx_bf16=dxb_)
+    o.absmax_into(dxb_, rl8)
+    grec.update(first=2, count=1)
+    o.layernorm_bwd(dyl, x, mean, rstd, gm, None, dgl, dbl, wsl, rows, dx_bf16=dxb_, dx8=dx8_, q8=rl8)
+    assert rel_err(dx8_.view(torch.float8_e5m2).float() / grec.q[2, 0].item(), dxb_) < 0.08
+    assert abs(grec.q[2, 2].item() - dxb_.float().abs().max().item()) <= 1e-2 * dxb_.float().abs().max().item()
     # the ring: a whole-table update stores the amax, restarts it and advances; a 3x larger tensor saturates under the old scale once
     o.quantize_fp8(A * 3, 1.0, q=ra)
     rec.update()

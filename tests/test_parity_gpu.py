@@ -319,12 +319,15 @@ FP8_LOSS_RTOL, FP8_LOGITS_ATOL, FP8_COS_MIN, FP8_RATIO_TOL = 5e-3, 0.12, 0.975, 
 
 @pytest.mark.parametrize("which", ["mae", "contrastive"])
 @pytest.mark.parametrize("shape", ["vit_base", "vit_huge14"])
-def test_fp8_forward_mode_against_oracle(shape, which):
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_fp8_forward_mode_against_oracle(shape, which, mode):
     """engine.FP8 (BASELINE.json configs[4]'s "fp8 MFMA path") pinned to oracle/ref_cpu.py (the fp32 restatement of
     /root/reference/src/models/cav_mae_base.py:685-741), not to the HIP bf16 path: losses, contrastive logits, and every live gradient
     tensor's cosine / norm ratio, at ViT-B and at the ViT-H/14 geometry the mode is meant for (2 layers, 2 frames).  Two steps are
     compared: the calibration step (scales from the first batch, activations quantised by a pass) and the step after it (delayed
-    scales on the device; LayerNorm / GELU / attention epilogues write the e4m3 operands themselves)."""
+    scales on the device; LayerNorm / GELU / attention epilogues write the e4m3 operands themselves).
+    mode "2": the fc2 / fc1 / proj input-gradient GEMMs run on e5m2 gradient operands as well (forward unchanged, so losses and logits
+    are those of mode "1"; the gradients carry the extra rounding - same stated tolerance)."""
     import random
     from avsiam_amd import engine
     from avsiam_amd.config import vit_huge14
@@ -336,13 +339,13 @@ def test_fp8_forward_mode_against_oracle(shape, which):
     plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(9))
     ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 93)
     try:
-        engine.FP8 = "1"
+        engine.FP8 = mode
         m = _model(cfg, 93)
         for step in (0, 1):
             out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
             out[0].backward()
             torch.cuda.synchronize()
-            tag = f"fp8_oracle_{shape}_{which}_step{step}"
+            tag = f"fp8{'' if mode == '1' else 'bwd'}_oracle_{shape}_{which}_step{step}"
             worst_loss = 0.0
             for i in (0, 1, 2, 3, 4):
                 err = abs(out[i].item() - ref[i].item()) / (abs(ref[i].item()) + 1e-12) if ref[i].item() != 0 else abs(out[i].item())
