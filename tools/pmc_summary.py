@@ -36,8 +36,8 @@ def load(path, counter):
 FAMILIES = {
     "gemm_nt": (("gemm_nt",), "gemm_nt"),
     "gemm_tn": (("gemm_tn",), "gemm_tn"),
-    "attn_hd32": (("attn_fwd_kernel<32", "attn_bwd_dq_kernel<32", "attn_bwd_dkv_kernel<32"), None),
-    "attn_hd64": (("attn_fwd_kernel<64", "attn_bwd_dq_kernel<64", "attn_bwd_dkv_kernel<64"), None),
+    "attn_hd32": (("attn_fwd_kernel<32", "attn_bwd_dq_kernel<32", "attn_bwd_dkv_kernel<32", "attn_bwd_fused_kernel<32"), None),
+    "attn_hd64": (("attn_fwd_kernel<64", "attn_bwd_dq_kernel<64", "attn_bwd_dkv_kernel<64", "attn_bwd_fused_kernel<64"), None),
     "ln_bwd": (("ln_bwd_kernel", "ln_bwd_reduce_kernel"), "ln_bwd_kernel"),
     "ln_fwd": (("ln_fwd_kernel",), "ln_fwd_kernel"),
 }
@@ -57,8 +57,8 @@ def main():
         mm = [r for r in rows if any(s in r[0] for s in subs)]
         if not mm:
             continue
-        if count_sub is None:          # attention: forward launches + backward launches (dq and dkv are one call)
-            n = sum(r[1] for r in mm if "attn_fwd" in r[0]) + sum(r[1] for r in mm if "attn_bwd_dkv" in r[0])
+        if count_sub is None:          # attention: forward launches + backward launches (dq and dkv are one call, a fused backward another)
+            n = sum(r[1] for r in mm if "attn_fwd" in r[0]) + sum(r[1] for r in mm if "attn_bwd_dkv" in r[0] or "attn_bwd_fused" in r[0])
         else:
             n = sum(r[1] for r in mm if count_sub in r[0] and "reduce" not in r[0])
         fb, wb = sum(r[2] for r in mm), sum(r[3] for r in mm)
