@@ -165,6 +165,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     char* sK = smem;
     char* sV = smem + 64 * HD * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    // fp8 mode: the output record's scale and the amax it already holds are requested up front (their latency hides under the key loop)
+    const float q8s = a.out8 ? a.q8[AVS_Q_SCALE] : 0.f;
+    const float q8seen = q_amax_peek(a.out8 ? a.q8 : nullptr);
     // 1-D grid, XCD-aware: logical id = head * ntiles + tile, so the query/key tiles of one (sequence, head) - which all
     // stream the same K/V (or Q/dO) rows - run on one XCD and re-read them from its L2 instead of from HBM.
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -308,7 +311,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qq = qw + (lane & 31);
-    const float q8s = a.out8 ? a.q8[AVS_Q_SCALE] : 0.f;
     float omax = 0.f;
     if (qq < L) {
         bf16_t* orow = a.out + (size_t)(seq0 + qq) * a.ldo + head * HG;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
             }
         if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
-    if (a.out8) q_amax_update(a.q8, omax);
+    if (a.out8) q_amax_update(a.q8, omax, q8seen);
 }
 
 // ---------------------------------------------------------------------------------------------------

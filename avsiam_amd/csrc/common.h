@@ -117,14 +117,15 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define AVS_Q_AMAX 2
 #define AVS_Q_SAT 3
 
-// fold a wave's max |x| (m >= 0, any lane's value; reduced here) into q[AVS_Q_AMAX].  The plain load filters: once the record holds
-// the tensor's typical maximum almost no wave issues the atomic (thousands of waves hitting one address would serialise).
-__device__ __forceinline__ void q_amax_update(float* q, float m) {
+// fold a wave's max |x| (m >= 0, any lane's value; reduced here) into q[AVS_Q_AMAX].  `seen` = q[AVS_Q_AMAX] as read by q_amax_peek at the
+// START of the kernel (a plain load whose latency hides under the kernel's work; a load here, at the end, was a dependent memory round
+// trip in every wave's tail - it doubled the LayerNorm forward's time).  It only filters: once the record holds the tensor's typical
+// maximum almost no wave issues the atomic (thousands of waves hitting one address would serialise); a stale value costs a few atomics.
+__device__ __forceinline__ float q_amax_peek(const float* q) { return q ? q[AVS_Q_AMAX] : 0.f; }
+
+__device__ __forceinline__ void q_amax_update(float* q, float m, float seen) {
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) {
-        const float cur = __hip_atomic_load(q + AVS_Q_AMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (m > cur) atomicMax(reinterpret_cast<int*>(q + AVS_Q_AMAX), __float_as_int(m));      // non-negative floats order like their bits
-    }
+    if ((threadIdx.x & 63) == 0 && m > seen) atomicMax(reinterpret_cast<int*>(q + AVS_Q_AMAX), __float_as_int(m));      // non-negative floats order like their bits
 }
 
 // ---- raw inputs: the arithmetic of the reference's dataset (/root/reference/src/dataloader.py:505-513

@@ -418,6 +418,7 @@ __global__ void absmax_kernel(const void* __restrict__ x, int is_f32, size_t n8,
 __global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint8_t* __restrict__ y, size_t n4, float scale_host, float* q, int e5m2) {
     // q (device record, common.h AVS_Q_*; may be NULL): the scale comes from q[0] and the largest |x| seen is folded into q[2]
     const float scale = q ? q[AVS_Q_SCALE] : scale_host;
+    const float amax_seen = q_amax_peek(q);
     float m = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float v[4];
@@ -443,7 +444,7 @@ __global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint
         }
         reinterpret_cast<int*>(y)[i] = w;
     }
-    if (q) q_amax_update(q, m);
+    if (q) q_amax_update(q, m, amax_seen);
 }
 
 // Delayed scaling (engine.FP8): per record s in [0, n): the amax gathered since the last update goes into the history ring

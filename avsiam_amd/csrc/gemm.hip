@@ -222,6 +222,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         constexpr int AG = EpiPrefetch<MI>::AG, NG = MI / AG;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
         const float q8s = (Q8 != 0 && a.out8) ? (a.q8 ? a.q8[AVS_Q_SCALE] : a.out8_scale) : 0.f;
+        const float q8seen = q_amax_peek((Q8 != 0 && a.out8) ? a.q8 : nullptr);
         float q8max = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -293,7 +294,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                 }
             }
         }
-        if (Q8 != 0 && a.out8 && a.q8) q_amax_update(a.q8, q8max);
+        if (Q8 != 0 && a.out8 && a.q8) q_amax_update(a.q8, q8max, q8seen);
         if (colsum) {
             // lanes with the same (lane & 7) hold the same 8 columns for different rows: fold the 8 row groups, then one
             // atomic per column and wave (fp32 atomics, like the weight gradients)

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     // one more byte per element written here instead of a quantising pass that reads two and writes one.  q8_dev (device record,
     // common.h AVS_Q_*; may be NULL): the scale comes from it and the row's max |y| is folded into its running amax (delayed scaling)
     const float q8 = (y8 && q8_dev) ? q8_dev[AVS_Q_SCALE] : q8_host;
+    const float amax_seen = q_amax_peek(y8 ? q8_dev : nullptr);
     float ymax = 0.f;
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         mean_out[row] = mean;
         rstd_out[row] = rs;
     }
-    if (!F32IO && y8 && q8_dev) q_amax_update(q8_dev, ymax);
+    if (!F32IO && y8 && q8_dev) q_amax_update(q8_dev, ymax, amax_seen);
 }
 
 // Backward.  dx = dres + rstd * (gy - mean(gy) - xhat * mean(gy * xhat)),  gy = dy * gamma.
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     // consumes dx - with max |dx| folded into the device record q8 (common.h AVS_Q_*)
     constexpr int D = NV * 256;
     const float q8s = dx8 ? q8[AVS_Q_SCALE] : 0.f;
+    const float amax_seen = q_amax_peek(dx8 ? q8 : nullptr);
     float dmax = 0.f;
     constexpr int LN_ROWS_PER_BLOCK = 4 * LN_ROWS_PER_WAVE;
     __shared__ float red[4][D];
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             }
         }
     }
-    if (dx8) q_amax_update(q8, dmax);
+    if (dx8) q_amax_update(q8, dmax, amax_seen);
     // cross-wave reduction of the five accumulator sets, one set at a time through LDS
     float* slab = ws + (size_t)blockIdx.x * LN_SETS * D;
 #pragma unroll

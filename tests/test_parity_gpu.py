@@ -315,6 +315,9 @@ def test_fp8_forward_mode_against_bf16(which):
 #   gradients, every live tensor: cosine >= 0.975 (measured >= 0.9919), norm within 25 % (measured <= 8.3 %: at batch 2-3 a small error of
 #   the 3 x 3 InfoNCE logits rescales the WHOLE contrastive gradient - direction 0.997, length +8 %; the MAE pass stays within 2.8 %)
 FP8_LOSS_RTOL, FP8_LOGITS_ATOL, FP8_COS_MIN, FP8_RATIO_TOL = 5e-3, 0.12, 0.975, 0.25
+# mode "2" (e5m2 gradient operands in the fc2 / fc1 / proj input-gradient GEMMs: 2 mantissa bits): losses and logits as above (the forward is
+# the same); gradients cosine >= 0.92 (measured >= 0.971 contrastive, >= 0.986 MAE), norm within 30 % (fp8bwd_oracle_* in the margins file)
+FP8B_COS_MIN, FP8B_RATIO_TOL = 0.92, 0.30
 
 
 @pytest.mark.parametrize("which", ["mae", "contrastive"])
@@ -357,7 +360,8 @@ def test_fp8_forward_mode_against_oracle(shape, which, mode):
                 err = float((eng.total.detach().cpu().double() - extras["logits"].detach().double()).abs().max())
                 record_margin(tag, logits_abs=err)
                 assert err <= FP8_LOGITS_ATOL, err
-            _compare_grads(m, rgrads, cos_min=FP8_COS_MIN, ratio_tol=FP8_RATIO_TOL, tag=tag)
+            _compare_grads(m, rgrads, cos_min=FP8_COS_MIN if mode == "1" else FP8B_COS_MIN, ratio_tol=FP8_RATIO_TOL if mode == "1" else FP8B_RATIO_TOL,
+                           tag=tag)
     finally:
         engine.FP8 = "0"
 
