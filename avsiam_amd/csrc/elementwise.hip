@@ -448,7 +448,7 @@ __global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint
 }
 
 // Delayed scaling (engine.FP8): per record s in [0, n): the amax gathered since the last update goes into the history ring
-// hist[pos][s], the scale becomes 448 / (margin * max over the ring), the running amax restarts at 0, and the saturation counter
+// hist[pos][s], the scale becomes fmax / (margin * max over the ring), the running amax restarts (at 0.9 x itself), and the saturation counter
 // advances when the values just quantised exceeded the range of the scale they were quantised with.  One thread per record.
 __global__ void fp8_scale_update_kernel(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax) {
     const int s = first + blockIdx.x * blockDim.x + threadIdx.x;
@@ -464,7 +464,10 @@ __global__ void fp8_scale_update_kernel(float* q, float* hist, int n, int nhist,
         r[AVS_Q_SCALE] = ns;
         r[AVS_Q_INV] = 1.0f / ns;
     }
-    r[AVS_Q_AMAX] = 0.f;
+    // the running amax restarts at 0.9 x what was just recorded, not at 0: producers filter their atomics against the value they read at
+    // kernel START (q_amax_peek) - from 0 every wave of the first kernel of a step would issue one (95 k atomics on one address: ~1 ms
+    // per LayerNorm launch) - and with the floor only rows near the tensor's maximum do.  The recorded amax can fall by 10 % per step.
+    r[AVS_Q_AMAX] = 0.9f * a;
 }
 
 extern "C" int avs_absmax(const void* x, int is_f32, long long n, float* out, hipStream_t stream) {

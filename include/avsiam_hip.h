@@ -75,7 +75,8 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
  * q = {scale, 1 / scale, running max |x| since the last update, saturation events}.  Where an entry point takes such a record
  * (qa / qw / qw2: operands of the GEMM, de-quantisation factor qa[1] * qw[1]; q8: the e4m3 copy a kernel writes - scale q8[0], amax into
  * q8[2]) it overrides the host float beside it.  avs_fp8_scale_update(q [n][4], hist [nhist][n], n, nhist, pos, margin, first, count, fmax): per
- * record in [first, first + count), hist[pos] = q[2]; scale = fmax / (margin * max over hist); q[2] = 0; q[3] += (q[2] * old scale > fmax);
+ * record in [first, first + count), hist[pos] = q[2]; scale = fmax / (margin * max over hist); q[2] *= 0.9 (the floor the producers filter their atomics against);
+ * q[3] += (q[2] * old scale > fmax);
  * fmax = 448 (e4m3 tensors) or 57344 (e5m2: the gradient operands of the input-gradient form).
  * Input-gradient form (a_e5m2 != 0; BASELINE configs[4]'s fp8 path in the backward): A holds e5m2 gradients, B the e4m3 transposed weight;
  * act 0, or act 2 with aux / colsum as in avs_gemm_nt_bf16 (fc2 input gradient); out8 (may be NULL) = e5m2(out * q8[0]) for the next one.
