@@ -488,6 +488,48 @@ extern "C" int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long
     return 0;
 }
 
+// One launch quantises MANY bf16 tensors (all weights of a stack, once per forward: the per-GEMM quantising passes were ~800 launches
+// of a few microseconds each per step).  desc[d] = {src (bf16), dst (u8), numel / 4, record index}; chunk c of 8192 elements belongs to
+// descriptor cmap[2c] and starts at 4-element group cmap[2c + 1]; the scale comes from q[record], the |max| seen is folded into it.
+__global__ __launch_bounds__(256) void quantize_fp8_batched_kernel(const long long* __restrict__ desc, const int* __restrict__ cmap, float* q, int e5m2) {
+    const int d = cmap[2 * blockIdx.x];
+    const size_t g0 = (size_t)cmap[2 * blockIdx.x + 1];
+    const uint2* src = reinterpret_cast<const uint2*>(desc[4 * d]);
+    int* dst = reinterpret_cast<int*>(desc[4 * d + 1]);
+    const size_t n4 = (size_t)desc[4 * d + 2];
+    float* rec = q + 4 * desc[4 * d + 3];
+    const float scale = rec[AVS_Q_SCALE], seen = rec[AVS_Q_AMAX];
+    const float lim = e5m2 ? 57344.0f : 448.0f;
+    float m = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const size_t i = g0 + (size_t)it * 256 + threadIdx.x;
+        if (i >= n4) break;
+        const uint2 u = src[i];
+        float v[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j] * scale, -lim, lim);
+        int w;
+        if (e5m2) {
+            w = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w, true);
+        } else {
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+        }
+        dst[i] = w;
+    }
+    q_amax_update(rec, m, seen);
+}
+
+extern "C" int avs_quantize_fp8_batched(const long long* desc, const int* cmap, int nchunks, float* q, int e5m2, hipStream_t stream) {
+    AVS_CHECK_ARG(desc && cmap && q && nchunks > 0, "quantize_fp8_batched: bad args");
+    quantize_fp8_batched_kernel<<<nchunks, 256, 0, stream>>>(desc, cmap, q, e5m2);
+    AVS_LAUNCH_CHECK("quantize_fp8_batched");
+    return 0;
+}
+
 extern "C" int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax, hipStream_t stream) {
     AVS_CHECK_ARG(fmax == 448.0f || fmax == 57344.0f, "fp8_scale_update: fmax is 448 (e4m3) or 57344 (e5m2)");
     AVS_CHECK_ARG(q && hist && n > 0 && nhist > 0 && pos >= 0 && pos < nhist && margin >= 1.0f && first >= 0 && count > 0 && first + count <= n,

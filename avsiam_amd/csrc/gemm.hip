@@ -48,6 +48,7 @@ struct GemmNtArgs {
     // operands' records - the de-quantisation factor is qa[INV] * qw[INV] (qw2 for rows from m_split); q8: the record of out8 - its
     // scale is read from it and the largest |gelu(x)| written is folded into its running amax
     const float* qa; const float* qw; const float* qw2; float* q8;
+    float q8_seen;                           // set by the kernel: the amax q8 held at kernel start (filter of the epilogue's atomic)
 };
 
 
@@ -221,8 +222,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         const unsigned raddr = stg_lds + (rq * 68 + cc) * 4, baddr = sbias_lds + cc * 4;      // rows rq and rq + 8: 2176 B apart
         constexpr int AG = EpiPrefetch<MI>::AG, NG = MI / AG;
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's 8 columns, summed over the rows it handles
-        const float q8s = (Q8 != 0 && a.out8) ? (a.q8 ? a.q8[AVS_Q_SCALE] : a.out8_scale) : 0.f;
-        const float q8seen = q_amax_peek((Q8 != 0 && a.out8) ? a.q8 : nullptr);
+        const float q8s = (Q8 != 0 && a.out8) ? a.out8_scale : 0.f;          // (with a record: its scale, read by the kernel at its start)
+        const float q8seen = a.q8_seen;
         float q8max = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -487,6 +488,23 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
     const int off_k1 = fr * 128 + (((FP8 ? 2 * fq + 1 : 4 + fq) ^ (lane & 7)) << 4);
     const int nk = a.K / BK;
     const unsigned lds_base = (unsigned)(size_t)(LDS_AS const char*)smem;
+    // fp8 with device records: the de-quantisation factors (one per weight set), the scale of the e4m3 / e5m2 output copy and the amax
+    // that record already holds are read ONCE, here, before any LDS-DMA is in flight, and kept in scalar registers - read in front of the
+    // epilogue (vector loads: the compiler cannot prove the records invariant) they were waited for with vmcnt(0) beside the next
+    // tile's DMAs, i.e. every epilogue waited for the next tile's first K-tile to land
+    float dq_a = a.alpha, dq_b = a.alpha, q8_scale = a.out8_scale, q8_seen = 0.f;
+    if (FP8) {
+        if (a.qa) {
+            const float ia = a.qa[AVS_Q_INV];
+            dq_a = ia * a.qw[AVS_Q_INV];
+            dq_b = ia * a.qw2[AVS_Q_INV];
+        }
+        if (a.out8 && a.q8) { q8_scale = a.q8[AVS_Q_SCALE]; q8_seen = a.q8[AVS_Q_AMAX]; }
+        dq_a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dq_a)));
+        dq_b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dq_b)));
+        q8_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q8_scale)));
+        q8_seen = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q8_seen)));
+    }
 
     // DMA bookkeeping.  Granule-local chunk p = j*512 + tid (j = 0,1): local row lr = p >> 3, slot p & 7, source chunk
     // (p & 7) ^ (lr & 7).  A granules: physical row = h*128 + lr; B granules: physical row = (lr>>5)*64 + h*32 + (lr&31).
@@ -674,13 +692,15 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
 #else
         if (FP8) {
             // the de-quantisation factor belongs to the product alone (the shared epilogue's alpha also scales bias and residual)
-            const float dq = a.qa ? a.qa[AVS_Q_INV] * (m0 >= a.m_split ? a.qw2 : a.qw)[AVS_Q_INV] : a.alpha;
+            const float dq = m0 >= a.m_split ? dq_b : dq_a;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < MI; ++j) acc[i][j] *= dq;
             GemmNtArgs e = a;
             e.alpha = 1.0f;
+            e.out8_scale = q8_scale;            // the epilogue takes the record's scale / amax filter from here, not from memory
+            e.q8_seen = q8_seen;
             nt_epilogue<ACT, MI, FP8>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
         } else {
             nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
@@ -1033,7 +1053,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt: the residual add is implemented for fp32 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M,
-                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr};
+                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr, 0.f};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;
@@ -1155,7 +1175,7 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
     GemmNtArgs a{reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, M, N, K / 2, bias, res, ldr, nullptr, aux, ldaux,
                  out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M, dual ? m_split : 0x7fffffff,
                  dual ? reinterpret_cast<const bf16_t*>(B2) : nullptr, dual ? bias2 : nullptr, dual ? colsum2 : nullptr,
-                 out8, ldo8, out8_scale, qa, qw, dual ? qw2 : qw, q8};
+                 out8, ldo8, out8_scale, qa, qw, dual ? qw2 : qw, q8, 0.f};
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;

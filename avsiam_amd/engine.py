@@ -209,7 +209,13 @@ class Stack:
         if self.fp8:
             r8 = ops.pad_rows(rows, 256)
             self.a8 = torch.zeros((r8, max(D, hidden)), dtype=U8, device=dev)      # calibration step only: an activation quantised by a pass
-            self.w8 = [torch.empty((max(3 * D, hidden) * max(D, hidden),), dtype=U8, device=dev) for _ in range(2)]   # the GEMM's weight (two sets)
+            # persistent e4m3 copies of the stack's weights (two sets: the MAE pass's second tower), re-quantised with the step's scales by
+            # ONE batched launch per forward once every GEMM is calibrated (ops.Fp8Batch); per block: qkv | proj | fc1 | fc2
+            per_blk = 4 * D * D + 2 * D * hidden
+            self.w8_flat = torch.zeros((2 * nblocks * per_blk,), dtype=U8, device=dev)
+            self.w8_off = {"qkv": 0, "proj": 3 * D * D, "fc1": 4 * D * D, "fc2": 4 * D * D + D * hidden}
+            self.w8_per_blk = per_blk
+            self.w8_batch = None                                                   # built after the calibration forward
             self.ln8 = torch.zeros((r8, D), dtype=U8, device=dev)                  # e4m3 copy a LayerNorm writes for qkv / fc1
             self.att8 = torch.zeros((r8, D), dtype=U8, device=dev)                 # ... the attention epilogue for proj
             self.act8 = torch.zeros((r8, hidden), dtype=U8, device=dev)            # ... and fc1's GELU epilogue for fc2
@@ -220,7 +226,11 @@ class Stack:
             self.g8_seen, self.g8_have = set(), set()
             self.dx8 = [torch.zeros((r8, D), dtype=U8, device=dev) for _ in range(2)]      # e5m2 copies of dbo / dbm
             self.dfc1_8 = torch.zeros((r8, hidden), dtype=U8, device=dev)
-            self.wt8 = [torch.empty((hidden * D,), dtype=U8, device=dev) for _ in range(2)]
+            per_blk_t = D * D + 2 * D * hidden                                    # transposed copies the fp8 input-gradient GEMMs read: fc2 | fc1 | proj
+            self.wt8_flat = torch.zeros((2 * nblocks * per_blk_t,), dtype=U8, device=dev)
+            self.wt8_off = {"fc2": 0, "fc1": D * hidden, "proj": 2 * D * hidden}
+            self.wt8_per_blk = per_blk_t
+            self.wt8_batch = None
         rp = ops.pad_rows(rows, 128)
         self.rp = rp
         # rows per attention workgroup (4 or 2 waves of 32 queries / keys), by the mean sequence length of the stack - measured on the
@@ -290,6 +300,16 @@ class Stack:
         (ops.gemm_nt(dual=...)), the LayerNorm picks the affine per row (row_mod: 0 below split, 1 from it)."""
         if self.fp8:
             self.f8.update()                   # delayed scaling: last forward's amax -> history -> this forward's scales (one launch)
+            nsets = 2 if blocks2 is not None else 1
+            if self.w8_batch is None and len(self.f8_seen) == 4 * self.nblocks:      # every GEMM calibrated: freeze the weight table
+                self.w8_batch = ops.Fp8Batch(self.f8)
+                for i, bp in enumerate(blocks):
+                    for name in ("qkv", "proj", "fc1", "fc2"):
+                        for st_, bl in enumerate((bp, blocks2[i] if blocks2 is not None else None)[:nsets]):
+                            self.w8_batch.add(getattr(bl, name).w, self._w8(i, name, st_), (i * 4 + self._G8[name]) * 3 + 1 + st_)
+                self.w8_batch.build(self.x[0].device)
+            if self.w8_batch is not None:
+                self.w8_batch.run()            # all weights of the stack -> e4m3 with this step's scales (one launch)
         for i, bp in enumerate(blocks):
             self._block_forward(i, bp, blocks2[i] if blocks2 is not None else None, split)
 
@@ -297,6 +317,20 @@ class Stack:
 
     def _rec(self, i, name, operand=0):
         return self.f8.rec((i * 4 + self._G8[name]) * 3 + operand)
+
+    def _w8(self, i, name, which=0):
+        """persistent e4m3 copy [N, K] of block i's weight `name` (which: weight set 0 / 1)"""
+        D, Hd = self.D, self.hidden
+        N, K = {"qkv": (3 * D, D), "proj": (D, D), "fc1": (Hd, D), "fc2": (D, Hd)}[name]
+        o = (which * self.nblocks + i) * self.w8_per_blk + self.w8_off[name]
+        return self.w8_flat[o:o + N * K].view(N, K)
+
+    def _wt8(self, i, name, which=0):
+        """persistent e4m3 copy of the TRANSPOSED weight (B operand [K_in, N_out] of the input-gradient GEMM)"""
+        D, Hd = self.D, self.hidden
+        N, K = {"fc2": (Hd, D), "fc1": (D, Hd), "proj": (D, D)}[name]
+        o = (which * self.nblocks + i) * self.wt8_per_blk + self.wt8_off[name]
+        return self.wt8_flat[o:o + N * K].view(N, K)
 
     def _block_forward(self, i, bp, b2, split, last_gemm=True):
         """Block i: x[i] -> x[i + 1] and everything its backward reads.  last_gemm=False (recompute in front of the backward): x[i + 1]
@@ -355,13 +389,13 @@ class Stack:
             self.f8_seen.add((i, name))
             a8 = self.a8[:A.shape[0], :K] if self.a8.shape[1] == K else self.a8.view(-1)[:A.shape[0] * K].view(A.shape[0], K)
             ops.quantize_fp8(A, 1.0, out=a8, q=ra)
-        w8 = self.w8[0][:N * K].view(N, K)
-        ops.quantize_fp8(W, 1.0, out=w8, q=rw)
-        dual = None
-        if W2 is not None:
-            w8b = self.w8[1][:N * K].view(N, K)
-            ops.quantize_fp8(W2, 1.0, out=w8b, q=rw2)
-            dual = (split, w8b, lin2.b, rw2)
+        w8 = self._w8(i, name, 0)
+        w8b = self._w8(i, name, 1) if W2 is not None else None
+        if self.w8_batch is None:                  # until the table exists (calibration forward): one quantising pass per weight
+            ops.quantize_fp8(W, 1.0, out=w8, q=rw)
+            if W2 is not None:
+                ops.quantize_fp8(W2, 1.0, out=w8b, q=rw2)
+        dual = (split, w8b, lin2.b, rw2) if W2 is not None else None
         ops.gemm_nt_fp8(a8, w8, out, M, bias=lin.b, qa=ra, qw=rw, dual=dual, **kw)
 
     def _dgrad_fp8(self, i, gname, wname, A, a8, lin, lin2, split, out, colsum2=None, **kw):
@@ -378,16 +412,18 @@ class Stack:
             self.g8_seen.add((i, gname))
         if (i, gname) not in self.g8_have:
             ops.quantize_fp8(A, 1.0, out=a8[:A.shape[0]], q=rec, e5m2=True)
-        Wt = lin.wt
-        N, K = Wt.shape
         rw, rw2 = self._rec(i, wname, 1), self._rec(i, wname, 2)
-        w8 = self.wt8[0][:N * K].view(N, K)
-        ops.quantize_fp8(Wt, 1.0, out=w8, q=rw)
-        dual = None
-        if lin2 is not None:
-            w8b = self.wt8[1][:N * K].view(N, K)
-            ops.quantize_fp8(lin2.wt, 1.0, out=w8b, q=rw2)
-            dual = (split, w8b, None, rw2, colsum2)
+        w8 = self._wt8(i, wname, 0)
+        w8b = self._wt8(i, wname, 1) if lin2 is not None else None
+        if self.wt8_batch is None:                 # first backward: per-weight passes, and the table for the batched launch is collected
+            pend = self.__dict__.setdefault("_wt8_pending", [])
+            base = (i * 4 + self._G8[wname]) * 3
+            ops.quantize_fp8(lin.wt, 1.0, out=w8, q=rw)
+            pend.append((lin.wt, w8, base + 1))
+            if lin2 is not None:
+                ops.quantize_fp8(lin2.wt, 1.0, out=w8b, q=rw2)
+                pend.append((lin2.wt, w8b, base + 2))
+        dual = (split, w8b, None, rw2, colsum2) if lin2 is not None else None
         ops.gemm_nt_fp8(a8, w8, out, M, qa=rec, qw=rw, grad=True, dual=dual, **kw)
 
     def fp8_state(self):
@@ -457,6 +493,13 @@ class Stack:
         if f8b:
             self.g8.update()                   # delayed scaling of the gradient operands: last backward's amax -> this backward's scales
             self.g8_have = set()               # (block, operand) whose e5m2 copy a producer has written in this backward
+            if self.wt8_batch is None and getattr(self, "_wt8_pending", None) is not None and len(self._wt8_pending) == 3 * self.nblocks * (2 if blocks2 is not None else 1):
+                self.wt8_batch = ops.Fp8Batch(self.f8)      # the transposed copies use the forward's weight records (the same tensors)
+                for src, dst, ridx in self._wt8_pending:
+                    self.wt8_batch.add(src, dst, ridx)
+                self.wt8_batch.build(dxo.device)
+            if self.wt8_batch is not None:
+                self.wt8_batch.run()
         G8 = {"dbo": 0, "dfc1": 1, "dbm": 2}
 
         def g8rec(blk, name):                  # (e5m2 buffer, record) of a gradient operand once calibrated, else (None, None)

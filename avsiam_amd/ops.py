@@ -257,6 +257,34 @@ def quantize_fp8(x, scale, out=None, q=None, e5m2=False):
     return y
 
 
+class Fp8Batch:
+    """Quantise many bf16 tensors (a stack's weights) into their persistent fp8 copies with ONE launch: entries (src bf16, dst u8,
+    record index into `records`); build() freezes the table.  The tensors must stay where they are (arena views do)."""
+
+    def __init__(self, records, e5m2=False):
+        self.records, self.e5m2 = records, e5m2
+        self.entries, self.keep = [], []
+        self.desc = self.cmap = None
+
+    def add(self, src, dst, rec_index):
+        assert self.desc is None, "table already built"
+        _chk(src, BF16, "fp8batch.src"); _chk(dst, U8, "fp8batch.dst")
+        assert src.numel() == dst.numel() and src.numel() % 4 == 0 and 0 <= rec_index < self.records.n
+        self.entries.append((src.data_ptr(), dst.data_ptr(), src.numel() // 4, int(rec_index)))
+        self.keep.append((src, dst))
+
+    def build(self, dev):
+        cmap = []
+        for d, (_, _, n4, _) in enumerate(self.entries):
+            cmap += [[d, g] for g in range(0, n4, 2048)]
+        self.desc = torch.tensor(self.entries, dtype=torch.int64, device=dev)
+        self.cmap = torch.tensor(cmap, dtype=I32, device=dev)
+        self.nchunks = len(cmap)
+
+    def run(self):
+        _lib.call("avs_quantize_fp8_batched", self.desc, self.cmap, self.nchunks, self.records.q, 1 if self.e5m2 else 0, _stream())
+
+
 def gemm_nt_fp8(A8, B8, out, M, alpha=1.0, bias=None, res=None, out2=None, act=0, scale_cols=0, col_scale=1.0, out8=None, out8_scale=1.0,
                 qa=None, qw=None, q8=None, dual=None, grad=False, aux=None, colsum=None):
     """x = alpha * (A8[M, K] @ B8[N, K]^T) + bias (+ res); act 0: out = x; act 1: out = gelu'(x), out2 = gelu(x) (like gemm_nt).
