@@ -453,8 +453,13 @@ __global__ void quantize_fp8_kernel(const void* __restrict__ x, int is_f32, uint
 __global__ void fp8_scale_update_kernel(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax) {
     const int s = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= first + count) return;
-    float* r = q + 4 * (size_t)s;
-    const float a = r[AVS_Q_AMAX], sc = r[AVS_Q_SCALE];
+    float* r = q + AVS_Q_STRIDE * (size_t)s;
+    float a = r[AVS_Q_AMAX];
+    for (int k = 0; k < AVS_Q_NSHARD; ++k) {                   // the producers' shards (common.h)
+        a = fmaxf(a, r[AVS_Q_SHARD0 + k]);
+        r[AVS_Q_SHARD0 + k] = 0.f;
+    }
+    const float sc = r[AVS_Q_SCALE];
     if (sc > 0.f && a * sc > fmax) r[AVS_Q_SAT] += 1.0f;
     hist[(size_t)pos * n + s] = a;
     float m = 0.f;
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256) void quantize_fp8_batched_kernel(const long lo
     const uint2* src = reinterpret_cast<const uint2*>(desc[4 * d]);
     int* dst = reinterpret_cast<int*>(desc[4 * d + 1]);
     const size_t n4 = (size_t)desc[4 * d + 2];
-    float* rec = q + 4 * desc[4 * d + 3];
+    float* rec = q + AVS_Q_STRIDE * desc[4 * d + 3];
     const float scale = rec[AVS_Q_SCALE], seen = rec[AVS_Q_AMAX];
     const float lim = e5m2 ? 57344.0f : 448.0f;
     float m = 0.f;

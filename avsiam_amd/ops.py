@@ -185,12 +185,15 @@ FP8_MAX = 448.0          # largest finite OCP e4m3 value
 BF8_MAX = 57344.0        # ... and OCP e5m2 (the gradient operands of the fp8 input-gradient GEMMs)
 
 
+Q_STRIDE = 64            # floats per device quantisation record (csrc/common.h AVS_Q_STRIDE): scale, 1 / scale, amax floor, saturation events, 60 amax shards
+
+
 def _qrec(q):
-    """a device quantisation record (fp32 [4]: scale, 1 / scale, running amax, saturation events; csrc/common.h AVS_Q_*) or None"""
+    """a device quantisation record (fp32 [64]: scale, 1 / scale, running amax, saturation events, amax shards; csrc/common.h AVS_Q_*) or None"""
     if q is None:
         return None
-    if not (q.is_cuda and q.dtype == F32 and q.numel() == 4 and q.is_contiguous()):
-        raise _lib.AvsiamHipError("fp8 record: need a contiguous fp32 GPU tensor of 4 elements")
+    if not (q.is_cuda and q.dtype == F32 and q.numel() == Q_STRIDE and q.is_contiguous()):
+        raise _lib.AvsiamHipError(f"fp8 record: need a contiguous fp32 GPU tensor of {Q_STRIDE} elements")
     return q
 
 
@@ -202,11 +205,15 @@ class Fp8Records:
     def __init__(self, n, dev, nhist=16, margin=2.0, fmax=FP8_MAX):
         """fmax: largest finite value of the format these tensors are quantised to - 448 (e4m3) or 57344 (e5m2, gradients)"""
         self.n, self.nhist, self.margin, self.pos, self.fmax = n, nhist, margin, 0, float(fmax)
-        self.q = torch.zeros((n, 4), dtype=F32, device=dev)
+        self.q = torch.zeros((n, Q_STRIDE), dtype=F32, device=dev)
         self.hist = torch.zeros((nhist, n), dtype=F32, device=dev)
 
     def rec(self, i):
         return self.q[i]
+
+    def amax(self, i):
+        """the amax gathered since the last update (synchronises: tests)"""
+        return float(torch.cat([self.q[i, 2:3], self.q[i, 4:]]).max().item())
 
     def update(self, first=0, count=None):
         """count None: the whole table, and the history ring advances (once per forward).  A sub-range (calibration of tensors seen
