@@ -116,12 +116,14 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 #define AVS_Q_INV 1
 #define AVS_Q_AMAX 2
 #define AVS_Q_SAT 3
-// A record is AVS_Q_STRIDE floats: the four above and AVS_Q_NSHARD shards of the running amax.  Producers fold their |max| into ONE shard,
+// A record is AVS_Q_STRIDE floats: the four above (one 256-byte line) and AVS_Q_NSHARD shards of the running amax.  Producers fold their |max| into ONE shard,
 // picked by workgroup (tens of thousands of waves adding to a single address serialise at the memory side: the LayerNorm forward took
 // 5x its time that way when most rows carry a value near the tensor's maximum); avs_fp8_scale_update takes the max over [2] and the shards.
-#define AVS_Q_STRIDE 64
-#define AVS_Q_SHARD0 4
-#define AVS_Q_NSHARD 60
+// Each shard sits in a 256-byte line of its own (same-line atomics still serialise at one memory channel).
+#define AVS_Q_NSHARD 15
+#define AVS_Q_SHARD_STRIDE 64                                   // floats between shards
+#define AVS_Q_SHARD0 64                                         // first shard: the line after the header
+#define AVS_Q_STRIDE (64 * (1 + AVS_Q_NSHARD))
 
 // fold a wave's max |x| (m >= 0, any lane's value; reduced here) into q[AVS_Q_AMAX].  `seen` = q[AVS_Q_AMAX] as read by q_amax_peek at the
 // START of the kernel (a plain load whose latency hides under the kernel's work; a load here, at the end, was a dependent memory round
@@ -132,7 +134,7 @@ __device__ __forceinline__ float q_amax_peek(const float* q) { return q ? q[AVS_
 __device__ __forceinline__ void q_amax_update(float* q, float m, float seen) {
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0 && m > seen)      // non-negative floats order like their bits
-        atomicMax(reinterpret_cast<int*>(q + AVS_Q_SHARD0 + (blockIdx.x + (threadIdx.x >> 6)) % AVS_Q_NSHARD), __float_as_int(m));
+        atomicMax(reinterpret_cast<int*>(q + AVS_Q_SHARD0 + ((blockIdx.x + (threadIdx.x >> 6)) % AVS_Q_NSHARD) * AVS_Q_SHARD_STRIDE), __float_as_int(m));
 }
 
 // ---- raw inputs: the arithmetic of the reference's dataset (/root/reference/src/dataloader.py:505-513

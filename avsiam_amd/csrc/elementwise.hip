@@ -456,8 +456,8 @@ __global__ void fp8_scale_update_kernel(float* q, float* hist, int n, int nhist,
     float* r = q + AVS_Q_STRIDE * (size_t)s;
     float a = r[AVS_Q_AMAX];
     for (int k = 0; k < AVS_Q_NSHARD; ++k) {                   // the producers' shards (common.h)
-        a = fmaxf(a, r[AVS_Q_SHARD0 + k]);
-        r[AVS_Q_SHARD0 + k] = 0.f;
+        a = fmaxf(a, r[AVS_Q_SHARD0 + k * AVS_Q_SHARD_STRIDE]);
+        r[AVS_Q_SHARD0 + k * AVS_Q_SHARD_STRIDE] = 0.f;
     }
     const float sc = r[AVS_Q_SCALE];
     if (sc > 0.f && a * sc > fmax) r[AVS_Q_SAT] += 1.0f;

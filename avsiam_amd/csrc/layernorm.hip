@@ -10,7 +10,9 @@
 #include "common.h"
 #include <stdlib.h>
 
-template <int NV, bool F32IO>
+// RPW: rows per wave (1; 8 when the e4m3 copy is written with a device record: the wave then folds the max over its rows into the
+// record with ONE atomic instead of one per row - 95 k atomics per launch on a handful of addresses cost more than the kernel itself)
+template <int NV, bool F32IO, int RPW = 1>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g0,
                                                      const float* __restrict__ b0, const float* __restrict__ g1,
                                                      const float* __restrict__ b1, const uint8_t* __restrict__ row_mod,
@@ -25,8 +27,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     float ymax = 0.f;
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+#pragma unroll 1
+    for (int row = row0; row < min(rows, row0 + RPW); ++row) {
     // the row's modality and output row are requested FIRST and the affine rows before the statistics: loaded where they are
     // used (after the two reductions) they formed a chain of three dependent memory round trips behind the row itself
     const int mod = row_mod ? row_mod[row] : 0;
@@ -75,6 +79,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (lane == 0) {
         mean_out[row] = mean;
         rstd_out[row] = rs;
+    }
     }
     if (!F32IO && y8 && q8_dev) q_amax_update(q8_dev, ymax, amax_seen);
 }
@@ -239,12 +244,16 @@ extern "C" int avs_layernorm_fwd_q8(const float* x, const float* g0, const float
     AVS_CHECK_ARG(!row_mod || (g1 && b1), "layernorm_fwd: row_mod given without second affine set");
     dim3 grid(ceil_div(rows, 4)), block(256);
 #define LN_FWD(NV, F) ln_fwd_kernel<NV, F><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps, y8, q8, q8_dev)
-    if (y_f32) {
+#define LN_FWD8(NV) ln_fwd_kernel<NV, false, 8><<<dim3(ceil_div(rows, 32)), block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps, y8, q8, q8_dev)
+    if (y8 && q8_dev) {                                   // e4m3 copy with a record: 8 rows per wave, one amax atomic per wave
+        if (D == 512) LN_FWD8(2); else if (D == 768) LN_FWD8(3); else if (D == 1024) LN_FWD8(4); else if (D == 1280) LN_FWD8(5); else LN_FWD8(6);
+    } else if (y_f32) {
         if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else if (D == 1024) LN_FWD(4, true); else if (D == 1280) LN_FWD(5, true); else LN_FWD(6, true);
     } else {
         if (D == 512) LN_FWD(2, false); else if (D == 768) LN_FWD(3, false); else if (D == 1024) LN_FWD(4, false); else if (D == 1280) LN_FWD(5, false); else LN_FWD(6, false);
     }
 #undef LN_FWD
+#undef LN_FWD8
     AVS_LAUNCH_CHECK("layernorm_fwd");
     return 0;
 }

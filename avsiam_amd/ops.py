@@ -185,11 +185,12 @@ FP8_MAX = 448.0          # largest finite OCP e4m3 value
 BF8_MAX = 57344.0        # ... and OCP e5m2 (the gradient operands of the fp8 input-gradient GEMMs)
 
 
-Q_STRIDE = 64            # floats per device quantisation record (csrc/common.h AVS_Q_STRIDE): scale, 1 / scale, amax floor, saturation events, 60 amax shards
+Q_STRIDE = 1024          # floats per device quantisation record (csrc/common.h AVS_Q_STRIDE): a 256-byte header line (scale, 1 / scale, amax
+                         # floor, saturation events) + 15 amax shards, each in a 256-byte line of its own
 
 
 def _qrec(q):
-    """a device quantisation record (fp32 [64]: scale, 1 / scale, running amax, saturation events, amax shards; csrc/common.h AVS_Q_*) or None"""
+    """a device quantisation record (fp32 [1024]: scale, 1 / scale, running amax, saturation events | 15 amax shards; csrc/common.h AVS_Q_*) or None"""
     if q is None:
         return None
     if not (q.is_cuda and q.dtype == F32 and q.numel() == Q_STRIDE and q.is_contiguous()):
@@ -213,7 +214,7 @@ class Fp8Records:
 
     def amax(self, i):
         """the amax gathered since the last update (synchronises: tests)"""
-        return float(torch.cat([self.q[i, 2:3], self.q[i, 4:]]).max().item())
+        return float(torch.cat([self.q[i, 2:3], self.q[i, 64::64]]).max().item())
 
     def update(self, first=0, count=None):
         """count None: the whole table, and the history ring advances (once per forward).  A sub-range (calibration of tensors seen

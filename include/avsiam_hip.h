@@ -71,11 +71,11 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
  * fp32 accumulation on v_mfma_f32_16x16x128_f8f6f4,
  * the 8-phase 256x256 kernel of the bf16 GEMM with 128-value K-tiles.  alpha carries 1 / (scale_A * scale_B).  N%256==0, K%128==0,
  * K>=256, leading dimensions multiples of 16.
- * Delayed scaling (no host synchronisation anywhere): a tensor's quantisation state is a DEVICE record of 64 floats
- * q = {scale, 1 / scale, running max |x| since the last update, saturation events, 60 shards of the running max (producers add to one
- * shard each: a single address would serialise their atomics)}.  Where an entry point takes such a record
+ * Delayed scaling (no host synchronisation anywhere): a tensor's quantisation state is a DEVICE record of 1024 floats:
+ * q[0..3] = {scale, 1 / scale, running max |x| since the last update, saturation events} and 15 shards of the running max at q[64 (1 + k)]
+ * (producers add to one shard each, every shard in a 256-byte line of its own: a single address would serialise their atomics).  Where an entry point takes such a record
  * (qa / qw / qw2: operands of the GEMM, de-quantisation factor qa[1] * qw[1]; q8: the e4m3 copy a kernel writes - scale q8[0], amax into
- * q8[2]) it overrides the host float beside it.  avs_fp8_scale_update(q [n][64], hist [nhist][n], n, nhist, pos, margin, first, count, fmax): per
+ * q8[2]) it overrides the host float beside it.  avs_fp8_scale_update(q [n][1024], hist [nhist][n], n, nhist, pos, margin, first, count, fmax): per
  * record in [first, first + count), hist[pos] = max(q[2], shards); scale = fmax / (margin * max over hist); q[2] *= 0.9 (the floor the producers filter their atomics against);
  * q[3] += (q[2] * old scale > fmax);
  * fmax = 448 (e4m3 tensors) or 57344 (e5m2: the gradient operands of the input-gradient form).
@@ -92,7 +92,7 @@ int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B, long long
 int avs_absmax(const void* x, int is_f32, long long n, float* out, avs_stream_t stream);
 int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float scale, float* q, int e5m2, avs_stream_t stream);
 /* many bf16 tensors in one launch (all weights of a stack, once per forward): desc [n][4] = {src, dst, numel / 4, record index}, cmap
- * [nchunks][2] = {descriptor, first 4-element group} per chunk of 8192 elements; scales from / amax into the records q [.][64] */
+ * [nchunks][2] = {descriptor, first 4-element group} per chunk of 8192 elements; scales from / amax into the records q [.][1024] */
 int avs_quantize_fp8_batched(const long long* desc, const int* cmap, int nchunks, float* q, int e5m2, avs_stream_t stream);
 int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax, avs_stream_t stream);
 /* the same GEMM over TWO weight sets in one launch: rows [0, m_split) of A meet B / bias / colsum, rows [m_split, M) meet
