@@ -4,10 +4,10 @@ the unmodified reference produced (tests/golden).
 
 Tolerances (bf16 GEMM/attention operands with fp32 accumulation vs an fp32 reference; north_star asks for a
 stated tolerance).  They are set at about 3x the worst error MEASURED on an MI355X and logged by these tests into
-profiles/r02/parity_margins.json (tests.helpers.record_margin):
+profiles/r03/parity_margins.json (tests.helpers.record_margin; round 3: with the bf16 residual-gradient stream):
   losses            rel 2e-3 (measured <= 5e-4; the constant-input golden case 1.8e-3 -> 6e-3)
   contrastive logits abs 0.01 (measured 1.7e-3 at tau = 0.05)
-  gradients, every live tensor: cosine >= 0.9998 (measured >= 0.99993), norm ratio within 1 % (measured <= 0.32 %; ViT-L 0.66 % -> 2 %)
+  gradients, every live tensor: cosine >= 0.9998 (measured >= 0.99990; ViT-L / ViT-H 0.99985), norm ratio within 1 % (measured <= 0.30 %; ViT-L 0.73 % -> 2 %)
   reference goldens, every live tensor: L2 norm within 1 % (0.29 %), the 8 sampled elements within 0.3 rms (0.10), the
   element sum within 2.0 / 0.25 norms (MAE / contrastive; 0.62 / 0.075 - the sum is a cancelling statistic, kept as a weak check)
   dead parameters get no gradient; masks are bit-exact."""
