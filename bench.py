@@ -301,6 +301,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = train_step(model, a, v, args.lr)
+    model.flush_deferred()                       # AVSIAM_DP_DEFER: the last step's MAE-only update belongs to the timed work
     sync()
     dt = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
@@ -338,7 +339,8 @@ def main():
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
                        "parallelism": f"dp{world}", "gflop_per_sample": gf, **({"activation_recompute": True} if args.recompute else {}),
                        **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
-                                        "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "allreduce_messages_last_backward": model.last_reduce_messages}}
+                                        "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "defer_mae_only": os.environ.get("AVSIAM_DP_DEFER", "0"),
+                                        "allreduce_messages_last_backward": model.last_reduce_messages}}
                           if args.force_dp else {})},
             "model_tflops": sps * gf / 1e3, "mfu_vs_dense_bf16_peak": sps * gf / 1e3 / (world * PEAK_BF16_TFLOPS),
             "final_losses": {"loss_mae": losses[0], "loss_mae_a": losses[1], "loss_mae_v": losses[2], "loss_c": losses[3], "c_acc": losses[4]},

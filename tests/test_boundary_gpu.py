@@ -260,6 +260,28 @@ def test_torchrun_entry_forms_the_rccl_group_and_runs(tmp_path):
     assert "engine path on rccl ok" in r.stdout, r.stdout[-1500:]
 
 
+@pytest.mark.parametrize("env", [{}, {"AVSIAM_COMM": "rccl"}, {"AVSIAM_DP_DEFER": "1", "AVSIAM_DP_WIRE": "bf16"}])
+def test_bench_force_dp_issues_every_collective_on_a_one_rank_rccl_group(env):
+    """`bench.py --force-dp` under torchrun with ONE rank: the distributed branch of the bench and of the engine executes on the hardware -
+    the "nccl" (= RCCL) group is formed, the packed embedding all-gather and the chunked, overlapped gradient all-reduce are issued
+    (torch.distributed, or the C ABI's communicator; fp32 or bf16 wire; with the deferred MAE-only update), the barriers and the MAX
+    over ranks run - and stdout carries exactly one line, the JSON (small shape: the full-size figures are in profiles/r03/dp_*.json)."""
+    import json
+    e = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", **env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29583", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--frames", "2",
+           "--no-cpu-baseline", "--force-dp", "--roofline-steps", "0"]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    f = d["config"]["force_dp"]
+    assert d["n_gpus"] == 1 and d["value"] > 0 and f["allreduce_messages_last_backward"] >= 2, d["config"]
+    assert f["comm"] == env.get("AVSIAM_COMM", "torch") and f["wire"] == env.get("AVSIAM_DP_WIRE", "fp32")
+    assert all(v == v and abs(v) < 1e4 for v in d["final_losses"].values()), d["final_losses"]
+
+
 @pytest.mark.parametrize("noise", [False, True])
 def test_raw_inputs_fused_into_the_input_reads(noise):
     """un-normalised fbank + uint8 frames handed to forward() with their transforms (input_xf): the patch
