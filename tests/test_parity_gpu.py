@@ -321,9 +321,10 @@ def test_fp8_forward_mode_against_bf16(which):
 #   the 3 x 3 InfoNCE logits rescales the WHOLE contrastive gradient - direction 0.997, length +8 %; the MAE pass stays within 2.8 %)
 FP8_LOSS_RTOL, FP8_LOGITS_ATOL, FP8_COS_MIN, FP8_RATIO_TOL = 5e-3, 0.12, 0.975, 0.25
 # mode "2" (e5m2 gradient operands in the fc2 / fc1 / proj input-gradient GEMMs: 2 mantissa bits): losses and logits as above (the forward is
-# the same); the whole live gradient as one vector: cosine >= 0.98; every tensor: cosine >= 0.80 (measured >= 0.9035: a 1280-element bias of
-# the batch-2 contrastive pass; >= 0.971 at ViT-B, >= 0.986 in the MAE pass), norm within 30 % (fp8bwd_oracle_* in the margins file)
-FP8B_COS_MIN, FP8B_RATIO_TOL, FP8B_WHOLE_COS = 0.80, 0.30, 0.98
+# the same); the whole live gradient as one vector: cosine >= 0.985 (measured 0.993 - 0.996); every tensor: cosine >= 0.70 (measured >= 0.877:
+# a 1280-element bias of the batch-2 contrastive pass, it moves between runs; >= 0.956 at ViT-B, >= 0.986 in the MAE pass), norm within 30 %
+# (measured <= 11.6 %)  (fp8bwd_oracle_* in the margins file)
+FP8B_COS_MIN, FP8B_RATIO_TOL, FP8B_WHOLE_COS = 0.70, 0.30, 0.985
 
 
 @pytest.mark.parametrize("which", ["mae", "contrastive"])
