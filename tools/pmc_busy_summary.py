@@ -63,13 +63,34 @@ def main():
         fam[name] = d
         print(f"{name:10s} x{d['dispatches']:5d}  mfma_busy {d['mfma_busy']:.3f}  valu {d['valu_active_of_wave_time']}  wait_any {d['wait_any_of_wave_time']}",
               file=sys.stderr)
+    # per KERNEL (not family) for the attention kernels: VERDICT r2 asks for the decoder attention's counters kernel by kernel
+    per_kernel = {}
+    for k in sorted(tot):
+        if "attn_" not in k:
+            continue
+        t, n = tot[k], cnt[k]
+        disp = n.get("SQ_WAVE_CYCLES", 0)
+        if not disp:
+            continue
+        passes = max(1, round(n["GRBM_GUI_ACTIVE"] / disp))
+        gpu_cycles = t["GRBM_GUI_ACTIVE"] / passes / 8.0
+        wave = t.get("SQ_WAVE_CYCLES", 0.0)
+        name = k.split("(")[0].replace("void ", "")
+        per_kernel[name] = {"dispatches": disp, "mfma_busy": t.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gpu_cycles * 1024.0),
+                            "valu_active_of_wave_time": t.get("SQ_ACTIVE_INST_VALU", 0.0) / wave if wave else None,
+                            "wait_any_of_wave_time": t.get("SQ_WAIT_ANY", 0.0) / wave if wave else None,
+                            "wait_inst_of_wave_time": t.get("SQ_WAIT_INST_ANY", 0.0) / wave if wave else None,
+                            "valu_insts_per_mfma": (t.get("SQ_INSTS_VALU", 0.0) / t["SQ_INSTS_MFMA"]) if t.get("SQ_INSTS_MFMA") else None,
+                            "gpu_cycles_per_dispatch": gpu_cycles / disp}
+        print(f"  {name:44s} x{disp:4d} mfma_busy {per_kernel[name]['mfma_busy']:.3f} valu {per_kernel[name]['valu_active_of_wave_time']} wait {per_kernel[name]['wait_any_of_wave_time']}",
+              file=sys.stderr)
     sha = {}
     csrc = os.path.join(ROOT, "avsiam_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
         if f.endswith((".hip", ".h", ".cpp")):
             with open(os.path.join(csrc, f), "rb") as fh:
                 sha[f] = hashlib.sha1(fh.read()).hexdigest()
-    print(json.dumps({"kernels": fam, "source_sha1": sha,
+    print(json.dumps({"kernels": fam, "attention_kernels": per_kernel, "source_sha1": sha,
                       "method": "rocprofv3 --pmc (two counter-only passes) of `AVSIAM_WGRAD_STREAM=0 bench.py --steps 1 --warmup 1 --no-cpu-baseline "
                                 "--no-kernel-events`; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"}, indent=1))
 
