@@ -34,6 +34,8 @@ def main():
         first = first or out
         last = out
     assert last[0] < first[0] and last[3] < first[3], (first, last)
+    if hasattr(m, "fp8_saturation_events") and os.environ.get("AVSIAM_FP8", "0") != "0":
+        print(f"fp8 mode {os.environ['AVSIAM_FP8']}: saturation events over {args.steps} steps: {m.fp8_saturation_events():.0f}", flush=True)
     print("ok: losses fell", flush=True)
 
 
