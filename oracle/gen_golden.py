@@ -180,7 +180,15 @@ def main():
     single = [("c_w1_b4", "contrastive", 4, 87, None),
               ("m_w1_b4", "mae", 4, 87, None),
               ("m_w1_b2_const", "mae", 2, 87, 0.01),
-              ("mc_w1_b4", "both", 4, 91, None)]
+              ("mc_w1_b4", "both", 4, 91, None),
+              # the 5-way chunk partition at its other two shapes (cav_mae_base.py:540-570): B = 5 -> five groups of ONE sample,
+              # B = 10 -> five groups of two (B in {4, 5, 10})
+              ("c_w1_b5", "contrastive", 5, 93, None),
+              ("c_w1_b10", "contrastive", 10, 95, None)]
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
+    if only:                                    # `python -m oracle.gen_golden c_w1_b5 c_w1_b10`: add cases without touching the others
+        _worker(0, 1, 29611, [c for c in single if c[0] in only], GOLDEN)
+        return
     _worker(0, 1, 29611, single, GOLDEN)
     import torch.multiprocessing as mp
     multi = [("c_w2_b3", "contrastive", 3, 87, None)]

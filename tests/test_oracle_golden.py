@@ -27,7 +27,7 @@ def _run(name):
     return d, out, extras, {k: p.grad for k, p in P.items()}
 
 
-@pytest.mark.parametrize("name", ["c_w1_b4", "m_w1_b4", "m_w1_b2_const"])
+@pytest.mark.parametrize("name", ["c_w1_b4", "m_w1_b4", "m_w1_b2_const", "c_w1_b5", "c_w1_b10"])
 def test_oracle_matches_reference(name):
     torch.set_num_threads(8)
     d, out, extras, grads = _run(name)

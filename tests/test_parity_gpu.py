@@ -99,22 +99,27 @@ def test_mae_pass_matches_reference_golden(name):
     gpu_grads_vs_golden(d, lambda n: m._params[n].grad, "golden_" + name, l2_rel=GOLD_L2, samp_rel=GOLD_SAMP, sum_rel=GOLD_SUM)
 
 
-def test_contrastive_pass_matches_reference_golden():
-    d = load_golden("c_w1_b4")
+@pytest.mark.parametrize("name", ["c_w1_b4", "c_w1_b5", "c_w1_b10"])
+def test_contrastive_pass_matches_reference_golden(name):
+    """The three shapes of the 5-way chunk partition (cav_mae_base.py:540-570): B = 4 (one group is empty), B = 5 (five groups of
+    one sample) and B = 10 (five groups of two) - outputs, logits and every live gradient against the unmodified reference's."""
+    d = load_golden(name)
     cfg = AVSiamConfig()
-    a, v = synth_inputs(cfg, 4, int(d["input_seed"]))
+    B = int(d["batch"])
+    a, v = synth_inputs(cfg, B, int(d["input_seed"]))
     plan = golden_plan(d)
     m = _model(cfg, int(d["weight_seed"]))
     out = m(a.cuda(), v.cuda(), mae_loss_weight=0, contrast_loss_weight=1, mask_plan=plan)
     out[0].backward()
     got = np.array([out[i].item() for i in (0, 1, 2, 3, 4, 7)])
     np.testing.assert_allclose(got[[0, 4]], d["out_scalars"][[0, 4]], rtol=LOSS_RTOL)
+    assert abs(got[5] - d["out_scalars"][5]) <= 1.0 / B + 1e-6          # c_acc moves in steps of 1/B
     assert out[5] is None and out[6] is None
-    eng = m._engine("contrastive", 4)
+    eng = m._engine("contrastive", B)
     np.testing.assert_allclose(eng.total.cpu().numpy(), d["logits"], atol=LOGITS_ATOL)
-    record_margin("golden_c_w1_b4", loss_rel=float(abs(got[0] - d["out_scalars"][0]) / abs(d["out_scalars"][0])),
+    record_margin("golden_" + name, loss_rel=float(abs(got[0] - d["out_scalars"][0]) / abs(d["out_scalars"][0])),
                   logits_abs=float(np.abs(eng.total.cpu().numpy() - d["logits"]).max()))
-    gpu_grads_vs_golden(d, lambda n: m._params[n].grad, "golden_c_w1_b4", l2_rel=GOLD_L2_C, samp_rel=GOLD_SAMP_C, sum_rel=GOLD_SUM_C)
+    gpu_grads_vs_golden(d, lambda n: m._params[n].grad, "golden_" + name, l2_rel=GOLD_L2_C, samp_rel=GOLD_SAMP_C, sum_rel=GOLD_SUM_C)
 
 
 @pytest.mark.parametrize("which,B,T,La", [("mae", 4, 1, 128), ("contrastive", 4, 1, 128), ("contrastive", 7, 1, 512),
