@@ -34,7 +34,18 @@ LN_EPS_BLOCK, LN_EPS_FINAL = 1e-5, 1e-6       # nn.LayerNorm default in Block; t
 # Per-layer activation recompute (AVSIAM_RECOMPUTE=1 / bench.py --recompute): a Stack keeps only the fp32 input of every block and
 # re-runs the block's forward (without its last GEMM) in front of the block's backward.  For shapes whose saved activations do not fit
 # 288 GB (ViT-H at batch 64 x 10 frames); costs about 8/12 of the forward GEMMs plus the attention forward again.
+# A FRACTION (AVSIAM_RECOMPUTE=0.5 / bench.py --recompute 0.5) recomputes only the first ceil(f x nblocks) blocks of every Stack and
+# saves the others' activations as usual: the memory between "everything recomputed" (75 GiB at ViT-H/14, batch 64) and the card's
+# 288 GB buys back the same share of the recompute time.
 RECOMPUTE = os.environ.get("AVSIAM_RECOMPUTE", "0")
+
+
+def recompute_blocks(nblocks, setting=None):
+    """number of leading blocks of a Stack of `nblocks` that are recomputed under engine.RECOMPUTE ("0" | "1" | a fraction in (0, 1))"""
+    f = float(RECOMPUTE if setting is None else setting)
+    if not 0.0 <= f <= 1.0:
+        raise ValueError(f"AVSIAM_RECOMPUTE must be 0, 1 or a fraction between them, not {f}")
+    return min(nblocks, int(math.ceil(f * nblocks - 1e-9)))
 # fp8 forward (AVSIAM_FP8=1 / bench.py --fp8; BASELINE configs[4]'s "fp8 MFMA path", never the default): the four forward GEMMs of a
 # block (qkv, proj, fc1, fc2) take OCP e4m3 operands with per-tensor DELAYED scaling and accumulate in fp32.  Every quantised tensor has a
 # device record {scale, 1/scale, running amax, saturation events} (ops.Fp8Records): the kernel that produces an operand (the LayerNorm
@@ -203,7 +214,8 @@ class Stack:
         self.rows, self.D, self.H, self.hidden, self.nblocks = rows, D, H, hidden, nblocks
         self.row_mod = row_mod
         self.inference = inference
-        self.recompute = RECOMPUTE == "1" and not inference
+        self.nrecomp = 0 if inference else recompute_blocks(nblocks)     # blocks [0, nrecomp) keep no activations (one shared set)
+        self.recompute = self.nrecomp > 0
         self.fp8 = FP8 in ("1", "2") and D % 256 == 0 and hidden % 256 == 0 and D >= 256     # the fp8 GEMM's tile constraints (N % 256, K % 128)
         self.fp8_bwd = self.fp8 and FP8 == "2" and not inference
         if self.fp8:
@@ -257,10 +269,11 @@ class Stack:
         self.q_scale = ops.attn_q_scale(D // H)          # q leaves the qkv GEMM ready for the attention kernels
 
         def per_block(shape, dtype):
-            if inference or self.recompute:                   # one buffer for all blocks (recompute: refilled in front of each block's backward)
-                one = _z(shape, dtype, dev)
-                return [one] * nblocks
-            return [_z(shape, dtype, dev) for _ in range(nblocks)]
+            if inference:                                     # one buffer for all blocks
+                return [_z(shape, dtype, dev)] * nblocks
+            # recomputed blocks share one buffer, refilled in front of each one's backward; the others keep their own
+            one = _z(shape, dtype, dev) if self.nrecomp else None
+            return [one if i < self.nrecomp else _z(shape, dtype, dev) for i in range(nblocks)]
 
         if inference:
             ping = [_z((rp, D), F32, dev) for _ in range(2)]
@@ -275,9 +288,9 @@ class Stack:
         self.fc1 = per_block((rp, hidden), BF16)          # gelu'(fc1 output): all the backward needs of the pre-activation (gemm act 1 / 2)
         self.act = per_block((rp, hidden), BF16)
         self.lse = per_block((H, rp), F32)
-        shared = inference or self.recompute
-        st = [_z((rp,), F32, dev) for _ in range(4)] if shared else None
-        self.stats = [st if shared else [_z((rp,), F32, dev) for _ in range(4)] for _ in range(nblocks)]   # mean1 rstd1 mean2 rstd2
+        nshared = nblocks if inference else self.nrecomp
+        st = [_z((rp,), F32, dev) for _ in range(4)] if nshared else None
+        self.stats = [st if i < nshared else [_z((rp,), F32, dev) for _ in range(4)] for i in range(nblocks)]   # mean1 rstd1 mean2 rstd2
         if inference:
             return
         # backward scratch (shared by all blocks)
@@ -463,15 +476,22 @@ class Stack:
         one = blocks2 is not None                # a row range has ONE affine set; the packed single-tower case selects by row_mod
         # recompute: the blocks share ONE set of activation buffers, refilled in front of every block's backward - weight-gradient GEMMs
         # still reading them on a second stream would race with the refill, so everything runs on one stream
-        mode = "0" if self.recompute else WGRAD_STREAM_MODE
+        # (a partially recomputed stack - engine.RECOMPUTE a fraction - uses the second stream for the blocks that keep their own buffers and
+        #  joins it in front of the first recomputed block, see the loop)
+        mode = "0" if self.nrecomp >= self.nblocks else WGRAD_STREAM_MODE
         side = _side_stream(dxo.device) if mode in ("1", "2") else _Inline()
         excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
         grp = excl or mode == "0"     # the block's fc2 / fc1 / proj weight gradients are issued together (one grouped launch); mode 1
                                       # issues each as early as its operands exist
         g16 = GRAD_STREAM == "bf16"   # the residual gradient travels between the LayerNorm backwards in bf16 only
 
+        done = set()
+
         def block_done(j):
             """Every kernel writing block j's parameter gradients is queued on the current stream or joined into it."""
+            if j in done:
+                return
+            done.add(j)
             if reducer is not None:
                 for bl in (blocks, blocks2):
                     if bl is not None:
@@ -511,7 +531,12 @@ class Stack:
         for i in reversed(range(self.nblocks)):
             bp, st = blocks[i], self.stats[i]
             b2 = blocks2[i] if blocks2 is not None else None
-            if self.recompute:
+            if i < self.nrecomp:
+                if not isinstance(side, _Inline):      # from here down the blocks share one set of activation buffers: one stream
+                    side.join()
+                    if excl and i + 1 < self.nblocks:
+                        block_done(i + 1)
+                    side, excl, grp = _Inline(), False, True
                 self._block_forward(i, bp, b2, split, last_gemm=False)
             # fc2: d(gelu out) fused with GELU' -> d(fc1 pre-activation)
             if excl:
@@ -579,9 +604,8 @@ class Stack:
                         hi - lo, None if one else self.row_mod, dres=(dbm if g16 else dxm)[lo:], dx_bf16=dbo[lo:],
                         dcol=bl[i - 1].fc2.gb if i > 0 else None, dx8=d8[lo:] if d8 is not None else None, q8=q8_)
         side.join()
-        if reducer is not None:
-            for j in ([0] if excl else reversed(range(self.nblocks))):
-                block_done(j)
+        for j in reversed(range(self.nblocks)):        # (mode 2 has reported all but block 0 on the way)
+            block_done(j)
 
 
 class PatchEmbedder:

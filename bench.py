@@ -209,8 +209,10 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) forward GEMMs (engine.FP8): configs[4]'s fp8 MFMA path as an extra data point; "
                     "the line then says dtype fp8-forward/bf16-backward and is NOT the headline metric")
     ap.add_argument("--fp8-dgrad", action="store_true", help="with --fp8: the fc2 / fc1 / proj input-gradient GEMMs on e5m2 gradient operands too (engine.FP8 = 2)")
-    ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved "
-                    "activations do not fit the GPU, e.g. --model vit_huge at batch 64; never for the headline metric")
+    ap.add_argument("--recompute", nargs="?", const="1", default=None, metavar="FRACTION",
+                    help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved activations do not fit the GPU, e.g. "
+                         "--model vit_huge14 at batch 64; with a FRACTION (0.25) only that share of every stack's blocks is recomputed and "
+                         "the rest of the 288 GB holds saved activations; never for the headline metric")
     ap.add_argument("--force-dp", action="store_true", help="form the RCCL process group and issue EVERY collective of the data-parallel step "
                     "(packed embedding all-gather, chunked overlapped gradient all-reduce) even at world size 1 - the most of the multi-GPU "
                     "path a one-GPU box can execute; AVSIAM_COMM=rccl selects the C ABI's communicator, AVSIAM_DP_WIRE=bf16 the bf16 wire")
@@ -268,7 +270,8 @@ def main():
     if args.recompute or args.fp8:
         from avsiam_amd import engine as _engine
         if args.recompute:
-            _engine.RECOMPUTE = "1"
+            _engine.recompute_blocks(1, args.recompute)       # validates the value
+            _engine.RECOMPUTE = args.recompute
         if args.fp8:
             _engine.FP8 = "2" if args.fp8_dgrad else "1"
     model = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
@@ -337,7 +340,7 @@ def main():
             "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x{cfg.video_tokens} + "
                                    f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
-                       "parallelism": f"dp{world}", "gflop_per_sample": gf, **({"activation_recompute": True} if args.recompute else {}),
+                       "parallelism": f"dp{world}", "gflop_per_sample": gf, **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
                        **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
                                         "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "defer_mae_only": os.environ.get("AVSIAM_DP_DEFER", "0"),
                                         "allreduce_messages_last_backward": model.last_reduce_messages}}

@@ -242,9 +242,9 @@ def test_vit_huge_width_matches_oracle(which):
 
 @pytest.mark.parametrize("which", ["mae", "contrastive"])
 def test_recompute_matches_saved_activations(which):
-    """engine.RECOMPUTE: every Stack keeps only its blocks' fp32 inputs and re-runs a block's forward in front of its backward.  The
-    kernels are deterministic, so the loss is bitwise the same and the gradients differ only by the order of the fp32 atomics of the
-    weight-gradient GEMMs."""
+    """engine.RECOMPUTE: every Stack keeps only its blocks' fp32 inputs and re-runs a block's forward in front of its backward ("1"), or
+    does so for the first half of its blocks only and saves the rest ("0.5").  The kernels are deterministic, so the loss is bitwise the
+    same and the gradients differ only by the order of the fp32 atomics of the weight-gradient GEMMs."""
     import random
     from avsiam_amd import engine
     cfg = AVSiamConfig(audio_tokens=128, frames=2)
@@ -255,23 +255,29 @@ def test_recompute_matches_saved_activations(which):
     plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(6))
     res = []
     try:
-        for rec in ("0", "1"):
+        for rec in ("0", "1", "0.5"):
             engine.RECOMPUTE = rec
             m = _model(cfg, 97)
+            if rec == "0.5":           # 12 / 2 / 8-block stacks: 6 / 1 / 4 recomputed, the others with buffers of their own
+                eng = m._engine("mae" if mae else "contrastive", B)
+                stacks = [v_ for v_ in vars(eng).values() if isinstance(v_, engine.Stack)]
+                assert stacks and all(0 < st.nrecomp < st.nblocks for st in stacks), [(st.nrecomp, st.nblocks) for st in stacks]
+                assert all(st.act[0] is st.act[st.nrecomp - 1] and st.act[st.nrecomp] is not st.act[0] for st in stacks)
             out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
             out[0].backward()
             torch.cuda.synchronize()
             res.append((out[0].item(), {k: p.grad.detach().double().cpu() for k, p in m._params.items() if p.grad is not None}))
     finally:
         engine.RECOMPUTE = "0"
-    assert res[0][0] == res[1][0]
-    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 100
-    worst = 0.0
-    for k, g0 in res[0][1].items():
-        g1 = res[1][1][k]
-        if float(g0.norm()) > 0:
-            worst = max(worst, float((g1 - g0).norm() / g0.norm()))
-    assert worst < 1e-5, worst
+    for r in res[1:]:
+        assert res[0][0] == r[0]
+        assert res[0][1].keys() == r[1].keys() and len(r[1]) > 100
+        worst = 0.0
+        for k, g0 in res[0][1].items():
+            g1 = r[1][k]
+            if float(g0.norm()) > 0:
+                worst = max(worst, float((g1 - g0).norm() / g0.norm()))
+        assert worst < 1e-5, worst
 
 
 @pytest.mark.parametrize("which", ["mae", "contrastive"])

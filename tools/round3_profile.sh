@@ -51,6 +51,8 @@ if has fp8; then
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute > $OUT/h_vit_huge14_b64_recompute_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 > $OUT/h_vit_huge14_b64_recompute_fp8_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute_fp8_dgrad_bench.json 2>> $OUT/fp8.err
+  python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.375 > $OUT/h_vit_huge14_b64_recompute0375_bench.json 2>> $OUT/fp8.err
+  python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.375 --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute0375_fp8_dgrad_bench.json 2>> $OUT/fp8.err
   python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/[bh]_*bench.json")):
