@@ -258,15 +258,40 @@ def test_recompute_matches_saved_activations(which):
         for rec in ("0", "1", "0.5"):
             engine.RECOMPUTE = rec
             m = _model(cfg, 97)
-            if rec == "0.5":           # 12 / 2 / 8-block stacks: 6 / 1 / 4 recomputed, the others with buffers of their own
-                eng = m._engine("mae" if mae else "contrastive", B)
-                stacks = [v_ for v_ in vars(eng).values() if isinstance(v_, engine.Stack)]
-                assert stacks and all(0 < st.nrecomp < st.nblocks for st in stacks), [(st.nrecomp, st.nblocks) for st in stacks]
-                assert all(st.act[0] is st.act[st.nrecomp - 1] and st.act[st.nrecomp] is not st.act[0] for st in stacks)
+            comm = None
+            if rec == "0.5":           # with the data-parallel reducer attached: every element of the pass's range must be reduced exactly once
+                from tests.helpers import _Waited
+
+                class Counting:
+                    active, world, rank = True, 1, 0
+
+                    def __init__(self):
+                        self.messages = []
+
+                    def all_gather(self, out, inp):
+                        out.view(1, -1).copy_(inp.reshape(1, -1))
+
+                    def all_reduce_async(self, t):
+                        self.messages.append(t.numel())
+                        return _Waited()
+
+                    def all_reduce(self, t):
+                        self.messages.append(t.numel())
+
+                comm = Counting()
+                m.set_distributed(1, 0, comm)
             out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
             out[0].backward()
             torch.cuda.synchronize()
             res.append((out[0].item(), {k: p.grad.detach().double().cpu() for k, p in m._params.items() if p.grad is not None}))
+            if rec == "0.5":           # 12 / 2 / 8-block stacks: 6 / 1 / 4 recomputed, the others with buffers of their own
+                from avsiam_amd.param_spec import P1, P2
+                lo, hi = m.arena.range[P2 if mae else P1]
+                assert len(comm.messages) >= 2 and sum(comm.messages) == hi - lo, (comm.messages, hi - lo)
+                eng = m._engine("mae" if mae else "contrastive", B)
+                stacks = [v_ for v_ in vars(eng).values() if isinstance(v_, engine.Stack)]
+                assert stacks and all(0 < st.nrecomp < st.nblocks for st in stacks), [(st.nrecomp, st.nblocks) for st in stacks]
+                assert all(st.act[0] is st.act[st.nrecomp - 1] and st.act[st.nrecomp] is not st.act[0] for st in stacks)
     finally:
         engine.RECOMPUTE = "0"
     for r in res[1:]:
