@@ -211,8 +211,9 @@ def main():
     ap.add_argument("--fp8-dgrad", action="store_true", help="with --fp8: the fc2 / fc1 / proj input-gradient GEMMs on e5m2 gradient operands too (engine.FP8 = 2)")
     ap.add_argument("--recompute", nargs="?", const="1", default=None, metavar="FRACTION",
                     help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved activations do not fit the GPU, e.g. "
-                         "--model vit_huge14 at batch 64; with a FRACTION (0.25) only that share of every stack's blocks is recomputed and "
-                         "the rest of the 288 GB holds saved activations; never for the headline metric")
+                         "--model vit_huge14 at batch 64; with a FRACTION (0.375) only that share of every stack's blocks is recomputed and "
+                         "the rest of the 288 GB holds saved activations; `auto` takes the smallest share that leaves a tenth of the card "
+                         "free after one step; never for the headline metric")
     ap.add_argument("--force-dp", action="store_true", help="form the RCCL process group and issue EVERY collective of the data-parallel step "
                     "(packed embedding all-gather, chunked overlapped gradient all-reduce) even at world size 1 - the most of the multi-GPU "
                     "path a one-GPU box can execute; AVSIAM_COMM=rccl selects the C ABI's communicator, AVSIAM_DP_WIRE=bf16 the bf16 wire")
@@ -269,21 +270,59 @@ def main():
     log(f"building model (frames={args.frames}, batch={args.batch}/GPU, world={world})")
     if args.recompute or args.fp8:
         from avsiam_amd import engine as _engine
-        if args.recompute:
+        if args.recompute and args.recompute != "auto":
             _engine.recompute_blocks(1, args.recompute)       # validates the value
             _engine.RECOMPUTE = args.recompute
         if args.fp8:
             _engine.FP8 = "2" if args.fp8_dgrad else "1"
-    model = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
     comm = None
     if args.force_dp and world == 1:
         from avsiam_amd.comm import RcclComm, TorchDistComm
         comm = RcclComm(always=True) if os.environ.get("AVSIAM_COMM", "torch") == "rccl" else TorchDistComm(always=True)
-    model.set_distributed(world, rank, comm)
-    model.publish_grads = False
     from avsiam_amd.weights import synth_inputs
     a, v = synth_inputs(cfg, args.batch, 87 + rank)
     a, v = a.to(dev), v.to(dev)
+
+    def build():
+        m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
+        m.set_distributed(world, rank, comm)
+        m.publish_grads = False
+        return m
+
+    if args.recompute == "auto":
+        # the smallest recomputed share of every stack's blocks with which one whole step fits the card and leaves a tenth of it free
+        # (every rank must arrive at the same answer: the verdict of a candidate is the AND over ranks)
+        import gc
+        model = None
+        for frac in ("0", "0.125", "0.25", "0.375", "0.5", "0.625", "0.75", "1"):
+            _engine.RECOMPUTE = frac
+            try:
+                model = build()
+                train_step(model, a, v, args.lr)
+                torch.cuda.synchronize()
+                free, total = torch.cuda.mem_get_info()
+                ok = free >= 0.10 * total
+                log(f"--recompute auto: fraction {frac}: {(total - free) / 2**30:.1f} of {total / 2**30:.1f} GiB in use -> {'taken' if ok else 'too close'}")
+            except torch.OutOfMemoryError:
+                ok = False
+                log(f"--recompute auto: fraction {frac}: out of memory")
+            if world > 1 or args.force_dp:
+                flag = torch.tensor([1 if ok else 0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = bool(flag.item())
+            if ok:
+                args.recompute = frac
+                break
+            model = None
+            gc.collect()
+            torch.cuda.empty_cache()
+        if model is None:
+            raise SystemExit("bench: --recompute auto: the shape does not fit even with every block recomputed")
+        if args.recompute == "0":
+            args.recompute = None
+        torch.cuda.reset_peak_memory_stats()          # the rejected candidates' peaks are not this run's
+    else:
+        model = build()
 
     def sync():
         torch.cuda.synchronize()
