@@ -20,6 +20,8 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <algorithm>
+#include <numeric>
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -49,6 +51,7 @@ struct GemmNtArgs {
     // scale is read from it and the largest |gelu(x)| written is folded into its running amax
     const float* qa; const float* qw; const float* qw2; float* q8;
     float q8_seen;                           // set by the kernel: the amax q8 held at kernel start (filter of the epilogue's atomic)
+    int tb;                                  // gemm_nt8_kernel: tiles [0, tb) are of the FIRST height class (a multiple of 8 and of N / 256); 0: one class
 };
 
 
@@ -172,9 +175,10 @@ __device__ __forceinline__ void nt_epilogue_stage_bias(const GemmNtArgs& a, char
 }
 
 // Q8: 0 no fp8 copy | 1 forward fp8 GEMM: ACT 1 also writes out8 = e4m3(gelu(x)) | 2 backward fp8 GEMM: out8 = e5m2(out) (ACT 0 / 2)
+// nrow: rows of the wave's MI x 16 that belong to the tile (a multiple of 16; fewer than MI x 16 in the reduced-height tiles of gemm_nt8_kernel)
 template <int ACT, int MI, int Q8 = 0>
 __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][MI], EpiPrefetch<MI>& pf, char* smem, int wave, int lane,
-                                            int mw0, int nw0) {
+                                            int mw0, int nw0, const int nrow = MI * 16) {
     const int fr = lane & 15, fq = lane >> 4;
     // this wave's 16 x 68-float transpose patch and its 64 staged bias values, as LDS byte addresses for the asm accessors
     const unsigned smem_lds = (unsigned)(size_t)(LDS_AS const char*)smem;
@@ -195,6 +199,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         constexpr int RG = EpiPrefetch<MI>::RG, NG = MI / RG;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
+            if (g * RG * 16 >= nrow) continue;
             if (a.res && g + 1 < NG) epi_load_res<MI>(a, pf.rs[(g + 1) & 1], g + 1, lane, mw0, nw0);
 #pragma unroll
             for (int mj = 0; mj < RG; ++mj) {
@@ -227,10 +232,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         float q8max = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
+            if (g * AG * 16 >= nrow) continue;
             if (ACT == 2) epi_load_aux<MI>(a, pf.ax, g, lane, mw0, nw0);
 #pragma unroll
             for (int mj = 0; mj < AG; ++mj) {
                 const int mi = g * AG + mj;
+                if (mi * 16 >= nrow) continue;
                 epi_lds_w128<0>(waddr, acc[0][mi]); epi_lds_w128<64>(waddr, acc[1][mi]);
                 epi_lds_w128<128>(waddr, acc[2][mi]); epi_lds_w128<192>(waddr, acc[3][mi]);
                 f32x4 tq[2][2], bq[2];
@@ -473,16 +480,25 @@ __device__ __forceinline__ void wait_vm() {
 // granules, waits and the epilogue do not change; a 128-byte K-tile row then holds 128 contraction values instead of 64, each
 // lane's two 16-byte fragment chunks are the ADJACENT chunks 2g, 2g + 1 of its row (lane group g: 32 consecutive values) instead of
 // chunks g and 4 + g, and a phase issues 8 v_mfma_f32_16x16x128_f8f6f4 (32 cycles each) instead of 16 v_mfma_f32_16x16x32_bf16.
-template <int ACT, int FP8 = 0>
+// Tile HEIGHT classes.  A tile is 2 x HG rows (one half per wave group), HG = 64 + 16 NB, NB = 16-row blocks in the second 64-row half of
+// a group's rows: 4 = the 256-row tile, 3 = a 224-row tile (the fragment reads, MFMAs and epilogue row blocks of the missing block do not
+// exist; the LDS image and the DMA granules keep their 128-row shape and carry rows nobody reads).  The persistent kernel pays whole
+// ROUNDS of tiles over the CUs, so the host fills the last round exactly by mixing two heights: tiles [0, tb) (in dispatch order: every
+// workgroup meets them first, so every CU gets the same share) have NBA blocks and cover rows [0, (tb / nt_n) * HA), the others NBB.
+// The two classes are two inlined copies of the tile body (NB is a compile-time constant in each).
+template <int ACT, int FP8 = 0, int NBA = 4, int NBB = 4>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
-    constexpr int NT = 512, TBM = 256, TBN = 256, MI = 8;
-    constexpr int A_BYTES = TBM * 128, BUF_BYTES = 2 * A_BYTES, GR = 16384;     // per K-tile buffer: [A 32 KiB | B 32 KiB]
+    constexpr int NT = 512, TBN = 256, MI = 8;
+    constexpr int HA = 128 + 32 * NBA, HB = 128 + 32 * NBB;     // tile heights of the two classes
+    constexpr int A_BYTES = 256 * 128, BUF_BYTES = 2 * A_BYTES, GR = 16384;     // per K-tile buffer: [A 32 KiB | B 32 KiB] (whatever the tile height)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wc = wave & 3;                   // wave group (row half) and 64-column slice
     const int nt_n = a.N / TBN;
-    const int ntiles = ((a.M + TBM - 1) / TBM) * nt_n;
+    const int tb = NBA == NBB ? 0 : a.tb;                     // tiles of the first class
+    const int rows_a = (tb / nt_n) * HA;                      // rows they cover
+    const int ntiles = tb + ((a.M - rows_a + HB - 1) / HB) * nt_n;
     const int fr = lane & 15, fq = lane >> 4;
     const int off_k0 = fr * 128 + (((FP8 ? 2 * fq : 0 + fq) ^ (lane & 7)) << 4);
     const int off_k1 = fr * 128 + (((FP8 ? 2 * fq + 1 : 4 + fq) ^ (lane & 7)) << 4);
@@ -515,16 +531,19 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
 #if NT8_ABLATE == 3
         const int wg = 0 * v;                                 // every tile streams tile 0's operands: all loads hit the L2
 #else
-        const int wg = xcd_remap(v, ntiles);
+        // (tb is a multiple of 8, so a dispatch index keeps its XCD class inside either range and xcd_remap stays a per-XCD contiguous run)
+        const bool first = v < tb;
+        const int wg = first ? xcd_remap(v, tb) : xcd_remap(v - tb, ntiles - tb);
 #endif
-        m0 = (wg / nt_n) * TBM;
+        const int hg = first ? HA / 2 : HB / 2;               // rows per wave group of this tile
+        m0 = first ? (wg / nt_n) * HA : rows_a + (wg / nt_n) * HB;
         n0 = (wg % nt_n) * TBN;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int p = j * NT + tid, lr = p >> 3, c = (p & 7) ^ (lr & 7);
-                sA[h][j] = a.A + (size_t)min(m0 + h * 128 + lr, a.M - 1) * a.lda + c * 8;
+                sA[h][j] = a.A + (size_t)min(m0 + h * hg + lr, a.M - 1) * a.lda + c * 8;
                 sB[h][j] = (m0 >= a.m_split ? a.B2 : a.B) + (size_t)(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31)) * a.ldb + c * 8;
             }
     };
@@ -554,7 +573,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
     if (v >= ntiles) return;
     set_tile(v);
     dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1);
-    for (; v < ntiles; v += gridDim.x) {
+    // one tile; srcA / srcB describe it on entry and the NEXT tile on exit.  nbc: its height class (see above)
+    auto run_tile = [&](auto nbc) {
+        constexpr int NB1 = decltype(nbc)::value, HG = 64 + 16 * NB1;
         f32x4 acc[4][MI];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -625,9 +646,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
 #pragma unroll
                         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                            for (int ni = 0; ni < 2; ++ni)
+                            for (int ni = 0; ni < 2; ++ni) {
+                                if (ah == 1 && mi >= NB1) continue;               // (folded: ah and mi are constants after inlining)
                                 acc[bh * 2 + ni][ah * 4 + mi] =
                                     __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[bh][ni][kk], xf[mi][kk], acc[bh * 2 + ni][ah * 4 + mi], 0, 0, 0);
+                            }
                 }
 #endif
                 __builtin_amdgcn_s_setprio(0);
@@ -642,7 +665,14 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
             if (n1) dma_b(t + 1, 1);
             bar(); mma(0, 1); bar();
             // ---- phase 3: (a1, b1)
-            NT8_RD_A(1);
+            // (a reduced-height tile reads only the blocks it multiplies: an asm read whose result no instruction uses would leave its
+            //  registers free for re-use while the LDS data is still on its way)
+            if (NB1 == 4) { NT8_RD_A(1); }
+            else {
+                NT8_RD(xf[0][0], va0, 8192 + 0);    NT8_RD(xf[0][1], va1, 8192 + 0);
+                NT8_RD(xf[1][0], va0, 8192 + 2048); NT8_RD(xf[1][1], va1, 8192 + 2048);
+                if (NB1 > 2) { NT8_RD(xf[2][0], va0, 8192 + 4096); NT8_RD(xf[2][1], va1, 8192 + 4096); }
+            }
             if (n2) dma_b(t + 2, 0);
             bar(); mma(1, 1); bar();
             // ---- phase 4: (a1, b0); A1(t+1) (and everything older) must have landed for the next K-tile's phase 1
@@ -654,7 +684,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
 #undef NT8_RD_A
 #undef NT8_RD_B
         if (g == 0) bar();                                    // pairs with G1's last barrier
-        const int em = m0 + g * 128, en = n0 + wc * 64;
+        const int em = m0 + g * HG, en = n0 + wc * 64;
         __syncthreads();                                      // every wave is done with both buffers, nothing in flight
         nt_epilogue_stage_bias(a, smem + BUF_BYTES, wave, lane, em, en);
         const bool has_next = v + (int)gridDim.x < ntiles;
@@ -701,9 +731,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
             e.alpha = 1.0f;
             e.out8_scale = q8_scale;            // the epilogue takes the record's scale / amax filter from here, not from memory
             e.q8_seen = q8_seen;
-            nt_epilogue<ACT, MI, FP8>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
+            nt_epilogue<ACT, MI, FP8>(e, acc, pf, smem + BUF_BYTES, wave, elane, em, en, HG);
         } else {
-            nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en);
+            nt_epilogue<ACT, MI>(a, acc, pf, smem + BUF_BYTES, wave, elane, em, en, HG);
         }
 #endif
         // a compiler-visible full drain: the K loop reuses registers the epilogue loaded into, and hipcc would otherwise
@@ -716,6 +746,10 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
             set_tile(vnext);
             if (!early) { dma_a(0, 0); dma_a(0, 1); dma_b(0, 0); dma_b(0, 1); }
         }
+    };
+    for (; v < ntiles; v += gridDim.x) {
+        if (NBA != NBB && v < tb) run_tile(std::integral_constant<int, NBA>{});
+        else run_tile(std::integral_constant<int, NBB>{});
     }
 }
 
@@ -1032,6 +1066,13 @@ extern "C" int avs_gemm_set_nt8(int on) {
     return 0;
 }
 
+static int g_force_h = -1;                 // tile heights of the 8-phase nt kernel: 0 automatic | 256 | 224 | 240 = half the row tiles of each (AVSIAM_NT_TILE_H / avs_gemm_set_tile_height)
+extern "C" int avs_gemm_set_tile_height(int h) {
+    AVS_CHECK_ARG(h == 0 || h == 256 || h == 224 || h == 240, "gemm_set_tile_height: 0 (auto), 256, 224, or 240 (both, half and half)");
+    g_force_h = h;
+    return 0;
+}
+
 extern "C" int avs_gemm_set_tile(int tile) {
     AVS_CHECK_ARG(tile == 0 || tile == 128 || tile == 256, "gemm_set_tile: tile must be 0 (auto), 128 or 256");
     g_force_tile = tile;
@@ -1053,7 +1094,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt: the residual add is implemented for fp32 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M,
-                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr, 0.f};
+                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
     if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;
@@ -1063,8 +1104,9 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     if (!attr_done) {
         hipError_t e = hipSuccess;
         const void* big_k[3] = {(const void*)gemm_nt_kernel<0, 4, 8>, (const void*)gemm_nt_kernel<1, 4, 8>, (const void*)gemm_nt_kernel<2, 4, 8>};
-        const void* k8[3] = {(const void*)gemm_nt8_kernel<0>, (const void*)gemm_nt8_kernel<1>, (const void*)gemm_nt8_kernel<2>};
-        for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipFuncSetAttribute(k8[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        const void* k8[6] = {(const void*)gemm_nt8_kernel<0>, (const void*)gemm_nt8_kernel<1>, (const void*)gemm_nt8_kernel<2>,
+                             (const void*)gemm_nt8_kernel<0, 0, 4, 3>, (const void*)gemm_nt8_kernel<1, 0, 4, 3>, (const void*)gemm_nt8_kernel<2, 0, 4, 3>};
+        for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(k8[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         const void* small_k[3] = {(const void*)gemm_nt_kernel<0, 2, 4>, (const void*)gemm_nt_kernel<1, 2, 4>, (const void*)gemm_nt_kernel<2, 2, 4>};
         for (int i = 0; i < 3 && e == hipSuccess; ++i) {
             e = hipFuncSetAttribute(big_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1100,15 +1142,49 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
         }
         if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
         if (g_nt8 >= 1 && K >= 128 && g_persistent && g_force_tile == 0) {
-            // 8-phase kernel, every tile a full 256x256 tile: a partial last round costs it the same as handing the leftover rows
-            // to the half-height-tile kernel in a second dispatch (measured: 185.7 vs 186.0 ms/step), so it keeps one dispatch
-            const int tiles8 = nt_m * nt_n;
+            // 8-phase kernel, one dispatch: a partial last round costs it the same as handing the leftover rows to the half-height-tile
+            // kernel in a second dispatch (measured: 185.7 vs 186.0 ms/step).  What it can do about a badly filled last round: the R rounds
+            // that 256-row tiles need offer R x CUs tile slots; with some of the row tiles 224 rows high (gemm_nt8_kernel's second height
+            // class) the same rows fill MORE of those slots with CHEAPER tiles (a 224-row tile costs ~0.90 of a 256-row one,
+            // profiles/r03/gemm_tile_height_by_shape.log) - e.g. 1122 tiles = 4.4 rounds of N = 768 become 21 + 1257 tiles in 5 full rounds:
+            // 4.6 tile-times per CU instead of 5.  Not for two weight sets (their row split is a multiple of 256 only).
+            if (g_force_h < 0) { const char* e = getenv("AVSIAM_NT_TILE_H"); g_force_h = e ? atoi(e) : 0; }
+            const bool one_set = m_split >= M || m_split <= 0;
+            const int unit = nt_n * 8 / std::gcd(nt_n, 8);      // the first class holds whole row tiles and a multiple of 8 tiles (XCD classes)
+            int tb = -1;                                          // -1: every tile 256 rows (the one-class kernel)
+            if (one_set && g_force_h == 224) tb = 0;              // every tile 224 rows
+            else if (one_set && g_force_h == 240) tb = ((nt_m / 2) * nt_n / unit) * unit;
+            else if (one_set && g_force_h == 0) {
+                const int rounds = ceil_div(nt_m * nt_n, ncu);
+                const int nrt = (rounds * ncu) / nt_n;            // row tiles the slots of those rounds hold
+                // a row tiles of 256 + b of 224 must cover M: b <= (nrt * 256 - M) / 32
+                int b = (int)(((long long)nrt * 256 - M) / 32);
+                if (b > nrt) b = nrt;
+                if (b > 0) {
+                    int ta = ((nrt - b) * nt_n + unit - 1) / unit * unit;       // first-class tiles, rounded UP (fewer small tiles: still covers M)
+                    if (ta / nt_n <= nrt) {
+                        const int na = ta / nt_n, nb = ceil_div(M - (na * 256 < M ? na * 256 : M), 224);
+                        // tile-times of the busiest CU: every workgroup meets its first-class tiles first, then the others
+                        const int nbig = ceil_div(ta, ncu), nall = ceil_div((na + nb) * nt_n, ncu);
+                        const double cost = nbig + 0.90 * (nall - nbig);
+                        if (nb > 0 && nall <= rounds && cost < 0.98 * rounds) tb = ta;
+                    }
+                }
+            }
+            a.tb = tb < 0 ? 0 : tb;
+            const int tiles8 = tb < 0 ? nt_m * nt_n : tb + ceil_div(M - (tb / nt_n) * 256 > 0 ? M - (tb / nt_n) * 256 : 0, 224) * nt_n;
             int grid8 = tiles8 < ncu ? tiles8 : ncu;
             // AVSIAM_NT_GRID: cap the persistent grid (tools/bench_stagger.py: two half-chip GEMMs side by side on two streams)
             { static int gcap = -1; if (gcap < 0) { const char* e = getenv("AVSIAM_NT_GRID"); gcap = e ? atoi(e) : 0; } if (gcap > 0 && gcap < grid8) grid8 = gcap; }
-            if (act == 0) gemm_nt8_kernel<0><<<grid8, 512, 131072, stream>>>(a);
-            else if (act == 1) gemm_nt8_kernel<1><<<grid8, 512, 131072, stream>>>(a);
-            else gemm_nt8_kernel<2><<<grid8, 512, 131072, stream>>>(a);
+#define NT8_LAUNCH(ACT_)                                                                          \
+    do {                                                                                          \
+        if (tb >= 0) gemm_nt8_kernel<ACT_, 0, 4, 3><<<grid8, 512, 131072, stream>>>(a);           \
+        else gemm_nt8_kernel<ACT_, 0, 4, 4><<<grid8, 512, 131072, stream>>>(a);                   \
+    } while (0)
+            if (act == 0) NT8_LAUNCH(0);
+            else if (act == 1) NT8_LAUNCH(1);
+            else NT8_LAUNCH(2);
+#undef NT8_LAUNCH
             AVS_LAUNCH_CHECK("gemm_nt8");
             ++g_nt_dispatches;
             return 0;

@@ -117,6 +117,12 @@ int avs_gemm_set_persistent(int on);
  * 16-KiB staging granules, counted vmcnt); 0: the two-buffer kernels (A/B measurements, the bitwise cross-check of
  * tests/test_kernels_gpu.py).  Environment: AVSIAM_GEMM_NT8=0|1. */
 int avs_gemm_set_nt8(int on);
+/* tile HEIGHTS of the 8-phase nt kernel.  A persistent workgroup per CU pays whole rounds of tiles, so 0 (default) lets the host mix
+ * 256-row and 224-row tiles per GEMM such that the rounds the 256-row tiling needs are filled exactly with cheaper tiles (1122 tiles of
+ * 256 rows = 4.4 rounds cost 5 tile-times per CU; 24 + 1254 tiles in two heights cost 4.6); 256 / 224: one height for every tile, 240: half
+ * the row tiles of each (A/B measurements, the bitwise cross-check of tests/test_kernels_gpu.py).  Launches with two weight sets always
+ * use 256.  Environment: AVSIAM_NT_TILE_H. */
+int avs_gemm_set_tile_height(int h);
 /* tn (weight gradient): C[N1,N2] += A[M,N1]^T . B[M,N2], fp32 atomics; A and B must be allocated and ZERO up to the
  * next multiple of 64 rows; N1%128==0, N2%128==0; splits<=0 picks a split of the contraction that fills the chip. */
 int avs_gemm_tn_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, float* C, long long ldc, int M,
