@@ -1147,14 +1147,15 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
             // that 256-row tiles need offer R x CUs tile slots; with some of the row tiles 224 rows high (gemm_nt8_kernel's second height
             // class) the same rows fill MORE of those slots with CHEAPER tiles (a 224-row tile costs ~0.90 of a 256-row one,
             // profiles/r03/gemm_tile_height_by_shape.log) - e.g. 1122 tiles = 4.4 rounds of N = 768 become 21 + 1257 tiles in 5 full rounds:
-            // 4.6 tile-times per CU instead of 5.  Not for two weight sets (their row split is a multiple of 256 only).
+            // 4.6 tile-times per CU instead of 5.  Two weight sets: their row split is a multiple of 256, so the 256-row class must cover
+            // the first set entirely (every 224-row tile then lies in the second).
             if (g_force_h < 0) { const char* e = getenv("AVSIAM_NT_TILE_H"); g_force_h = e ? atoi(e) : 0; }
             const bool one_set = m_split >= M || m_split <= 0;
             const int unit = nt_n * 8 / std::gcd(nt_n, 8);      // the first class holds whole row tiles and a multiple of 8 tiles (XCD classes)
             int tb = -1;                                          // -1: every tile 256 rows (the one-class kernel)
             if (one_set && g_force_h == 224) tb = 0;              // every tile 224 rows
             else if (one_set && g_force_h == 240) tb = ((nt_m / 2) * nt_n / unit) * unit;
-            else if (one_set && g_force_h == 0) {
+            else if (g_force_h == 0) {
                 const int rounds = ceil_div(nt_m * nt_n, ncu);
                 const int nrt = (rounds * ncu) / nt_n;            // row tiles the slots of those rounds hold
                 // a row tiles of 256 + b of 224 must cover M: b <= (nrt * 256 - M) / 32
@@ -1162,6 +1163,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
                 if (b > nrt) b = nrt;
                 if (b > 0) {
                     int ta = ((nrt - b) * nt_n + unit - 1) / unit * unit;       // first-class tiles, rounded UP (fewer small tiles: still covers M)
+                    if (!one_set && ta / nt_n * 256 < m_split) ta = ceil_div(ceil_div(m_split, 256) * nt_n, unit) * unit;
                     if (ta / nt_n <= nrt) {
                         const int na = ta / nt_n, nb = ceil_div(M - (na * 256 < M ? na * 256 : M), 224);
                         // tile-times of the busiest CU: every workgroup meets its first-class tiles first, then the others

@@ -120,8 +120,9 @@ int avs_gemm_set_nt8(int on);
 /* tile HEIGHTS of the 8-phase nt kernel.  A persistent workgroup per CU pays whole rounds of tiles, so 0 (default) lets the host mix
  * 256-row and 224-row tiles per GEMM such that the rounds the 256-row tiling needs are filled exactly with cheaper tiles (1122 tiles of
  * 256 rows = 4.4 rounds cost 5 tile-times per CU; 24 + 1254 tiles in two heights cost 4.6); 256 / 224: one height for every tile, 240: half
- * the row tiles of each (A/B measurements, the bitwise cross-check of tests/test_kernels_gpu.py).  Launches with two weight sets always
- * use 256.  Environment: AVSIAM_NT_TILE_H. */
+ * the row tiles of each (A/B measurements, the bitwise cross-check of tests/test_kernels_gpu.py).  With two weight sets the 256-row class
+ * covers the first set (the row split is a multiple of 256); the forced one-height modes 224 / 240 apply to one weight set only.
+ * Environment: AVSIAM_NT_TILE_H. */
 int avs_gemm_set_tile_height(int h);
 /* tn (weight gradient): C[N1,N2] += A[M,N1]^T . B[M,N2], fp32 atomics; A and B must be allocated and ZERO up to the
  * next multiple of 64 rows; N1%128==0, N2%128==0; splits<=0 picks a split of the contraction that fills the chip. */
