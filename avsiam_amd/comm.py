@@ -154,9 +154,12 @@ class GradReducer:
     is waited for (the local gradients and everything downstream - Adam moments, master weights - stay fp32).
     """
 
-    def __init__(self, comm, g, lo, hi, min_elems=16 << 20, overlap=None, wire=None, staging=None, boundary=None):
+    def __init__(self, comm, g, lo, hi, min_elems=16 << 20, overlap=None, wire=None, staging=None, boundary=None, staging_lo=None):
         """boundary: an offset inside (lo, hi) no message may straddle - finish(defer_from=boundary) can then leave the messages
-        above it in flight (the MAE-only parameters, whose all-reduce need not end before the next contrastive pass)."""
+        above it in flight (the MAE-only parameters, whose all-reduce need not end before the next contrastive pass).
+        staging / staging_lo: the bf16 wire buffer and the arena offset its element 0 stands for.  A buffer shared between reducers
+        (the model keeps one across steps) must be indexed by ABSOLUTE arena offset (staging_lo = 0, at least `hi` elements): messages
+        one reducer leaves in flight (deferral) then never alias the range another reducer stages."""
         self.comm, self.g, self.lo, self.hi = comm, g, lo, hi
         self.boundary = boundary if boundary is not None and lo < boundary < hi else None
         self.deferred = []
@@ -168,9 +171,9 @@ class GradReducer:
         self.wire = wire or os.environ.get("AVSIAM_DP_WIRE", "fp32")
         assert self.wire in ("fp32", "bf16"), self.wire
         # staging: a bf16 buffer of at least hi - lo elements the caller keeps across steps (allocated here if not given)
-        self.staging = staging
-        if self.wire == "bf16" and self.active and (staging is None or staging.numel() < hi - lo):
-            self.staging = torch.empty(hi - lo, dtype=torch.bfloat16, device=g.device)
+        self.staging, self.staging_lo = staging, (lo if staging_lo is None else staging_lo)
+        if self.wire == "bf16" and self.active and (staging is None or self.staging_lo > lo or self.staging_lo + staging.numel() < hi):
+            self.staging, self.staging_lo = torch.empty(hi - lo, dtype=torch.bfloat16, device=g.device), lo
         self.sent = []            # [a, b) ranges already handed to the collective
         self.pending = []         # declared final, not yet sent
         self.handles = []
@@ -182,7 +185,7 @@ class GradReducer:
             self._send(self.boundary, b)
             return
         if self.wire == "bf16":
-            st = self.staging[a - self.lo:b - self.lo]
+            st = self.staging[a - self.staging_lo:b - self.staging_lo]
             st.copy_(self.g[a:b])                                    # round to nearest even, on the stream the gradients were written on
             self.handles.append((self.comm.all_reduce_async(st), a, b))
         else:
@@ -219,7 +222,7 @@ class GradReducer:
         for h, a, b in handles:
             h.wait()
             if self.wire == "bf16":
-                self.g[a:b].copy_(self.staging[a - self.lo:b - self.lo])
+                self.g[a:b].copy_(self.staging[a - self.staging_lo:b - self.staging_lo])
 
     def finish(self, defer_from=None):
         """Send what was never declared, then wait.  defer_from (= the reducer's boundary): messages at or above it stay in flight;

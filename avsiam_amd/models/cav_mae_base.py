@@ -19,6 +19,7 @@ Differences that are deliberate and documented:
   accumulation across several backward calls are not supported (the reference loop does neither).
 There is no CPU/eager fallback: calling ``forward`` without a GPU and libavsiam_hip.so raises.
 """
+import os
 import random as _pyrandom
 
 import torch
@@ -167,7 +168,8 @@ class CAVMAE_BASE(nn.Module):
         self._world, self._rank = 1, 0
         self._comm, self._dp = None, False
         self.reduce_in_backward = True             # data parallel: loss.backward() all-reduces, like DDP (False: call allreduce_grads)
-        self.defer_p2 = __import__("os").environ.get("AVSIAM_DP_DEFER", "0") == "1"      # see _HotPath.backward
+        self.defer_p2 = os.environ.get("AVSIAM_DP_DEFER", "0") == "1"      # see _HotPath.backward
+        self.dp_wire = os.environ.get("AVSIAM_DP_WIRE", "fp32")     # gradient all-reduce wire format (comm.GradReducer): "fp32" | "bf16"
         self._deferred = None                      # {"reducer": in-flight all-reduce of the MAE-only gradients, "adam": its postponed update}
         self._reduced = {P1: False, P2: False}     # this pass's gradients in the arena are already summed over the ranks
         # factor the arena's gradients still owe (1/W after a SUM all-reduce), per SEGMENT of the arena: the live ranges of the two
@@ -224,10 +226,15 @@ class CAVMAE_BASE(nn.Module):
 
     def _make_reducer(self, lo, hi, overlap=None, boundary=None):
         from ..comm import GradReducer
-        r = GradReducer(self._comm, self.arena.ensure_grads(), lo, hi, overlap=overlap, staging=getattr(self, "_wire_staging", None),
-                        boundary=boundary)
-        self._wire_staging = r.staging               # the bf16 wire buffer (AVSIAM_DP_WIRE=bf16) is kept across steps
-        return r
+        # the bf16 wire buffer (AVSIAM_DP_WIRE=bf16) is kept across steps and shared by the passes' reducers: it spans the whole live
+        # arena and is indexed by absolute offset, so the MAE-only messages a deferred reducer leaves in flight never alias what the
+        # next contrastive backward stages
+        g = self.arena.ensure_grads()
+        st = getattr(self, "_wire_staging", None)
+        if st is None and self.dp_wire == "bf16" and self._dp:
+            st = self._wire_staging = torch.empty(self.arena.live_end, dtype=torch.bfloat16, device=g.device)
+        return GradReducer(self._comm, g, lo, hi, overlap=overlap, wire=self.dp_wire, staging=st, staging_lo=0 if st is not None else None,
+                           boundary=boundary)
 
     def _segments(self, which):
         """(name, lo, hi) of the arena segments pass `which` is live in: [P1 only | shared | P2 only]"""
@@ -242,6 +249,8 @@ class CAVMAE_BASE(nn.Module):
     def _average(self, which, live=None):
         """Apply the factor the gradients of pass `which` still owe (DDP's 1/W).  The factor is tracked per arena segment, so the
         parameters both passes share are scaled once however the calls for the two passes are ordered."""
+        if self._deferred is not None and (which == P2 or live == (P1 | P2)):
+            self.flush_deferred()                  # never scale a range whose all-reduce is still in flight
         for w in ((P1, P2) if live == (P1 | P2) else (which,)):
             for name, lo, hi in self._segments(w):
                 s = self._grad_scale[name]
@@ -423,6 +432,8 @@ class CAVMAE_BASE(nn.Module):
             return
         if already_reduced is None:
             already_reduced = self._reduced[which]
+        if which == P2 and self._deferred is not None and (average or not already_reduced):
+            self.flush_deferred()                  # about to touch the MAE-only range while its deferred all-reduce may be in flight: settle it
         if not already_reduced:
             r = self._make_reducer(*self.arena.range[which], overlap=False)
             r.finish()

@@ -127,6 +127,18 @@ def _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train):
     cfg = AVSiamConfig(audio_tokens=args.target_length // 16 * 8, frames=args.frames)
     audio_model = models.CAVMAE_BASE(audio_length=args.target_length, norm_pix_loss=args.norm_pix_loss,
                                      modality_specific_depth=23, tr_pos=args.tr_pos, opt=args, cfg=cfg)        # :175
+    if args.pretrain_path not in ('None', '', None):
+        # resume from a checkpoint this loop (or the reference's, traintest_cavmae_base.py:223-234: 'module.'-prefixed keys) wrote - the
+        # reference carries the same load commented out (:181-198).  With the fp8 mode the delayed-scaling state saved beside the weights
+        # ('<path>.fp8') is restored too, so the resumed run quantises on the grids it stopped with instead of re-calibrating.
+        sd = torch.load(args.pretrain_path, map_location='cpu')
+        sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
+        miss, unexpected = audio_model.load_state_dict(sd, strict=False)
+        print('now load pretrain model from {:s}, missing keys: {:d}, unexpected keys: {:d}'.format(args.pretrain_path, len(miss), len(unexpected)))
+        from . import engine as _engine
+        if _engine.FP8 != "0" and os.path.exists(args.pretrain_path + ".fp8"):
+            audio_model.load_fp8_state(torch.load(args.pretrain_path + ".fp8", map_location='cpu'))
+            print('restored the fp8 delayed-scaling state from {:s}.fp8'.format(args.pretrain_path))
     if args.exp_dir and args.rank == 0:
         os.makedirs("%s/models" % args.exp_dir, exist_ok=True)
         with open("%s/args.pkl" % args.exp_dir, "wb") as f:

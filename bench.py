@@ -65,7 +65,7 @@ def _cpu_leg(cfg, batch, warmup, steps, cores, label):
             "gflop_per_sample": gflop_per_sample(cfg, B), "gflops": B * gflop_per_sample(cfg, B) / dt}
 
 
-def cpu_baseline(cfg, batch=2, warmup=1, steps=2, survey_legs=True):
+def cpu_baseline(cfg, batch=2, warmup=1, steps=3, survey_legs=True):
     """SURVEY.md 8(d) / BASELINE.md section 3: the oracle (oracle/ref_cpu.py, the CPU restatement of the reference validated against
     it) timed on THIS node's host cores in the same run, fp32 torch, all the cores the process may use - full reference steps (both
     passes forward + backward + both Adam updates), each a bounded sample:
@@ -96,7 +96,7 @@ def cpu_baseline(cfg, batch=2, warmup=1, steps=2, survey_legs=True):
     if survey_legs and cfg.embed_dim == 768 and cfg.st == cfg.patch:
         legs = []
         for label, kw, b, w, n in (("C1: BASELINE configs[0] (batch 4, 1 frame x196 + 128 audio tokens)", {"frames": 1, "audio_tokens": 128}, 4, 1, 3),
-                                   ("C2-shaped (batch 8, 1 frame x196 + 512 audio tokens: reference pre-training semantics)", {"frames": 1, "audio_tokens": 512}, 8, 1, 2)):
+                                   ("C2-shaped (batch 8, 1 frame x196 + 512 audio tokens: reference pre-training semantics)", {"frames": 1, "audio_tokens": 512}, 8, 1, 3)):
             try:
                 legs.append(_cpu_leg(dataclasses.replace(cfg, **kw), b, w, n, cores, label))
             except Exception as e:                                   # a report, never a gate
@@ -188,6 +188,42 @@ def pmc_busy(args, kernel_file="gemm.hip", key="gemm_nt"):
         return None
 
 
+def launch_ranks(n, argv, dry_run=False):
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run: this process - which has made no GPU call (importing torch
+    initialises nothing) and makes none - starts `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a
+    CHILD process (never an exec: a process that touched the GPU must not be replaced, and this one stays the parent anyway), relays the
+    child's stdout - rank 0's one JSON line - and returns the child's exit code (non-zero if any rank failed: torch.distributed.run
+    propagates it).  The reference gets the same shape of launch from its shell script (run_pretrain_base.sh:75 torchrun -> env
+    RANK / WORLD_SIZE / LOCAL_RANK -> utils.py:283-299)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                    # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: without it RCCL's cross-process buffer sharing fails on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    argv = [a for a in argv if a != "--dry-run-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    if dry_run:
+        print(json.dumps({"launch": cmd, "ranks": n, "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")},
+                          "parent_touched_gpu": bool(torch.cuda.is_initialized())}))
+        return 0
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks as a child torch.distributed.run (port {port})", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in child.stdout:
+        lines.append(ln)
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc == 0 and not any(ln.lstrip().startswith("{") for ln in lines):
+        print("[bench] the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    return rc
+
+
 def log(msg):
     if int(os.environ.get("RANK", 0)) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -223,7 +259,11 @@ def main():
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="HIP-event timing of every kernel family (default: the dominant kernel, gemm_nt, only - each timed "
                          "launch costs the stream ~5 us)")
+    ap.add_argument("--dry-run-launch", action="store_true", help="with --gpus N > 1 outside torch.distributed.run: print the launch command and "
+                    "the environment the ranks would get as one JSON line, start nothing (tests/test_bench_launcher_cpu.py)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.dry_run_launch))
     # stdout carries exactly ONE line, the JSON: whatever libraries print on the way (RCCL's version banner when a process group
     # forms, ...) goes to stderr
     sys.stdout.flush()
@@ -239,9 +279,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus and not (args.force_dp and args.gpus == 1 and world == 1):
+        raise SystemExit(f"bench: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path runs only on the HIP kernels")
     _lib.load()
@@ -379,7 +418,11 @@ def main():
             "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x{cfg.video_tokens} + "
                                    f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
-                       "parallelism": f"dp{world}", "gflop_per_sample": gf, **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
+                       "parallelism": f"dp{world}", "gflop_per_sample": gf,
+                       # what the collective library itself reports: the size of the process group the step's collectives ran in
+                       **({"collectives": {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)", "group_world_size": dist.get_world_size(),
+                                           "comm": os.environ.get("AVSIAM_COMM", "torch"), "allreduce_messages_last_backward": model.last_reduce_messages}}
+                          if world > 1 else {}), **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
                        **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
                                         "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "defer_mae_only": os.environ.get("AVSIAM_DP_DEFER", "0"),
                                         "allreduce_messages_last_backward": model.last_reduce_messages}}

@@ -1,0 +1,46 @@
+"""`python bench.py --gpus N` outside a launcher starts its own ranks: the parent makes no GPU call, starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a CHILD process and relays rank 0's line.
+Here (no GPU): the dry run prints the command and the environment, and the relay path is run end to end against a stand-in child."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_dry_run_shows_a_child_torchrun_with_the_same_arguments():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--warmup", "2", "--dry-run-launch"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    cmd = d["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "7", "--warmup", "2"]            # the ranks see the same arguments, minus the dry-run switch
+    assert d["ranks"] == 8 and d["parent_touched_gpu"] is False
+    assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_under_a_launcher_the_script_does_not_launch_again():
+    """WORLD_SIZE set (torch.distributed.run's environment): no second launcher; a world size that contradicts --gpus is an error"""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run-launch"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE is 2" in out.stderr and "launch" not in out.stdout
+
+
+def test_relay_passes_the_line_and_the_exit_code(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    fake = tmp_path / "fake_python.sh"
+    fake.write_text("#!/bin/sh\necho '{\"metric\": \"x\", \"n_gpus\": 2}'\nexit 0\n")
+    fake.chmod(0o755)
+    monkeypatch.setattr(sys, "executable", str(fake))
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
+    fake.write_text("#!/bin/sh\necho rank 1 died >&2\nexit 3\n")
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 3
+    fake.write_text("#!/bin/sh\nexit 0\n")                                    # clean exit without a line is still a failure
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 1

@@ -213,6 +213,30 @@ def _reducer_worker(rank, world, port, q):
         assert not dfr.deferred and torch.equal(g4, want), float((g4 - want).abs().max())
         with pytest.raises(AssertionError):
             GradReducer(comm, g4.clone(), lo, hi, boundary=bnd).finish(defer_from=bnd + 1)
+        # deferral with the bf16 wire and ONE staging buffer shared by two reducers (the model keeps one across steps): the
+        # MAE pass's reducer [3000, 9000) leaves its messages above the boundary staged and in flight; the next contrastive reducer
+        # [100, 4500) stages its own range in the same buffer.  Indexed by absolute arena offset the two never alias, so the deferred
+        # values that land in g afterwards are still the MAE pass's sums.
+        shared = torch.zeros(n, dtype=torch.bfloat16)
+        parts5 = [torch.randn(n, generator=torch.Generator().manual_seed(40 + r)) for r in range(world)]
+        g5 = parts5[rank].clone()
+        p2 = GradReducer(comm, g5, 3000, hi, min_elems=1500, overlap=True, wire="bf16", staging=shared, staging_lo=0, boundary=bnd)
+        for a, b in ((8000, 8500), (5000, 8000), (3000, 5000)):
+            p2.ready(a, b)
+        p2.finish(defer_from=bnd)
+        assert p2.staging is shared and p2.deferred
+        want_hi = sum(p.bfloat16() for p in parts5).float()[bnd:hi] if world == 2 else None      # two addends: one rounding, order-free
+        g5[lo:bnd] = parts5[rank][lo:bnd] * 3.0                                                    # "the next contrastive backward"
+        p1 = GradReducer(comm, g5, lo, bnd, min_elems=1500, overlap=True, wire="bf16", staging=shared, staging_lo=0)
+        p1.ready(lo, bnd)
+        p1.finish()
+        assert p1.staging is shared
+        p2.wait_deferred()
+        if want_hi is not None:
+            assert torch.equal(g5[bnd:hi], want_hi), "the deferred bf16 messages were overwritten by the next reducer's staging"
+        # a shared buffer that does not cover the reducer's range in absolute offsets is not used
+        small = GradReducer(comm, g5.clone(), lo, hi, wire="bf16", staging=torch.zeros(hi - lo, dtype=torch.bfloat16), staging_lo=0)
+        assert small.staging.numel() == hi - lo and small.staging_lo == lo
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback

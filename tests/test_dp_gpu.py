@@ -88,54 +88,140 @@ def test_two_ranks_on_one_gpu_match_reference_w2_golden():
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
+def _segs(m):
+    from avsiam_amd.param_spec import P1, P2
+    b1, b2 = m.arena.range[P1]
+    b12, end = m.arena.range[P2]
+    return b1, b12, b2, end
+
+
+def _predict_adam(p, g, mm, vv, lr, step, scale):
+    """what ONE launch of the fused Adam kernel leaves from these inputs (the same kernel on copies: element-wise, so bit-exact)"""
+    from avsiam_amd import ops
+    p, g, mm, vv = p.clone(), g.clone(), mm.clone(), vv.clone()
+    pb = torch.empty_like(p, dtype=torch.bfloat16)
+    ops.adam(p, g, mm, vv, pb, p.numel(), lr, step, 0.95, 0.999, 1e-8, 5e-7, scale)
+    return p, mm, vv, pb
+
+
 def _defer_worker(rank, world, port, q):
-    """AVSIAM_DP_DEFER: the MAE-only parameters' all-reduce stays in flight after backward and their Adam update is applied before
-    the next MAE forward - N training steps must leave the same weights as the undeferred schedule (the same per-element updates;
-    run-to-run only the order of the weight-gradient atomics differs), and both ranks must hold bit-identical weights."""
+    """AVSIAM_DP_DEFER: the MAE-only parameters' all-reduce stays in flight after backward and their Adam update is applied before the
+    next MAE forward.  Checked WITHOUT comparing two noisy training runs (round 3's statistic - weights after 3 steps against one pair
+    of undeferred runs - measured the chaos of a lr = 1e-3 run, profiles/r04/defer_study.txt):
+      A. one step, deferred vs undeferred from the same weights: what is LINEAR in the gradient - the all-reduced gradient arena, both
+         optimizers' first and second moments, the step counters - agrees per arena segment to the noise of the weight-gradient atomics;
+      B. three steps of the deferred schedule, every update predicted BIT-exactly from snapshots: the shared parameters are updated at
+         once from the gradients as they are after backward; the MAE-only parameters, their gradients and moments do not change while the
+         next contrastive pass runs (nothing races with the pending messages / update), and after the next MAE forward they hold exactly
+         the postponed update - same step count, same 1/W - of the gradients that were in flight (fp32 wire and bf16 wire: ADVICE r3's
+         staging overlap would show here); bf16 shadows and a transposed copy follow;
+      C. both ranks end bit-identical."""
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from avsiam_amd.models import CAVMAE_BASE
         from avsiam_amd.param_spec import P1, P2
         from avsiam_amd.traintest_cavmae_base import train_step
-        from tests.helpers import HostStagedComm
+        from tests.helpers import HostStagedComm, record_margin
         cfg = AVSiamConfig(audio_tokens=128)
         B = 3
         a, v = synth_inputs(cfg, B, 50 + rank)
         a, v = a.cuda(), v.cuda()
-        finals = []
-        for defer in (False, False, True):
+
+        def make(defer, wire="fp32"):
             m = CAVMAE_BASE(cfg=cfg, init_seed=3, init_mode="random", verbose=False, plan_seed=77 + rank).cuda()
             m.publish_grads = False
             m.defer_p2 = defer
-            comm = HostStagedComm()
-            m.set_distributed(world, rank, comm)
-            for step in range(3):
-                train_step(m, a, v, 1e-3)
-                if defer:
-                    assert m._deferred is not None and "adam" in m._deferred          # the MAE-only update is pending between steps
-            lo, b = m.arena.range[P2][0], m.arena.range[P1][1]
-            sd = m.state_dict()                                                        # flushes the pending update
-            assert m._deferred is None
+            m.dp_wire = wire
+            m.set_distributed(world, rank, HostStagedComm())
+            return m
+
+        # ---- A: one step, deferred vs undeferred ------------------------------------------------------------------------------
+        snap = {}
+        for defer in (False, True):
+            m = make(defer)
+            train_step(m, a, v, 1e-6)                # a step this small leaves the MAE pass's weights equal to ~1e-6 whatever signs Adam#1 drew
             if defer:
-                assert any(n > 0 for n in comm.messages) and m.last_reduce_messages >= 2
-            w = m.arena.p[:m.arena.live_end].detach().cpu().clone()
+                assert m._deferred is not None and "adam" in m._deferred          # the MAE-only update is pending after the step
+            m.flush_deferred()
+            assert m._deferred is None
+            b1, b12, b2, end = _segs(m)
+            snap[defer] = {"g": m.arena.g[:end].clone(), "m1": m._opt_state[P1]["m"].clone(), "v1": m._opt_state[P1]["v"].clone(),
+                           "m2": m._opt_state[P2]["m"].clone(), "v2": m._opt_state[P2]["v"].clone(),
+                           "steps": (m._opt_state[P1]["step"], m._opt_state[P2]["step"]), "w": m.arena.p[:end].clone()}
+            del m
+        assert snap[False]["steps"] == snap[True]["steps"] == (1, 1)
+        rel = lambda x, y: float((x.double() - y.double()).norm() / x.double().norm())
+        worst = 0.0
+        for key, segs in (("g", ((b1, b12), (b12, b2), (b2, end))), ("m1", ((0, b12 - b1), (b12 - b1, b2 - b1))), ("v1", ((0, b12 - b1), (b12 - b1, b2 - b1))),
+                          ("m2", ((0, b2 - b12), (b2 - b12, end - b12))), ("v2", ((0, b2 - b12), (b2 - b12, end - b12)))):
+            for lo, hi in segs:
+                r = rel(snap[False][key][lo:hi], snap[True][key][lo:hi])
+                worst = max(worst, r)
+                assert r <= 1e-4, (key, lo, hi, r)                           # measured ~1e-6 (order of the fp32 atomics)
+        moved = (snap[False]["w"] - snap[True]["w"]).abs() > 0.5e-6          # elements whose first Adam step took the other sign
+        record_margin("defer_one_step", worst_rel_linear_quantities=worst, frac_elements_other_sign=float(moved.float().mean()))
+        assert float(moved.float().mean()) < 1e-2
+
+        # ---- B: three deferred steps, predicted bit-exactly ---------------------------------------------------------------------
+        lr = 1e-3
+        for wire in ("fp32", "bf16"):
+            m = make(True, wire)
+            ar = m.arena
+            b1, b12, b2, end = _segs(m)
+            name = "decoder_blocks.0.mlp.fc1.weight"                      # a MAE-only Linear: its shadow and transposed copy must follow
+            pend = None
+            for step in range(1, 4):
+                out = m(a, v, mae_loss_weight=0, contrast_loss_weight=1)
+                out[0].backward()
+                m.allreduce_grads(P1, average=False)
+                m.adam_step(P1, lr)
+                torch.cuda.synchronize()
+                if pend is not None:                 # the contrastive pass ran with the MAE-only update pending: nothing there moved
+                    assert m._deferred is not None and "adam" in m._deferred
+                    assert torch.equal(ar.p[b2:end], pend["p0"]) and torch.equal(m._opt_state[P2]["m"][b2 - b12:], pend["m0"]), (wire, step)
+                    if wire == "bf16":
+                        assert torch.equal(m._wire_staging[b2:end], pend["staged"]), (wire, step, "the in-flight bf16 messages were overwritten")
+                    else:
+                        assert torch.equal(ar.g[b2:end], pend["g"]), (wire, step)
+                out = m(a, v, mae_loss_weight=1, contrast_loss_weight=0)                  # its forward applies the pending update first
+                if pend is not None:
+                    assert torch.equal(ar.p[b2:end], pend["p"]) and torch.equal(m._opt_state[P2]["m"][b2 - b12:], pend["m"]) and \
+                        torch.equal(m._opt_state[P2]["v"][b2 - b12:], pend["v"]), (wire, step, "postponed update differs from the prediction")
+                    assert torch.equal(ar.pb[b2:end], pend["pb"])
+                    assert torch.equal(ar.wtb(name), ar.wb(name).t())
+                out[0].backward()
+                m.allreduce_grads(P2, average=False)                                      # must NOT settle the deferred messages
+                assert m._deferred is not None and m.last_reduce_messages >= 2
+                st = m._opt_state.get(P2)
+                zeros = lambda n: torch.zeros(n, device=ar.p.device)
+                m2 = st["m"].clone() if st is not None else zeros(end - b12)
+                v2 = st["v"].clone() if st is not None else zeros(end - b12)
+                g_now, p_now = ar.g[b12:end].clone(), ar.p[b12:end].clone()
+                if wire == "bf16":                   # the MAE-only sums still sit in the wire buffer; wait_deferred() copies them over g
+                    staged = m._wire_staging[b2:end].clone()
+                    g_now[b2 - b12:] = staged.float()
+                m.adam_step(P2, lr)
+                torch.cuda.synchronize()
+                assert "adam" in m._deferred and m._opt_state[P2]["step"] == step
+                want = _predict_adam(p_now, g_now, m2, v2, lr, step, 1.0 / world)
+                sh = slice(0, b2 - b12)
+                assert torch.equal(ar.p[b12:b2], want[0][sh]) and torch.equal(m._opt_state[P2]["m"][sh], want[1][sh]), (wire, step, "shared update")
+                assert torch.equal(ar.p[b2:end], p_now[b2 - b12:]), (wire, step, "MAE-only parameters moved before the flush")
+                mo = slice(b2 - b12, end - b12)
+                pend = {"p0": p_now[mo].clone(), "m0": m2[mo].clone(), "g": g_now[mo].clone(), "p": want[0][mo], "m": want[1][mo], "v": want[2][mo],
+                        "pb": want[3][mo]}
+                if wire == "bf16":
+                    pend["staged"] = staged
+            sd = m.state_dict()                                                            # flushes the last pending update
+            assert m._deferred is None and len(sd) == 963
+            assert torch.equal(ar.p[b2:end], pend["p"])
+            # ---- C: ranks bit-identical
+            w = ar.p[:ar.live_end].detach().cpu().clone()
             other = [torch.empty_like(w) for _ in range(world)]
             dist.all_gather(other, w)
-            assert torch.equal(other[0], other[1]), "ranks diverged"
-            finals.append(w)
-            assert len(sd) == 963
+            assert torch.equal(other[0], other[1]), f"ranks diverged ({wire} wire)"
             del m
-        # Two runs of the SAME schedule differ, too: the weight-gradient atomics land in another order, and Adam turns a gradient
-        # element of noise level into a +-lr step.  That floor (run 0 vs run 1, both undeferred) is the yardstick: the deferred run
-        # must sit at the same distance - over the whole arena and inside the MAE-only segment the deferral touches.
-        def rel(x, y, sl=slice(None)):
-            return float((x[sl].double() - y[sl].double()).norm() / x[sl].double().norm())
-        seg = slice(b, finals[0].numel())
-        floor, floor_seg = rel(finals[0], finals[1]), rel(finals[0], finals[1], seg)
-        got, got_seg = rel(finals[0], finals[2]), rel(finals[0], finals[2], seg)
-        assert got <= 2.0 * floor + 1e-6 and got_seg <= 2.0 * floor_seg + 1e-6, (floor, got, floor_seg, got_seg)
-        assert floor < 0.05, floor
         q.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback
@@ -145,7 +231,7 @@ def _defer_worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_deferred_mae_only_update_leaves_the_same_weights():
+def test_deferred_mae_only_update_is_the_same_update():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_defer_worker, args=(r, 2, 29765, q)) for r in range(2)]
