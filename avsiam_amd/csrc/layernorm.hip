@@ -213,6 +213,201 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same backward with the NEXT row's operands in flight while the current row is reduced (round 4).  The kernel above issues a
+// row's loads, waits for them, reduces, stores - per wave one row's ~6 KB in flight for about half of the ~3.5 us a row takes, so
+// with the bf16 residual-gradient stream (10 B per element) it sat at 4.1 TB/s.  A second row of loads in REGISTERS costs the
+// occupancy step that pays for it (measured in round 3: spills at three waves per SIMD).  Here the rows come in through LDS-DMA
+// (global_load_lds, 16 B per lane, no VGPR): each wave owns two 8 D-byte slots [x fp32 | dy bf16 | dres bf16]; at the top of row r the
+// DMAs of row r + 1 are issued into the other slot, a COUNTED s_waitcnt leaves them in flight while it waits for row r's (a row's
+// stores are issued one row late so that this wait never stands behind a fresh store), and the row is read back with ds_read_b128 / b64 through inline asm (hipcc would put vmcnt(0) in front of every
+// LDS read it can see beside a pending DMA).  gamma of the current modality stays in registers (re-loaded, behind a full wait,
+// when the modality of the wave's rows changes); the two row reductions use DPP adds instead of six ds_bpermute round trips each.
+// Covers the case the step is made of: bf16 dy, bf16 dres (the gradient stream), bf16 dx only; everything else takes the kernel above.
+#define LDS_AS __attribute__((address_space(3)))
+#define GLOBAL_AS __attribute__((address_space(1)))
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
+
+// sum over the 64 lanes, returned in an SGPR-uniform float (every lane gets it): quad swaps, half-row / row mirrors, then the row
+// totals walk down the rows (row_bcast15 / 31) and lane 63 holds the wave's sum
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = dpp_add<0xB1, 0xF>(v);                      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);                      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);                     // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);                     // row_mirror: every lane of a row of 16 holds the row's sum
+    v = dpp_add<0x142, 0xA>(v);                     // row_bcast15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);                     // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_r128(f32x4& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+// (a 64-bit INTEGER output: with a two-float vector as the asm's output operand hipcc used the low register for both elements)
+template <int OFF>
+__device__ __forceinline__ void lds_r64(unsigned long long& v, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+
+template <int NV, int RPW>
+__global__ __launch_bounds__(256) void ln_bwd_dma_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         const float* __restrict__ g0, const float* __restrict__ g1,
+                                                         const uint8_t* __restrict__ row_mod, const int* __restrict__ out_map,
+                                                         const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx_bf16,
+                                                         float* __restrict__ ws, int rows) {
+    constexpr int D = NV * 256;
+    constexpr int SLOT = 8 * D;                        // bytes: x | dy | dres
+    constexpr int NH = (NV * 32 + 63) / 64;            // DMA instructions of a bf16 row (16 B per lane; the last one may use half the lanes)
+    constexpr int NDMA = NV + 2 * NH;                  // LDS-DMA instructions per row
+    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * SLOT];       // 48 KiB at D = 768: three blocks per CU; reused by the slab reduction
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* const myslots = smem + wave * 2 * SLOT;
+    const unsigned lds0 = (unsigned)(size_t)(LDS_AS const char*)myslots;
+    // (ext-vector arrays throughout: arrays of HIP's float4 STRUCT are not always scalarised and then live in scratch, whose
+    //  loads and stores are vector-memory operations - they would break the counted waits below)
+    f32x4 dg0[NV], db0[NV], dg1[NV], db1[NV], dc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        dg0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; db0[i] = dg0[i]; dg1[i] = dg0[i]; db1[i] = dg0[i]; dc[i] = dg0[i];
+    }
+    const int row0 = (blockIdx.x * 4 + wave) * RPW;
+    const int lrow = min(row0 + (lane & (RPW - 1)), rows - 1);
+    const int l_mod = row_mod ? row_mod[lrow] : 0;
+    const float l_mean = mean_in[lrow], l_rs = rstd_in[lrow];
+    const int l_drow = out_map ? out_map[lrow] : lrow;
+
+    auto issue = [&](int row, int drow, int slot) {     // the three operand rows of `row` -> slot, by LDS-DMA
+        char* base = myslots + slot * SLOT;
+        const char* xs = reinterpret_cast<const char*>(x + (size_t)row * D) + lane * 16;
+        const char* ds_ = reinterpret_cast<const char*>(dy + (size_t)drow * D) + lane * 16;
+        const char* rs_ = reinterpret_cast<const char*>(dres + (size_t)row * D) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xs + i * 1024), (LDS_AS void*)(base + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            if ((j + 1) * 64 <= NV * 32 || lane < NV * 32 - j * 64) {          // whole instruction, or the half the row still has
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(ds_ + j * 1024), (LDS_AS void*)(base + 4 * D + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(rs_ + j * 1024), (LDS_AS void*)(base + 6 * D + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 gcur[NV];
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    u32x2 held[NV];                                    // bf16 output of the previous row (stored one iteration late, see the wait)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { gcur[i] = f32x4{0.f, 0.f, 0.f, 0.f}; held[i] = u32x2{0u, 0u}; }
+    int cur_mod = -1, last = -1;
+    // the per-row scalars are consumed here, in the compiler's view: it waits for their loads ONCE, before the loop (left to the first
+    // v_readlane it would wait at the loop header - vmcnt(0) in every iteration, in front of the next row's DMA issue)
+    asm volatile("" ::"v"(l_mod), "v"(l_mean), "v"(l_rs), "v"(l_drow) : "memory");
+    if (row0 < rows) issue(row0, __builtin_amdgcn_readlane(l_drow, 0), 0);
+    const int nmine = max(0, min(RPW, rows - row0));          // rows of this wave (one loop exit: with a `break` hipcc keeps a second copy of
+                                                              // every accumulator for the merge of the two exits)
+#pragma unroll 1
+    for (int rr = 0; rr < nmine; ++rr) {
+        const int row = row0 + rr;
+        const int mod = __builtin_amdgcn_readlane(l_mod, rr);
+        const float mean = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l_mean), rr));
+        const float rs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l_rs), rr));
+        if (mod != cur_mod) {                            // wave-uniform, rare: before the next DMAs are issued, so its wait drains only what is due anyway
+            const f32x4* gp = reinterpret_cast<const f32x4*>(mod ? g1 : g0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) gcur[i] = gp[i * 64 + lane];
+            cur_mod = mod;
+            // consumed HERE, in the compiler's view: it then waits for these loads inside the branch; left pending at the join, its wait
+            // (vmcnt(0): it cannot see the asm waits) would sit in front of the first use of gamma in EVERY iteration - behind the DMAs
+#pragma unroll
+            for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(gcur[i])::"memory");
+        }
+        // the next row (clamped: the instruction count per row must not depend on the data) goes into the other slot
+        {
+            const int nxt = min(rr + 1, RPW - 1);
+            const int nrow = min(row0 + nxt, rows - 1);
+            issue(nrow, __builtin_amdgcn_readlane(l_drow, nxt), (rr + 1) & 1);
+        }
+        // Wait for row r's DMAs and leave the ones just issued in flight.  The count must hold whatever the STORES in the queue do:
+        // loads retire in order among themselves, but a store may be acknowledged before an older load (a count that budgets for
+        // pending stores - vmcnt(NDMA + NST) - read stale rows on hardware), so the only safe count is the loads that may stay, and
+        // it then also covers every older store.  To make that free, a row's stores are issued one iteration late (below): by the
+        // time of this wait they are a whole row's arithmetic old.
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        const unsigned sb = lds0 + (rr & 1) * SLOT;
+        f32x4 xv[NV];
+        unsigned long long dv[NV], rv[NV];
+        {
+            const unsigned ax = sb + lane * 16, ad = sb + 4 * D + lane * 8, ar = sb + 6 * D + lane * 8;
+            lds_r128<0>(xv[0], ax); lds_r64<0>(dv[0], ad); lds_r64<0>(rv[0], ar);
+            if (NV > 1) { lds_r128<1024>(xv[1], ax); lds_r64<512>(dv[1], ad); lds_r64<512>(rv[1], ar); }
+            if (NV > 2) { lds_r128<2048>(xv[2], ax); lds_r64<1024>(dv[2], ad); lds_r64<1024>(rv[2], ar); }
+            if (NV > 3) { lds_r128<3072>(xv[3], ax); lds_r64<1536>(dv[3], ad); lds_r64<1536>(rv[3], ar); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (rr > 0) {                                     // the previous row's output, held back across the wait above
+#pragma unroll
+            for (int i = 0; i < NV; ++i) reinterpret_cast<u32x2*>(dx_bf16 + (size_t)(row - 1) * D)[i * 64 + lane] = held[i];
+        }
+        f32x4 xh[NV], gy[NV];
+        float s1 = 0.f, s2 = 0.f;
+        const float w1 = mod ? 1.f : 0.f, w0 = 1.f - w1;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 g = gcur[i];
+            const unsigned d01 = (unsigned)dv[i], d23 = (unsigned)(dv[i] >> 32);
+            const f32x4 d = {__uint_as_float(d01 << 16), __uint_as_float(d01 & 0xffff0000u), __uint_as_float(d23 << 16), __uint_as_float(d23 & 0xffff0000u)};
+            xh[i] = (xv[i] - mean) * rs;
+            gy[i] = d * g;
+            s1 += (gy[i][0] + gy[i][1]) + (gy[i][2] + gy[i][3]);
+            const f32x4 gx = gy[i] * xh[i];
+            s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+            // branch-free: a wave-uniform `if (mod)` around the two accumulator sets makes hipcc carry copies of all of them
+            // across the join (+70 VGPRs once anything else is loop-carried); two scalar weights cost two FMAs per element instead
+            const f32x4 dxh = d * xh[i];
+            dg0[i] += w0 * dxh; db0[i] += w0 * d;
+            dg1[i] += w1 * dxh; db1[i] += w1 * d;
+        }
+        const float m1 = wave_sum_dpp(s1) * (1.0f / D);
+        const float m2 = wave_sum_dpp(s2) * (1.0f / D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned r01 = (unsigned)rv[i], r23 = (unsigned)(rv[i] >> 32);
+            const f32x4 rsd = {__uint_as_float(r01 << 16), __uint_as_float(r01 & 0xffff0000u), __uint_as_float(r23 << 16), __uint_as_float(r23 & 0xffff0000u)};
+            const f32x4 o = rs * (gy[i] - m1 - xh[i] * m2) + rsd;
+            dc[i] += o;
+            held[i] = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+        }
+        last = row;
+    }
+    if (last >= 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) reinterpret_cast<u32x2*>(dx_bf16 + (size_t)last * D)[i * 64 + lane] = held[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (dummy) prefetch has landed: the slots can be reused
+    float (*red)[D] = reinterpret_cast<float (*)[D]>(smem);
+    float* slab = ws + (size_t)blockIdx.x * LN_SETS * D;
+#pragma unroll
+    for (int set = 0; set < LN_SETS; ++set) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 a = set == 0 ? dg0[i] : set == 1 ? db0[i] : set == 2 ? dg1[i] : set == 3 ? db1[i] : dc[i];
+            reinterpret_cast<f32x4*>(red[wave])[i * 64 + lane] = a;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) slab[set * D + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
+}
+
 // Sum the per-block slabs: grid (D/256, set, chunk); each chunk of blocks is summed in registers and added with one
 // atomic per column (LN_REDUCE_CHUNKS adders per address).
 __global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, int D, float* dg0, float* db0,
@@ -232,6 +427,7 @@ __global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, 
 
 extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, 4 * LN_MIN_ROWS_PER_WAVE) * LN_SETS * D; }
 
+static int g_ln_dma = -1;                   // 1: the LDS-DMA backward kernel where it applies (default); 0: never (AVSIAM_LN_DMA, A/B)
 static int g_ln_rpw = -1;                   // rows per wave of the backward kernel: 0 automatic; 4 / 8 / 16 forced (AVSIAM_LN_RPW, tuning)
 
 extern "C" int avs_layernorm_fwd_q8(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
@@ -284,6 +480,24 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
     if (rpw != 4 && rpw != 8 && rpw != 16) rpw = rows >= 16384 ? 16 : 8;        // measured (tools/bench_ln.py): 8 wins only on the 8192-row audio tower
     const int nblocks = ceil_div(rows, 4 * rpw);
     dim3 grid(nblocks), block(256);
+    if (g_ln_dma < 0) { const char* e = getenv("AVSIAM_LN_DMA"); g_ln_dma = e ? atoi(e) : 1; }
+    // the step's common case - bf16 dy, bf16 residual-gradient stream in, bf16 dx out only - takes the LDS-DMA kernel (D <= 1024:
+    // two slots per wave must leave room for at least two blocks per CU); AVSIAM_LN_DMA=0: the register-load kernel for everything (A/B)
+    if (g_ln_dma && !dy_f32 && dres && dres_bf16 && !dx && dx_bf16 && !dx8 && D <= 1024) {
+#define LN_DMA(NV)                                                                                                                              \
+    do {                                                                                                                                        \
+        if (rpw == 16) ln_bwd_dma_kernel<NV, 16><<<grid, block, 0, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows); \
+        else if (rpw == 8) ln_bwd_dma_kernel<NV, 8><<<grid, block, 0, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows); \
+        else ln_bwd_dma_kernel<NV, 4><<<grid, block, 0, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows); \
+    } while (0)
+        if (D == 512) LN_DMA(2); else if (D == 768) LN_DMA(3); else LN_DMA(4);
+#undef LN_DMA
+        AVS_LAUNCH_CHECK("layernorm_bwd_dma");
+        const int chunks_ = nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;
+        ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), LN_SETS, chunks_), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1, dcol);
+        AVS_LAUNCH_CHECK("layernorm_bwd_reduce");
+        return 0;
+    }
 #define LN_BWD_R(NV, F, R)                                                                                                                     \
     do {                                                                                                                                       \
         if (dres && dres_bf16) ln_bwd_kernel<NV, F, 2, R><<<grid, block, 0, stream>>>(dy, x, mean, rstd, g0, g1, row_mod, out_map, dres, dx, dx_bf16, ws, rows, dx8, q8);   \

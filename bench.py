@@ -152,7 +152,7 @@ def _pmc_file(args, name, kernel_file):
     it is now (SHA-1 stored beside the numbers); else None."""
     if args.batch != 64 or args.frames != 10 or args.audio_tokens != 512 or args.model != "vit_base" or args.fp8 or args.recompute:
         return None
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         if not os.path.exists(path):
             continue
@@ -160,6 +160,7 @@ def _pmc_file(args, name, kernel_file):
             with open(path) as f:
                 d = json.load(f)
             if d["source_sha1"].get(kernel_file) == _sha1(os.path.join(ROOT, "avsiam_amd", "csrc", kernel_file)):
+                d["_file"] = os.path.relpath(path, ROOT)
                 return d
         except Exception:
             pass
@@ -175,6 +176,19 @@ def pmc_traffic(args, kernel_file="gemm.hip", key="gemm_nt"):
         return float(d["kernels"][key]["hbm_bytes_per_launch"]) if d else None
     except Exception:
         return None
+
+
+def pmc_source(args, kernel_file="gemm.hip"):
+    """Where the `traffic` / `pmc` figures of the line come from: they are NOT measured in this run (counters need rocprofv3 passes
+    of their own) but read from committed summaries of such passes of this same command, attached only while the kernel source is
+    byte-identical to the one they were measured on."""
+    out = {}
+    for name in ("traffic.json", "pmc_busy.json"):
+        d = _pmc_file(args, name, kernel_file)
+        if d:
+            out[name] = {"file": d["_file"], "kernel_source": kernel_file, "kernel_source_sha1": d["source_sha1"].get(kernel_file),
+                         "commit": d.get("commit"), "box": d.get("box"), "measured": d.get("date")}
+    return out or None
 
 
 def pmc_busy(args, kernel_file="gemm.hip", key="gemm_nt"):
@@ -397,7 +411,7 @@ def main():
         mode, _eng.WGRAD_STREAM_MODE = _eng.WGRAD_STREAM_MODE, "0"
         train_step(model, a, v, args.lr)
         torch.cuda.synchronize()
-        ops.prof = ops.KernelProfiler(("gemm_tn", "attn_", "layernorm_"))
+        ops.prof = ops.KernelProfiler()                  # every launch of every kernel family (outside the timed region: the event cost is free here)
         for _ in range(args.roofline_steps):
             train_step(model, a, v, args.lr)
         torch.cuda.synchronize()
@@ -440,7 +454,7 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt8_kernel / gemm_nt_kernel (forward + dgrad bf16 MFMA GEMMs, one avs_gemm_nt_bf16 call = one launch)", "achieved": ach,
                                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args),
-                                "pmc": pmc_busy(args), "launches": n, "avg_launch_us": 1e3 * ms / n, "flops_per_launch": flops / n,
+                                "pmc": pmc_busy(args), "pmc_source": pmc_source(args), "launches": n, "avg_launch_us": 1e3 * ms / n, "flops_per_launch": flops / n,
                                 "dispatches": nd, "avg_dispatch_us": 1e3 * ms / nd,
                                 "sampling": "all launches" if args.all_kernel_events else "every 5th launch of the timed region"}
             if "gemm_nt_fp8" in s:              # --fp8: the e4m3 forward GEMMs are a kernel family of their own, against the fp8 peak
@@ -492,9 +506,15 @@ def main():
                 fam(("layernorm_fwd",), "hbm", PEAK_HBM_GBS, "GB/s", "ln_fwd_kernel (rows*D*(4+2) algorithmic bytes per launch)",
                     traffic=pmc_traffic(args, "layernorm.hip", "ln_fwd")),
             ]
+            # every kernel family's own time per step (single stream: a launch's duration is the kernel's), so that the step can be added up
+            # from the line alone; what the sum leaves of the timed region's ms_per_step is torch's two gradient zero-fills, launch gaps
+            # and - in the timed region only - what the second stream overlaps
+            fams = {k: round(x["total_ms"] / args.roofline_steps, 3) for k, x in sorted(s2.items())}
             line["roofline_more"] = {"pass": f"{args.roofline_steps} extra steps after the timed region, single stream (AVSIAM_WGRAD_STREAM=0 schedule), HIP events on every "
-                                             "launch of these families; the headline `value` and `roofline` come from the timed region",
-                                     "kernels": [m for m in more if m]}
+                                             "launch of every kernel family; the headline `value` and `roofline` come from the timed region",
+                                     "kernels": [m for m in more if m], "ms_per_step_by_family": fams,
+                                     "kernel_sum_ms_per_step": round(sum(fams.values()), 3),
+                                     "launches_per_step": sum(x["launches"] for x in s2.values()) // args.roofline_steps}
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline (oracle) on the host cores")
             try:

@@ -98,6 +98,63 @@ def test_layernorm(D, rows):
         o.layernorm_bwd(dyf, x, mean, rstd, g[0], None, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres_b, dres_b)
 
 
+@pytest.mark.parametrize("D,rows", [(768, 1000), (768, 20001), (512, 16500), (1024, 777)])
+def test_layernorm_bwd_dma_kernel(D, rows):
+    """The step's common LayerNorm backward - bf16 dy, bf16 residual-gradient stream in, bf16 dx out only - runs the LDS-DMA kernel
+    (ln_bwd_dma_kernel: next row prefetched into LDS under the current row's reductions, counted waits, DPP row sums).  Against an fp64
+    reference of the same formula, and against the register-load kernel (same call with an fp32 dx requested): equal up to the order of
+    the two row sums - the bf16 outputs may differ by one rounding in a handful of elements.  Random per-row modality (gamma is
+    re-loaded whenever it changes), permuted dy rows (out_map), 8 and 16 rows per wave, a last block with missing rows."""
+    o = ops()
+    x = torch.randn(rows, D, device=DEV) * 2 + 0.3
+    g = [torch.randn(D, device=DEV) * 0.1 + 1 for _ in range(2)]
+    mod = (torch.rand(rows, device=DEV) > 0.5).to(torch.uint8)
+    mod[: rows // 3] = 0                                           # and a long run of one modality
+    perm = torch.randperm(rows, device=DEV).to(torch.int32)
+    mean = x.mean(1).contiguous()
+    rstd = (1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)).contiguous()
+    dy_nat = bf(torch.randn(rows, D, device=DEV))
+    dy = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    dy[perm.long()] = dy_nat
+    dres = bf(torch.randn(rows, D, device=DEV))
+    ws = torch.empty(o.layernorm_ws(rows, D), device=DEV)
+
+    def run(dx):
+        dg = [torch.zeros(D, device=DEV) for _ in range(2)]
+        db = [torch.zeros(D, device=DEV) for _ in range(2)]
+        dxb = torch.full((rows, D), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dcol = torch.zeros(D, device=DEV)
+        o.layernorm_bwd(dy, x, mean, rstd, g[0], dx, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres, dxb, dcol)
+        return dxb, dg, db, dcol
+
+    dxb, dg, db, dcol = run(None)                                  # -> ln_bwd_dma_kernel
+    dx_ref = torch.empty(rows, D, device=DEV)
+    dxb_r, dg_r, db_r, dcol_r = run(dx_ref)                        # an fp32 dx is wanted too -> the register-load kernel
+    assert torch.isfinite(dxb.float()).all()
+    diff = (dxb.float() != dxb_r.float())
+    if float(diff.float().mean()) >= 1e-3:                          # say WHERE before failing: which rows, how far
+        rowbad = diff.float().mean(1)
+        bad_rows = torch.nonzero(rowbad > 0.5).flatten()[:24].tolist()
+        per_row = ((dxb.float() - dxb_r.float()).norm(dim=1) / dxb_r.float().norm(dim=1))
+        raise AssertionError(f"{float(diff.float().mean()):.4f} of the elements differ; rel err {rel_err(dxb.float(), dxb_r.float()):.3e}; rows mostly different: "
+                             f"{int((rowbad > 0.5).sum())} of {rows}, first {bad_rows}; per-row rel err of rows 0..15: {[round(float(v), 4) for v in per_row[:16]]}; "
+                             f"mod of rows 0..15: {mod[:16].tolist()}")
+    assert rel_err(dxb.float(), dxb_r.float()) < 1e-4
+    for a, b_ in zip(dg + db + [dcol], dg_r + db_r + [dcol_r]):
+        assert rel_err(a, b_) < 2e-5
+    # fp64 reference of the formula
+    xh = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    gam = torch.where(mod.bool()[:, None], g[1].double(), g[0].double())
+    gy = dy_nat.double() * gam
+    want = rstd.double()[:, None] * (gy - gy.mean(1, keepdim=True) - xh * (gy * xh).mean(1, keepdim=True)) + dres.double()
+    assert rel_err(dxb.float(), want) < 3e-3                       # bf16 rounding of the output
+    assert rel_err(dcol, want.sum(0)) < 1e-4
+    for i in range(2):
+        sel = (mod == i).double()[:, None]
+        assert rel_err(dg[i], (dy_nat.double() * xh * sel).sum(0)) < 1e-4
+        assert rel_err(db[i], (dy_nat.double() * sel).sum(0)) < 1e-4
+
+
 @pytest.mark.parametrize("M,N,K", [(333, 256, 768), (1000, 768, 3072), (4099, 2304, 768), (128, 512, 256), (25700, 768, 768)])
 def test_gemm_nt_epilogues(M, N, K):
     o = ops()

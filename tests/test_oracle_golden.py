@@ -190,3 +190,35 @@ def test_patch14_checkpoint_kernel_is_zero_padded_into_the_16x16_storage():
     got = ref_cpu.patch_embed(img, w, None, cfg.stride)
     want = torch.nn.functional.conv2d(img, w14, None, stride=14).flatten(2).transpose(1, 2)
     assert got.shape == (2, 256, cfg.embed_dim) and torch.allclose(got, want, atol=1e-5)
+
+
+def test_golden_gradient_checker_discriminates():
+    """tests.helpers.gpu_grads_vs_golden is what the GPU suite holds the HIP gradients against the reference's per-tensor statistics with
+    (L2 norm, 8 sampled elements, element sum).  Each of its three tolerances must be able to FAIL (a bound nothing can
+    exceed is not a check): on a synthetic golden record, with the tolerances the GPU tests use,
+      - the exact tensor and a tensor with bf16-sized independent noise pass;
+      - a zero tensor, a 2 % scaled tensor and a tensor with 10 % noise fail (norm / samples);
+      - a tensor whose elements all carry an offset of 2e-3 of an element's rms - invisible to the norm and the samples - fails on the sum."""
+    import json
+    import zlib
+    from tests.helpers import gpu_grads_vs_golden, sample_positions
+    from tests.test_parity_gpu import GOLD_L2, GOLD_L2_C, GOLD_SAMP, GOLD_SAMP_C, GOLD_SUM, GOLD_SUM_C
+    gen = torch.Generator().manual_seed(0)
+    name = "mm_layer_2.mlp.fc2.weight"
+    ref = torch.randn(768 * 3072, generator=gen, dtype=torch.float64) * 1e-3
+    d = {"grad_names": np.array(json.dumps([name])), "grad_none": np.array(json.dumps([])), "grad_sum": np.array([ref.sum().item()]),
+         "grad_l2": np.array([ref.norm().item()]), "grad_samples": np.array([[ref[i].item() for i in sample_positions(name, ref.numel())]])}
+    rms = ref.norm().item() / ref.numel() ** 0.5
+    noise = torch.randn(ref.numel(), generator=gen, dtype=torch.float64)
+    for l2, samp, sm in ((GOLD_L2, GOLD_SAMP, GOLD_SUM), (GOLD_L2_C, GOLD_SAMP_C, GOLD_SUM_C)):
+        check = lambda g: gpu_grads_vs_golden(d, lambda n: g, "selftest", l2, samp, sm)
+        check(ref.clone())
+        check(ref + 2.0 ** -9 * rms * noise)                        # independent errors of bf16 size: inside every bound
+        for bad in (torch.zeros_like(ref), ref * 1.02, ref + 0.1 * rms * noise * 5, ref + 2e-3 * rms):
+            with pytest.raises(AssertionError):
+                check(bad)
+    # the offset case is rejected by the SUM alone: norm and samples cannot see it
+    off = ref + 2e-3 * rms
+    with pytest.raises(AssertionError) as e:
+        gpu_grads_vs_golden(d, lambda n: off, "selftest", GOLD_L2, GOLD_SAMP, GOLD_SUM)
+    assert "sum" in str(e.value)

@@ -24,9 +24,11 @@ from tests.helpers import golden_plan, gpu_grads_vs_golden, load_golden, record_
 pytestmark = pytest.mark.gpu
 
 
-# Tolerances of the reference-golden gradient checks (normalised as tests.helpers.gpu_grads_vs_golden says), first run with the
-# round-1 bounds; tightened to ~3x the measured worst case once profiles/r02/parity_margins.json exists.
-GOLD_L2, GOLD_SAMP, GOLD_SUM = 0.01, 0.3, 2.0
+# Tolerances of the reference-golden gradient checks (normalised as tests.helpers.gpu_grads_vs_golden says).  Measured worst cases
+# (profiles/r03/parity_margins.json): l2 0.28 %, samples 0.11 rms, sum 0.66 norms (MAE pass: mm_layer_2.mlp.fc2.weight - the element
+# sum is a BIAS detector: 0.66 norms over 2.4 M elements is a common offset of 4e-4 of an element's rms) / 0.066 (contrastive).
+# What each tolerance can and cannot reject is pinned on the CPU by tests/test_oracle_golden.py::test_golden_gradient_checker_discriminates.
+GOLD_L2, GOLD_SAMP, GOLD_SUM = 0.01, 0.3, 1.2
 GOLD_L2_C, GOLD_SAMP_C, GOLD_SUM_C = 0.01, 0.3, 0.25
 LOSS_RTOL, LOSS_RTOL_GOLD, LOGITS_ATOL, COS_MIN, RATIO_TOL = 2e-3, 6e-3, 0.01, 0.9998, 0.01
 

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--stream", choices=("fp32", "bf16"), default="bf16", help="residual-gradient stream of the backward (engine.GRAD_STREAM)")
     args = ap.parse_args()
     dev = "cuda"
     tot = 0.0
@@ -41,8 +42,14 @@ def main():
         mod = (torch.arange(rows, device=dev) >= rows // 4).to(torch.uint8)
         ws = torch.zeros(ops.layernorm_ws(rows, D), device=dev)
         tf = timeit(lambda: ops.layernorm_fwd(x, g0, b0, y, mean, rstd, rows, 1e-5, g1, b1, mod), args.iters)
-        tb = timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1, dg1, db1, mod, None, dres, dxb, dcol), args.iters)
-        bf, bb = rows * D * 6.0, rows * D * 16.0
+        if args.stream == "bf16":           # the step's form: bf16 residual-gradient stream in, bf16 dx out only (10 B per element)
+            dres_b, dxb2 = dres.to(BF16), torch.zeros(rp, D, device=dev, dtype=BF16)
+            tb = timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g0, None, dg0, db0, ws, rows, g1, dg1, db1, mod, None, dres_b, dxb2, dcol), args.iters)
+            bb = rows * D * 10.0
+        else:
+            tb = timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1, dg1, db1, mod, None, dres, dxb, dcol), args.iters)
+            bb = rows * D * 16.0
+        bf = rows * D * 6.0
         tot += calls * (tf + tb)
         print(f"{args.tag:8s} {name:6s} rows={rows:6d} D={D}: fwd {tf * 1e6:7.1f} us {bf / tf / 1e9:7.0f} GB/s   bwd {tb * 1e6:7.1f} us {bb / tb / 1e9:7.0f} GB/s", flush=True)
     print(f"{args.tag:8s} per step (fwd+bwd, block LayerNorms): {tot * 1e3:.2f} ms", flush=True)

@@ -29,6 +29,18 @@ FAMILIES = {
 }
 
 
+
+def provenance():
+    """box / date / commit of the measurement.  The GPU box has no .git: the commit is what `git rev-parse HEAD > HEAD_COMMIT` left in
+    the repo root before the snapshot was sent (tools/round4_profile.sh says how); the kernel sources' SHA-1 tie the numbers to the code."""
+    import socket
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "HEAD_COMMIT")
+    commit = open(path).read().strip() if os.path.exists(path) else None
+    return {"box": socket.gethostname(), "date": time.strftime("%Y-%m-%dT%H:%M:%S"), "commit": commit}
+
+
 def main():
     tot = defaultdict(lambda: defaultdict(float))
     cnt = defaultdict(lambda: defaultdict(int))
@@ -90,7 +102,7 @@ def main():
         if f.endswith((".hip", ".h", ".cpp")):
             with open(os.path.join(csrc, f), "rb") as fh:
                 sha[f] = hashlib.sha1(fh.read()).hexdigest()
-    print(json.dumps({"kernels": fam, "attention_kernels": per_kernel, "source_sha1": sha,
+    print(json.dumps({"kernels": fam, "attention_kernels": per_kernel, "source_sha1": sha, **provenance(),
                       "method": "rocprofv3 --pmc (two counter-only passes) of `AVSIAM_WGRAD_STREAM=0 bench.py --steps 1 --warmup 1 --no-cpu-baseline "
                                 "--no-kernel-events`; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)"}, indent=1))
 
