@@ -130,6 +130,35 @@ class RcclComm:
             pass
 
 
+class HostStagedComm:
+    """The same collectives on a gloo group, device tensors staged through the host.  NOT a production path (every message is a
+    device -> host -> gloo -> host -> device round trip, synchronous): it exists to rehearse the multi-rank code path where RCCL
+    cannot run - several ranks sharing one GPU (RCCL refuses two ranks on one device), i.e. the tests and `bench.py` under
+    AVSIAM_BENCH_SHARE_GPU=1.  `messages` records the element count of every all-reduce."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.active = self.world > 1
+        self.messages = []
+
+    def all_gather(self, out, inp):
+        host = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(self.world)]
+        self.dist.all_gather(host, inp.detach().cpu(), group=self.group)
+        out.view(self.world, -1).copy_(torch.stack([h.reshape(-1) for h in host]))
+
+    def all_reduce_async(self, t):
+        self.all_reduce(t)
+        return _Done()
+
+    def all_reduce(self, t):
+        self.messages.append(t.numel())
+        h = t.detach().cpu()
+        self.dist.all_reduce(h, group=self.group)
+        t.copy_(h)
+
+
 def default_comm(world):
     """AVSIAM_COMM=rccl: the C ABI's own RCCL communicator instead of torch.distributed's."""
     if world <= 1:

@@ -60,6 +60,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The same sum with DPP adds instead of six ds_bpermute round trips through the LDS pipe (~60 cycles of dependent latency each):
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
+
+// sum over the 64 lanes, returned wave-uniform (every lane gets it): quad swaps, half-row / row mirrors, then the row totals walk down
+// the rows (row_bcast15 / 31) and lane 63 holds the wave's sum (checked on hardware against 1 + 2 + ... + 64)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = dpp_add<0xB1, 0xF>(v);                      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);                      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);                     // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);                     // row_mirror: every lane of a row of 16 holds the row's sum
+    v = dpp_add<0x142, 0xA>(v);                     // row_bcast15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);                     // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

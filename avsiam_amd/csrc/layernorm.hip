@@ -47,14 +47,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    const float mean = wave_sum(s) * (1.0f / D);
+    const float mean = wave_sum_dpp(s) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-    const float var = wave_sum(q) * (1.0f / D);
+    const float var = wave_sum_dpp(q) * (1.0f / D);
     const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                 db0[i].x += d.x; db0[i].y += d.y; db0[i].z += d.z; db0[i].w += d.w;
             }
         }
-        const float m1 = wave_sum(s1) * (1.0f / D);
-        const float m2 = wave_sum(s2) * (1.0f / D);
+        const float m1 = wave_sum_dpp(s1) * (1.0f / D);
+        const float m2 = wave_sum_dpp(s2) * (1.0f / D);
         float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * D);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -226,24 +226,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 // Covers the case the step is made of: bf16 dy, bf16 dres (the gradient stream), bf16 dx only; everything else takes the kernel above.
 #define LDS_AS __attribute__((address_space(3)))
 #define GLOBAL_AS __attribute__((address_space(1)))
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
-    return v + __builtin_bit_cast(float, t);
-}
-
-// sum over the 64 lanes, returned in an SGPR-uniform float (every lane gets it): quad swaps, half-row / row mirrors, then the row
-// totals walk down the rows (row_bcast15 / 31) and lane 63 holds the wave's sum
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v = dpp_add<0xB1, 0xF>(v);                      // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xF>(v);                      // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xF>(v);                     // row_half_mirror
-    v = dpp_add<0x140, 0xF>(v);                     // row_mirror: every lane of a row of 16 holds the row's sum
-    v = dpp_add<0x142, 0xA>(v);                     // row_bcast15 into rows 1 and 3
-    v = dpp_add<0x143, 0xC>(v);                     // row_bcast31 into rows 2 and 3
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 
 template <int OFF>
 __device__ __forceinline__ void lds_r128(f32x4& v, unsigned addr) {

@@ -298,13 +298,24 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path runs only on the HIP kernels")
     _lib.load()
+    # AVSIAM_BENCH_SHARE_GPU=1: REHEARSAL of the multi-rank path on a one-GPU box - every rank uses device 0, the group is gloo and the
+    # collectives are staged through the host (comm.HostStagedComm; RCCL refuses two ranks on one device).  The line says so
+    # (`config.rehearsal`) and its value is not a throughput of anything: the point is that `python bench.py --gpus N` - launcher,
+    # rank environment, world-size branches, max-over-ranks timing - runs end to end (tests/test_boundary_gpu.py).
+    share = os.environ.get("AVSIAM_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    cdev = torch.device("cpu") if share else dev          # where the few scalar collectives of this script live
 
     if args.model == "vit_large":
         from avsiam_amd.config import vit_large
@@ -329,6 +340,9 @@ def main():
         if args.fp8:
             _engine.FP8 = "2" if args.fp8_dgrad else "1"
     comm = None
+    if share and world > 1:
+        from avsiam_amd.comm import HostStagedComm
+        comm = HostStagedComm()
     if args.force_dp and world == 1:
         from avsiam_amd.comm import RcclComm, TorchDistComm
         comm = RcclComm(always=True) if os.environ.get("AVSIAM_COMM", "torch") == "rccl" else TorchDistComm(always=True)
@@ -360,7 +374,7 @@ def main():
                 ok = False
                 log(f"--recompute auto: fraction {frac}: out of memory")
             if world > 1 or args.force_dp:
-                flag = torch.tensor([1 if ok else 0], device=dev)
+                flag = torch.tensor([1 if ok else 0], device=cdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = bool(flag.item())
             if ok:
@@ -417,7 +431,7 @@ def main():
         torch.cuda.synchronize()
         prof2, ops.prof = ops.prof, None
         _eng.WGRAD_STREAM_MODE = mode
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
     if world > 1 or args.force_dp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -433,10 +447,12 @@ def main():
                                    f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
                        "parallelism": f"dp{world}", "gflop_per_sample": gf,
+                       "residual_gradient_stream": __import__("avsiam_amd.engine", fromlist=["GRAD_STREAM"]).GRAD_STREAM,   # bf16 (default) | fp32
                        # what the collective library itself reports: the size of the process group the step's collectives ran in
-                       **({"collectives": {"backend": dist.get_backend(), "library": "RCCL (torch.distributed 'nccl' on ROCm)", "group_world_size": dist.get_world_size(),
-                                           "comm": os.environ.get("AVSIAM_COMM", "torch"), "allreduce_messages_last_backward": model.last_reduce_messages}}
+                       **({"collectives": {"backend": dist.get_backend(), "library": "gloo, staged through the host (rehearsal)" if share else "RCCL (torch.distributed 'nccl' on ROCm)", "group_world_size": dist.get_world_size(),
+                                           "comm": "host-staged" if share else os.environ.get("AVSIAM_COMM", "torch"), "allreduce_messages_last_backward": model.last_reduce_messages}}
                           if world > 1 else {}), **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
+                       **({"rehearsal": "AVSIAM_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo + host-staged collectives - not a throughput figure"} if share else {}),
                        **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
                                         "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "defer_mae_only": os.environ.get("AVSIAM_DP_DEFER", "0"),
                                         "allreduce_messages_last_backward": model.last_reduce_messages}}

@@ -126,32 +126,4 @@ def ft_outputs_as_dict(d, out):
     return {"out": out}
 
 
-class HostStagedComm:
-    """Test-only collective for avsiam_amd.comm: gloo with device tensors staged through the host (RCCL refuses two ranks on
-    one GPU; gloo has no device all_gather_into_tensor).  Same interface as comm.TorchDistComm."""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self.dist = dist
-        self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.messages = []
-
-    def all_gather(self, out, inp):
-        host = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(self.world)]
-        self.dist.all_gather(host, inp.detach().cpu())
-        out.view(self.world, -1).copy_(torch.stack([h.reshape(-1) for h in host]))
-
-    def all_reduce_async(self, t):
-        self.all_reduce(t)
-        return _Waited()
-
-    def all_reduce(self, t):
-        self.messages.append(t.numel())
-        h = t.detach().cpu()
-        self.dist.all_reduce(h)
-        t.copy_(h)
-
-
-class _Waited:
-    def wait(self):
-        pass
+from avsiam_amd.comm import HostStagedComm  # noqa: E402,F401  (gloo through the host: several ranks on the one GPU of the test box)

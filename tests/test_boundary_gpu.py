@@ -282,6 +282,30 @@ def test_bench_force_dp_issues_every_collective_on_a_one_rank_rccl_group(env):
     assert all(v == v and abs(v) < 1e4 for v in d["final_losses"].values()), d["final_losses"]
 
 
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` the way the driver's scaling run would start it - no launcher around it: the parent (no GPU call)
+    starts two ranks as a child torch.distributed.run, the ranks run the WORLD_SIZE = 2 branches of the script and of the engine (rank
+    environment, per-rank batches and seeds, the packed embedding all-gather, the chunked gradient all-reduce inside backward, barrier
+    + max-over-ranks timing, the collectives' own report of the group size) and rank 0's ONE JSON line comes back through the
+    parent.  A rehearsal: the box has one GPU, RCCL refuses two ranks on it, so AVSIAM_BENCH_SHARE_GPU=1 puts both ranks on device 0
+    with gloo + host-staged collectives - everything but RCCL itself, whose calls the --force-dp test above issues at one rank."""
+    import json
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(PYTHONPATH=ROOT, AVSIAM_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "6", "--frames", "2",
+           "--no-cpu-baseline", "--roofline-steps", "0"]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["global_batch"] == 12 and c["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0
+    assert c["collectives"]["group_world_size"] == 2 and c["collectives"]["allreduce_messages_last_backward"] >= 2 and "rehearsal" in c
+    assert all(v == v and abs(v) < 1e4 for v in d["final_losses"].values()), d["final_losses"]
+    assert "starting 2 ranks as a child torch.distributed.run" in r.stderr
+
+
 @pytest.mark.parametrize("noise", [False, True])
 def test_raw_inputs_fused_into_the_input_reads(noise):
     """un-normalised fbank + uint8 frames handed to forward() with their transforms (input_xf): the patch
