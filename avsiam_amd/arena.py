@@ -64,6 +64,8 @@ class ParamArena:
         self.t_total = toff
         self.p = torch.zeros(self.total, dtype=torch.float32)
         self._tr_tables = {}
+        self.zero_epoch = 0              # bumped whenever a backward zero-fills gradients; gb_epoch: block prefix -> epoch of its last backward
+        self.gb_epoch = {}
         self.g = None
         self.pb = None
         self.wt = None

@@ -112,6 +112,7 @@ class BlockParams:
     ('' plain, '_a', '_v')."""
 
     def __init__(self, arena, prefix, sfx0, sfx1=None):
+        self.arena, self.prefix = arena, prefix
         self.ranges = grad_ranges(arena, prefix + ".")
         self.n1 = [Norm(arena, f"{prefix}.norm1{sfx0}")] + ([Norm(arena, f"{prefix}.norm1{sfx1}")] if sfx1 is not None else [])
         self.n2 = [Norm(arena, f"{prefix}.norm2{sfx0}")] + ([Norm(arena, f"{prefix}.norm2{sfx1}")] if sfx1 is not None else [])
@@ -598,6 +599,12 @@ class Stack:
                 # gradient, complete since this block's LayerNorm-2 backward) . W_proj; key third = 0 exactly (ops.vecmat)
                 D = self.D
                 ops.colsum(self.dqkv[lo:, :D], bl[i].qkv.gb[:D], hi - lo)
+                # (the vector-matrix product reads the WHOLE accumulated proj bias gradient: a second backward over the same block
+                #  between two zero-fills must say accumulate=True, or the value third would be counted twice - ADVICE r3)
+                ar = bl[i].arena
+                if not accumulate and ar.gb_epoch.get(bl[i].prefix) == ar.zero_epoch:
+                    raise RuntimeError(f"{bl[i].prefix}: second backward over this block since its gradients were zeroed - pass accumulate=True")
+                ar.gb_epoch[bl[i].prefix] = ar.zero_epoch
                 ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * D:])
                 d8, q8_ = g8rec(i - 1, "dbo")          # the block below reads this gradient through its fc2 input-gradient GEMM
                 _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, None if g16 and i > 0 else dxo[lo:], self.lnws,

@@ -97,6 +97,7 @@ class _HotPath(torch.autograd.Function):
             if live & w:
                 model._reduced[w] = False                              # fresh local gradients
         from .. import ops as _ops
+        arena.zero_epoch += 1                                        # (engine.Stack.backward: one backward per block and epoch unless accumulate=True)
         if live & P1:
             _ops.timed("torch_zero_grads", lambda: arena.zero_grad_range(P1))
         if live & P2:
