@@ -24,7 +24,7 @@ FAMILIES = {
     "gemm_tn": ("gemm_tn",),
     "attn_hd32": ("attn_fwd_kernel<32", "attn_bwd_dq_kernel<32", "attn_bwd_dkv_kernel<32", "attn_bwd_fused_kernel<32"),
     "attn_hd64": ("attn_fwd_kernel<64", "attn_bwd_dq_kernel<64", "attn_bwd_dkv_kernel<64", "attn_bwd_fused_kernel<64"),
-    "ln_bwd": ("ln_bwd_kernel",),
+    "ln_bwd": ("ln_bwd_kernel", "ln_bwd_dma_kernel"),
     "ln_fwd": ("ln_fwd_kernel",),
 }
 
