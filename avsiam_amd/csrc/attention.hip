@@ -146,7 +146,17 @@ struct AttnArgs {
     float scale;                                // hd^-0.5 (q columns of qkv hold q * scale * log2(e))
     uint8_t* out8; long long ldo8; float* q8;   // fwd, fp8 mode (may be NULL): e4m3 copy of the output for the proj GEMM, scaled by the
                                                 // device record q8 (common.h AVS_Q_*), whose running amax takes the largest |o| written
+    uint8_t* dqkv8; long long ld8; float* qd8;  // bwd, fp8 mode (may be NULL): e5m2 copy of dqkv [rows, 3*D] - the gradient operand of the fp8 qkv
+                                                // input-gradient GEMM - scaled by the device record qd8, whose running amax takes the largest |dqkv|
 };
+
+// four consecutive gradient values -> one dword of e5m2 at `dst` (scaled, clamped to the e5m2 range), their |max| folded into gmax
+__device__ __forceinline__ void store_bf8x4(uint8_t* dst, float v0, float v1, float v2, float v3, float scale, float& gmax) {
+    gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+    int w = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(v0 * scale, -57344.f, 57344.f), __builtin_amdgcn_fmed3f(v1 * scale, -57344.f, 57344.f), 0, false);
+    w = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(v2 * scale, -57344.f, 57344.f), __builtin_amdgcn_fmed3f(v3 * scale, -57344.f, 57344.f), w, true);
+    *reinterpret_cast<int*>(dst) = w;
+}
 
 __device__ __forceinline__ f32x16 splat16(float v) {
     f32x16 t;
@@ -341,7 +351,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
 // dQ (query-major).  Also produces delta = rowsum(dO * O), reused by the dK/dV kernel.
 // (hd 32, 4 waves: the second launch-bound argument - 4 waves per SIMD - holds the kernel to 128 registers; it needs 132 otherwise and
 //  would run at three waves per SIMD)
-template <int HD, int NW, int HG = HD>
+// G8: the instantiation that also writes the e5m2 copy of its third of dqkv (fp8 backward).  A template parameter, not a run-time test: the
+// extra epilogue costs the bf16 instantiations registers they do not have (hd 32: a spill under the 128-register bound; hd 64, 2 waves:
+// 172 instead of 164, an occupancy step).
+template <int HD, int NW, int HG = HD, bool G8 = false>
 __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int NTH = 64 * NW;
     constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
@@ -441,6 +454,10 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : 1) void attn_b
         key_block(1);
     }
     if (!active) return;
+    // fp8 backward: the record's scale and the amax it holds are read HERE (scalar loads of a uniform address), not at kernel start: three
+    // more live registers across the key loop spill in the 128-register hd-32 instantiation, which the bf16 path shares
+    float g8s = 0.f, g8seen = 0.f, g8max = 0.f;
+    if (G8) { g8s = a.qd8[AVS_Q_SCALE]; g8seen = a.qd8[AVS_Q_AMAX]; }
     const int qq = qw + (lane & 31);
     if (qq < L) {
         bf16_t* drow = a.dqkv + (size_t)(seq0 + qq) * a.ld + head * HG;
@@ -453,13 +470,17 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : 1) void attn_b
                 w.x = pack_bf2(dq[d][4 * t + 0] * a.scale, dq[d][4 * t + 1] * a.scale);
                 w.y = pack_bf2(dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale);
                 *reinterpret_cast<uint2*>(drow + d * 32 + 8 * t + 4 * hh) = w;
+                if (G8)
+                    store_bf8x4(a.dqkv8 + (size_t)(seq0 + qq) * a.ld8 + head * HG + d * 32 + 8 * t + 4 * hh, dq[d][4 * t + 0] * a.scale,
+                                dq[d][4 * t + 1] * a.scale, dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale, g8s, g8max);
             }
     }
+    if (G8) q_amax_update(a.qd8, g8max, g8seen);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // dK, dV (key-major): each wave owns 32 keys (the lane) and walks the query rows of the sequence.
-template <int HD, int NW, int HG = HD>
+template <int HD, int NW, int HG = HD, bool G8 = false>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int NTH = 64 * NW;
     constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
@@ -560,6 +581,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
         q_block(1);
     }
     if (!active) return;
+    // fp8 backward: the record's scale and the amax it holds are read HERE (scalar loads of a uniform address), not at kernel start: three
+    // more live registers across the key loop spill in the 128-register hd-32 instantiation, which the bf16 path shares
+    float g8s = 0.f, g8seen = 0.f, g8max = 0.f;
+    if (G8) { g8s = a.qd8[AVS_Q_SCALE]; g8seen = a.qd8[AVS_Q_AMAX]; }
     const int kq = kw + (lane & 31);
     if (kq < L) {
         bf16_t* krow = a.dqkv + (size_t)(seq0 + kq) * a.ld + a.D + head * HG;
@@ -577,8 +602,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
                 w.x = pack_bf2(dv[d][4 * t + 0], dv[d][4 * t + 1]);
                 w.y = pack_bf2(dv[d][4 * t + 2], dv[d][4 * t + 3]);
                 *reinterpret_cast<uint2*>(vrow + d * 32 + 8 * t + 4 * hh) = w;
+                if (G8) {
+                    uint8_t* k8 = a.dqkv8 + (size_t)(seq0 + kq) * a.ld8 + a.D + head * HG + d * 32 + 8 * t + 4 * hh;
+                    store_bf8x4(k8, dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2, dk[d][4 * t + 2] * LN2, dk[d][4 * t + 3] * LN2, g8s, g8max);
+                    store_bf8x4(k8 + a.D, dv[d][4 * t + 0], dv[d][4 * t + 1], dv[d][4 * t + 2], dv[d][4 * t + 3], g8s, g8max);
+                }
             }
     }
+    if (G8) q_amax_update(a.qd8, g8max, g8seen);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -591,7 +622,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 //   phase 2 (as attn_bwd_dq): wave w owns queries 32w..: dQ^T += K^T . dS^T with BOTH operands read transposed from LDS (K image
 //     written from the key fragments the wave already holds, into the space of the Q image; the dS image written in phase 1).
 // No atomics, no second pass; per (sequence, head) the arithmetic and its order equal the two-kernel form's.
-template <int HD, int NW>
+template <int HD, int NW, bool G8 = false>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs a) {
     constexpr int R = 32 * NW;                            // rows (queries = keys) a workgroup holds
     constexpr int NKK = HD / 16, NDB = HD / 32;
@@ -713,6 +744,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs a) {
         for (int d = 0; d < NDB; ++d)
             dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, 16 * ks, d, lane), dsf, dq[d], 0, 0, 0);
     }
+    // fp8 backward: the record's scale and the amax it holds are read HERE (scalar loads of a uniform address), not at kernel start: three
+    // more live registers across the key loop spill in the 128-register hd-32 instantiation, which the bf16 path shares
+    float g8s = 0.f, g8seen = 0.f, g8max = 0.f;
+    if (G8) { g8s = a.qd8[AVS_Q_SCALE]; g8seen = a.qd8[AVS_Q_AMAX]; }
     if (rl < L) {
         bf16_t* qrow = a.dqkv + (size_t)(seq0 + rl) * a.ld + head * HD;
         bf16_t* krow = qrow + a.D;
@@ -732,8 +767,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs a) {
                 w.x = pack_bf2(dv[d][4 * t + 0], dv[d][4 * t + 1]);
                 w.y = pack_bf2(dv[d][4 * t + 2], dv[d][4 * t + 3]);
                 *reinterpret_cast<uint2*>(vrow + d * 32 + 8 * t + 4 * hh) = w;
+                if (G8) {
+                    uint8_t* q8p = a.dqkv8 + (size_t)(seq0 + rl) * a.ld8 + head * HD + d * 32 + 8 * t + 4 * hh;
+                    store_bf8x4(q8p, dq[d][4 * t + 0] * a.scale, dq[d][4 * t + 1] * a.scale, dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale, g8s, g8max);
+                    store_bf8x4(q8p + a.D, dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2, dk[d][4 * t + 2] * LN2, dk[d][4 * t + 3] * LN2, g8s, g8max);
+                    store_bf8x4(q8p + 2 * a.D, dv[d][4 * t + 0], dv[d][4 * t + 1], dv[d][4 * t + 2], dv[d][4 * t + 3], g8s, g8max);
+                }
             }
     }
+    if (G8) q_amax_update(a.qd8, g8max, g8seen);
 }
 
 // ===================================================================================================
@@ -757,7 +799,7 @@ extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
     if (int e = check_common("attn_fwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && lse && (ldo % 4) == 0, "attn_fwd: null output");
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd),
-               out8, ldo8, q8};
+               out8, ldo8, q8, nullptr, 0, nullptr};
     dim3 grid(ntiles * H);
     // hd 80 (ViT-H: 1280 / 16 heads): a 96-wide LDS image whose last 16 columns are zero, five contraction steps, 128-row tiles only
     if (hd == 80) attn_fwd_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
@@ -778,57 +820,78 @@ extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const
     return avs_attn_fwd_q8(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, ldo, lse, rows_total, nullptr, 0, nullptr, stream);
 }
 
-extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
-                            const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
-                            const float* lse, float* delta, int rows_total, bf16_t* dqkv, hipStream_t stream) {
+// dqkv8 / ld8 / qd8 (all or none): also write e5m2(clamp(dqkv * qd8[0], +-57344)) [rows, 3*D] / ld8 - the gradient operand of the fp8 qkv
+// input-gradient GEMM - and fold max |dqkv| into the device record qd8
+extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                               const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
+                               const float* lse, float* delta, int rows_total, bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
+                               hipStream_t stream) {
+    AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 4) == 0)), "attn_bwd: dqkv8 and its record go together, ld8 %% 4 == 0");
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_bwd: tile_rows must be 64 or 128");
     AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_bwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr};
+               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8};
     dim3 grid(ntiles * H);
-    if (hd == 80) attn_bwd_dq_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
-    else if (tile_rows == 128) {
-        if (hd == 64) attn_bwd_dq_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
-        else attn_bwd_dq_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
-    } else {
-        if (hd == 64) attn_bwd_dq_kernel<64, 2><<<grid, 128, 0, stream>>>(a);
-        else attn_bwd_dq_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
-    }
+#define ATTN_BWD2(K, G)                                                                                     \
+    do {                                                                                                    \
+        if (hd == 80) K<96, 4, 80, G><<<grid, 256, 0, stream>>>(a);                                         \
+        else if (tile_rows == 128) {                                                                        \
+            if (hd == 64) K<64, 4, 64, G><<<grid, 256, 0, stream>>>(a);                                     \
+            else K<32, 4, 32, G><<<grid, 256, 0, stream>>>(a);                                              \
+        } else {                                                                                            \
+            if (hd == 64) K<64, 2, 64, G><<<grid, 128, 0, stream>>>(a);                                     \
+            else K<32, 2, 32, G><<<grid, 128, 0, stream>>>(a);                                              \
+        }                                                                                                   \
+    } while (0)
+    if (dqkv8) ATTN_BWD2(attn_bwd_dq_kernel, true); else ATTN_BWD2(attn_bwd_dq_kernel, false);
     AVS_LAUNCH_CHECK("attn_bwd_dq");
-    if (hd == 80) attn_bwd_dkv_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
-    else if (tile_rows == 128) {
-        if (hd == 64) attn_bwd_dkv_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
-        else attn_bwd_dkv_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
-    } else {
-        if (hd == 64) attn_bwd_dkv_kernel<64, 2><<<grid, 128, 0, stream>>>(a);
-        else attn_bwd_dkv_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
-    }
+    if (dqkv8) ATTN_BWD2(attn_bwd_dkv_kernel, true); else ATTN_BWD2(attn_bwd_dkv_kernel, false);
+#undef ATTN_BWD2
     AVS_LAUNCH_CHECK("attn_bwd_dkv");
     return 0;
 }
 
+extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                            const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
+                            const float* lse, float* delta, int rows_total, bf16_t* dqkv, hipStream_t stream) {
+    return avs_attn_bwd_q8(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, dout, ldo, lse, delta, rows_total, dqkv, nullptr, 0,
+                           nullptr, stream);
+}
+
 // One workgroup per (sequence, head) for sequences of at most `rows_per_wg` (64 or 128) tokens: seq_start / seq_len [nseq].
-extern "C" int avs_attn_bwd_fused(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
-                                  int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
-                                  bf16_t* dqkv, hipStream_t stream) {
+extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
+                                     int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
+                                     bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, hipStream_t stream) {
+    AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 4) == 0)), "attn_bwd_fused: dqkv8 and its record go together, ld8 %% 4 == 0");
     AVS_CHECK_ARG(rows_per_wg == 64 || rows_per_wg == 128, "attn_bwd_fused: rows_per_wg must be 64 or 128");
     const int hd = H > 0 ? D / H : 0;
     AVS_CHECK_ARG(qkv && seq_start && seq_len && nseq > 0 && H > 0 && (hd == 32 || hd == 64) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0,
                   "attn_bwd_fused: bad arguments (D=%d H=%d hd=%d ld=%lld nseq=%d)", D, H, hd, ld, nseq);
     AVS_CHECK_ARG(out && dout && lse && dqkv && (ldo % 8) == 0, "attn_bwd_fused: null pointer");
     AttnArgs a{qkv, ld, D, seq_start, seq_len, nullptr, nseq, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr};
+               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8};
     dim3 grid(nseq * H);
-    if (rows_per_wg == 128) {
-        if (hd == 64) attn_bwd_fused_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
-        else attn_bwd_fused_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
-    } else {
-        if (hd == 64) attn_bwd_fused_kernel<64, 2><<<grid, 128, 0, stream>>>(a);
-        else attn_bwd_fused_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
-    }
+#define ATTN_BWDF(G)                                                                                        \
+    do {                                                                                                    \
+        if (rows_per_wg == 128) {                                                                           \
+            if (hd == 64) attn_bwd_fused_kernel<64, 4, G><<<grid, 256, 0, stream>>>(a);                     \
+            else attn_bwd_fused_kernel<32, 4, G><<<grid, 256, 0, stream>>>(a);                              \
+        } else {                                                                                            \
+            if (hd == 64) attn_bwd_fused_kernel<64, 2, G><<<grid, 128, 0, stream>>>(a);                     \
+            else attn_bwd_fused_kernel<32, 2, G><<<grid, 128, 0, stream>>>(a);                              \
+        }                                                                                                   \
+    } while (0)
+    if (dqkv8) ATTN_BWDF(true); else ATTN_BWDF(false);
+#undef ATTN_BWDF
     AVS_LAUNCH_CHECK("attn_bwd_fused");
     return 0;
+}
+
+extern "C" int avs_attn_bwd_fused(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
+                                  int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
+                                  bf16_t* dqkv, hipStream_t stream) {
+    return avs_attn_bwd_fused_q8(qkv, ld, D, H, seq_start, seq_len, nseq, rows_per_wg, out, dout, ldo, lse, rows_total, dqkv, nullptr, 0, nullptr, stream);
 }

@@ -55,10 +55,11 @@ def recompute_blocks(nblocks, setting=None):
 # the checkpoint (CAVMAE_BASE.fp8_state).  The first time a GEMM runs its operands are calibrated on the spot (absmax -> scale, still
 # on the device) and the activation is quantised by a pass.  The MAE pass's two towers run as one stack with two weight sets here too.
 # Everything the backward reads is still produced in bf16.  AVSIAM_FP8=2 (bench.py --fp8 --fp8-dgrad) extends the mode into the backward:
-# the input-gradient GEMMs of fc2 (with its GELU' epilogue), fc1 and proj run on e5m2 gradient operands - written, beside the bf16
-# gradient the weight-gradient GEMMs and LayerNorm still read, by the LayerNorm backward that produces the residual gradient and by the
-# fc2 input-gradient epilogue; own records, fmax 57344 - against the e4m3 copy of the transposed weight (the forward's weight scale).
-# The qkv input gradient and all weight gradients stay bf16.
+# ALL FOUR input-gradient GEMMs of a block - fc2 (with its GELU' epilogue), fc1, proj and (round 4) qkv - run on e5m2 gradient operands,
+# written, beside the bf16 gradient the weight-gradient GEMMs and LayerNorm still read, by the kernels that produce them: the LayerNorm
+# backward (residual gradient), the fc2 input-gradient epilogue and the three attention backward kernels (dqkv; avs_attn_bwd_q8 /
+# avs_attn_bwd_fused_q8); own records, fmax 57344 - against the e4m3 copy of the transposed weight (the forward's weight scale).
+# The weight gradients stay bf16.
 FP8 = os.environ.get("AVSIAM_FP8", "0")
 # The residual-GRADIENT stream between the blocks of a stack (AVSIAM_GRAD_STREAM=bf16 | fp32).  bf16 (default): a LayerNorm backward
 # reads the upstream residual gradient from the bf16 copy the previous LayerNorm backward wrote for the GEMMs anyway and writes
@@ -239,9 +240,10 @@ class Stack:
             self.g8_seen, self.g8_have = set(), set()
             self.dx8 = [torch.zeros((r8, D), dtype=U8, device=dev) for _ in range(2)]      # e5m2 copies of dbo / dbm
             self.dfc1_8 = torch.zeros((r8, hidden), dtype=U8, device=dev)
-            per_blk_t = D * D + 2 * D * hidden                                    # transposed copies the fp8 input-gradient GEMMs read: fc2 | fc1 | proj
+            self.dqkv8 = torch.zeros((r8, 3 * D), dtype=U8, device=dev)           # e5m2 copy of dqkv, written by the attention backward kernels
+            per_blk_t = 4 * D * D + 2 * D * hidden                                # transposed copies the fp8 input-gradient GEMMs read: fc2 | fc1 | proj | qkv
             self.wt8_flat = torch.zeros((2 * nblocks * per_blk_t,), dtype=U8, device=dev)
-            self.wt8_off = {"fc2": 0, "fc1": D * hidden, "proj": 2 * D * hidden}
+            self.wt8_off = {"fc2": 0, "fc1": D * hidden, "proj": 2 * D * hidden, "qkv": 2 * D * hidden + D * D}
             self.wt8_per_blk = per_blk_t
             self.wt8_batch = None
         rp = ops.pad_rows(rows, 128)
@@ -342,7 +344,7 @@ class Stack:
     def _wt8(self, i, name, which=0):
         """persistent e4m3 copy of the TRANSPOSED weight (B operand [K_in, N_out] of the input-gradient GEMM)"""
         D, Hd = self.D, self.hidden
-        N, K = {"fc2": (Hd, D), "fc1": (D, Hd), "proj": (D, D)}[name]
+        N, K = {"fc2": (Hd, D), "fc1": (D, Hd), "proj": (D, D), "qkv": (D, 3 * D)}[name]
         o = (which * self.nblocks + i) * self.wt8_per_blk + self.wt8_off[name]
         return self.wt8_flat[o:o + N * K].view(N, K)
 
@@ -417,7 +419,7 @@ class Stack:
         producer when (i, gname) is in g8_have, else by a pass here) and the e4m3 copy of the transposed weight, quantised with the
         scale of the forward's weight record (the same tensor)."""
         M = self.rows
-        G8 = {"dbo": 0, "dfc1": 1, "dbm": 2}
+        G8 = {"dbo": 0, "dfc1": 1, "dbm": 2, "dqkv": 3}
         idx = i * 4 + G8[gname]
         rec = self.g8.rec(idx)
         if (i, gname) not in self.g8_seen:            # first use: calibrate on the device
@@ -514,20 +516,20 @@ class Stack:
         if f8b:
             self.g8.update()                   # delayed scaling of the gradient operands: last backward's amax -> this backward's scales
             self.g8_have = set()               # (block, operand) whose e5m2 copy a producer has written in this backward
-            if self.wt8_batch is None and getattr(self, "_wt8_pending", None) is not None and len(self._wt8_pending) == 3 * self.nblocks * (2 if blocks2 is not None else 1):
+            if self.wt8_batch is None and getattr(self, "_wt8_pending", None) is not None and len(self._wt8_pending) == 4 * self.nblocks * (2 if blocks2 is not None else 1):
                 self.wt8_batch = ops.Fp8Batch(self.f8)      # the transposed copies use the forward's weight records (the same tensors)
                 for src, dst, ridx in self._wt8_pending:
                     self.wt8_batch.add(src, dst, ridx)
                 self.wt8_batch.build(dxo.device)
             if self.wt8_batch is not None:
                 self.wt8_batch.run()
-        G8 = {"dbo": 0, "dfc1": 1, "dbm": 2}
+        G8 = {"dbo": 0, "dfc1": 1, "dbm": 2, "dqkv": 3}
 
         def g8rec(blk, name):                  # (e5m2 buffer, record) of a gradient operand once calibrated, else (None, None)
             if not f8b or blk < 0 or (blk, name) not in self.g8_seen:
                 return None, None
             self.g8_have.add((blk, name))
-            return {"dbo": self.dx8[0], "dbm": self.dx8[1], "dfc1": self.dfc1_8}[name], self.g8.rec(blk * 4 + G8[name])
+            return {"dbo": self.dx8[0], "dbm": self.dx8[1], "dfc1": self.dfc1_8, "dqkv": self.dqkv8}[name], self.g8.rec(blk * 4 + G8[name])
 
         for i in reversed(range(self.nblocks)):
             bp, st = blocks[i], self.stats[i]
@@ -583,14 +585,22 @@ class Stack:
             else:
                 wgrads(i, "dbm", (dbm, self.att[i], "proj"))
                 side.before_write("dqkv")
+            a8 = {}
+            if f8b:                                # the attention backward kernels write the e5m2 copy of dqkv themselves once its record is calibrated
+                d8, q8_ = g8rec(i, "dqkv")
+                if d8 is not None:
+                    a8 = {"dqkv8": d8, "q8": q8_}
             if self.tiles_bwd.ntiles:
-                ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv)
+                ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv, **a8)
             for sq in self.fused_bwd:
-                ops.attn_bwd_fused(self.qkv[i], sq, self.H, self.att[i], self.datt, self.lse[i], self.dqkv)
+                ops.attn_bwd_fused(self.qkv[i], sq, self.H, self.att[i], self.datt, self.lse[i], self.dqkv, **a8)
             # qkv
             if excl:
                 side.join()
-            ops.gemm_nt(self.dqkv, bp.qkv.wt, self.dln, M, dual=(split, b2.qkv.wt, None, None) if b2 is not None else None)
+            if f8b:
+                self._dgrad_fp8(i, "dqkv", "qkv", self.dqkv, self.dqkv8, bp.qkv, b2.qkv if b2 else None, split, self.dln)
+            else:
+                ops.gemm_nt(self.dqkv, bp.qkv.wt, self.dln, M, dual=(split, b2.qkv.wt, None, None) if b2 is not None else None)
             wgrads(i, "dqkv", (self.dqkv, self.ln1[i], "qkv"))
             if not excl:
                 side.before_write("dbo")

@@ -416,8 +416,11 @@ def attn_fwd(qkv, tiles, H, out, lse, out8=None, q8=None):
             lse, lse.shape[1], out8, out8.stride(0) if out8 is not None else 0, _qrec(q8), _stream())
 
 
-def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
-    _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2)
+def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None):
+    """dqkv8 / q8 (fp8 backward): also write the e5m2 copy of dqkv - the gradient operand of the fp8 qkv input-gradient GEMM - scaled by
+    the device record q8, whose running amax takes the largest |dqkv| written"""
+    _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2); _chk(dqkv8, U8, "attnb.dqkv8", 2)
+    assert (dqkv8 is None) == (q8 is None) and (dqkv8 is None or (dqkv8.shape[0] >= tiles.max_row and dqkv8.shape[1] == qkv.shape[1]))
     _chk(lse, F32, "attnb.lse", 2); _chk(delta, F32, "attnb.delta", 2); _chk(dqkv, BF16, "attnb.dqkv", 2)
     D = qkv.shape[1] // 3
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape and D // H in (32, 64, 80)
@@ -425,8 +428,8 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv):
     # algorithmic FLOP: 8 * sum L^2 * D - the four products of the backward (dV, dP, dQ, dK); the recomputation of S = Q.K^T that the
     # kernels pay instead of keeping an L x L tensor is NOT counted.  Algorithmic HBM bytes of the two kernels: dQ
     # reads q, k, v, o, dO and writes dq (+ delta); dK/dV reads q, k, v, dO and writes dk, dv
-    _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
-            out.stride(0), lse, delta, lse.shape[1], dqkv, _stream())
+    _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd_q8", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
+            out.stride(0), lse, delta, lse.shape[1], dqkv, dqkv8, dqkv8.stride(0) if dqkv8 is not None else 0, _qrec(q8), _stream())
 
 
 class AttnSeqs:
@@ -445,18 +448,20 @@ class AttnSeqs:
         self.sum_sq = float(sum(L * L for L in lens))
 
 
-def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv):
+def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv, dqkv8=None, q8=None):
     """dq, dk, dv of the sequences in `seqs` (each at most seqs.max_len = 64 | 128 tokens) in one kernel: one read of q, k, v, o, dO and
     one evaluation of S per (sequence, head).  Rows of other sequences are not touched."""
     _chk(qkv, BF16, "attnf.qkv", 2); _chk(out, BF16, "attnf.out", 2); _chk(dout, BF16, "attnf.dout", 2)
-    _chk(lse, F32, "attnf.lse", 2); _chk(dqkv, BF16, "attnf.dqkv", 2)
+    _chk(lse, F32, "attnf.lse", 2); _chk(dqkv, BF16, "attnf.dqkv", 2); _chk(dqkv8, U8, "attnf.dqkv8", 2)
+    assert (dqkv8 is None) == (q8 is None) and (dqkv8 is None or (dqkv8.shape[0] >= seqs.max_row and dqkv8.shape[1] == qkv.shape[1]))
     D = qkv.shape[1] // 3
     assert seqs.nseq > 0 and seqs.max_len in (64, 128) and D // H in (32, 64) and D % H == 0
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape
     assert qkv.shape[0] >= seqs.max_row and out.shape[0] >= seqs.max_row and lse.shape[0] == H and lse.shape[1] >= seqs.max_row
     # algorithmic work: 8 * sum L^2 * D FLOP; q, k, v, o, dO read and dq, dk, dv written once (bf16), lse read
-    _launch("attn_bwd_hd%d" % (D // H), (8.0 * seqs.sum_sq * D, seqs.rows * (16.0 * D + 4.0 * H)), "avs_attn_bwd_fused", qkv, qkv.stride(0), D, H, seqs.start,
-            seqs.len, seqs.nseq, seqs.max_len, out, dout, out.stride(0), lse, lse.shape[1], dqkv, _stream())
+    _launch("attn_bwd_hd%d" % (D // H), (8.0 * seqs.sum_sq * D, seqs.rows * (16.0 * D + 4.0 * H)), "avs_attn_bwd_fused_q8", qkv, qkv.stride(0), D, H, seqs.start,
+            seqs.len, seqs.nseq, seqs.max_len, out, dout, out.stride(0), lse, lse.shape[1], dqkv, dqkv8, dqkv8.stride(0) if dqkv8 is not None else 0,
+            _qrec(q8), _stream())
 
 
 # ---------------------------------------------------------------------------------------------------
