@@ -1342,6 +1342,193 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
 // Up to three weight gradients over the same M token rows in ONE launch (problem i absent when Ai is NULL; problem 0 must exist):
 // Ci[N1i, N2i] += Ai[M, N1i]^T . Bi[M, N2i].  8-phase 256 x 256 kernel only: every N1i, N2i a multiple of 256 and M >= 512.
 // Shapes that do not qualify (or the 8-phase kernels switched off) are issued as one avs_gemm_tn_bf16 launch per problem.
+// ---------------------------------------------------------------------------------------------------
+// fp8 weight gradients (round 4; engine.FP8 = 3): C[N1,N2] += (1 / (sa sb)) (sa dY)^T (sb X) with dY in e5m2 and X in e4m3 - the copies
+// the producers already write for the fp8 forward / input-gradient GEMMs.  Same 256 x 256 output tile, same split over the token rows and
+// fp32 atomics as gemm_tn8_kernel; what changes is the contraction: a 64-row STAGE is one v_mfma_f32_32x32x64_f8f6f4 per 32 x 32 output
+// block (64 cycles) instead of four v_mfma_f32_32x32x16_bf16 (4 x 32), and the staged tiles are [64 rows][256 bytes] (16 KB per operand).
+// Fragments: lane (i = lane & 31, h = lane >> 5) of an operand holds the 32 contraction values k = 32 h .. 32 h + 31 of column i - four
+// ds_read_b64_tr_b8 (probed on hardware: in a 16-lane group lane t addresses 8 bytes of row t / 2 at column 8 (t & 1); lane i receives
+// column i of the 8 x 16 block, rows in byte order), i.e. a quarter of the bf16 kernel's LDS read instructions per contraction value -
+// the bf16 kernel is bound by exactly those.  Conflict-free image: the 16-byte chunk c of row r sits at position c ^ ((r & 7) << 1) (applied
+// to the DMA source address and to the read), so the 8 rows of a transposing read fall on 8 different bank groups.
+// Three stage buffers of 32 KB: [A rows 0-31 | A rows 32-63 | B rows 0-31 | B rows 32-63], each 8-KB granule one 16-byte LDS-DMA per thread;
+// stage t + 2 is requested when stage t's reads are issued, the wait in front of a stage's barrier leaves the next stage's four DMAs in
+// flight.  (No two-group phase offset yet: one barrier per stage, every wave in the same phase.)
+struct TnProb8 {
+    const uint8_t* A; long long lda;         // e5m2 gradient [M, N1]
+    const uint8_t* B; long long ldb;         // e4m3 activation [M, N2]
+    float* C; long long ldc;
+    const float* qa; const float* qb;        // device records of the two operands: the product is scaled by qa[INV] * qb[INV]
+    int N1, N2, tile0;
+};
+struct GemmTn8Args {
+    TnProb8 p[3];
+    int nprob, tiles, M, stages_per_split;
+};
+
+__global__ __launch_bounds__(512) void gemm_tn8f_kernel(GemmTn8Args g) {
+    constexpr int T1 = 256, T2 = 256, MI = 4;
+    constexpr int GRAN = 32 * 256, STAGE = 4 * GRAN, NBUF = 3;          // 8-KB granule, 32-KB stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / g.tiles;
+    int tile = lid % g.tiles;
+    const int pi = (g.nprob > 2 && tile >= g.p[2].tile0) ? 2 : (g.nprob > 1 && tile >= g.p[1].tile0) ? 1 : 0;
+    const TnProb8 a = g.p[pi];
+    tile -= a.tile0;
+    const int tiles2 = a.N2 / T2;
+    const int n2_0 = (tile % tiles2) * T2, n1_0 = (tile / tiles2) * T1;
+    const int nstages = (g.M + 63) / 64;
+    const int s_begin = split * g.stages_per_split;
+    const int nst = min(nstages, s_begin + g.stages_per_split) - s_begin;
+    if (nst <= 0) return;
+    const float alpha = a.qa[AVS_Q_INV] * a.qb[AVS_Q_INV];
+
+    // this thread's chunk of a granule: row tid / 16 of its 32, physical chunk position tid % 16 <- logical chunk (tid % 16) ^ ((row & 7) << 1)
+    const int grow = tid >> 4, gch = (tid & 15) ^ ((grow & 7) << 1);
+    const uint8_t* srcA = a.A + (size_t)(s_begin * 64 + grow) * a.lda + n1_0 + gch * 16;
+    const uint8_t* srcB = a.B + (size_t)(s_begin * 64 + grow) * a.ldb + n2_0 + gch * 16;
+    auto dma = [&](int t) {                                              // the four granules of stage t
+        char* dst = smem + (t % NBUF) * STAGE + wave * 1024;
+        const size_t r = (size_t)t * 64;
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA + r * a.lda), (LDS_AS void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA + (r + 32) * a.lda), (LDS_AS void*)(dst + GRAN), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB + r * a.ldb), (LDS_AS void*)(dst + 2 * GRAN), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB + (r + 32) * a.ldb), (LDS_AS void*)(dst + 3 * GRAN), 16, 0, 0);
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets inside a stage: lane = 16 G + t; h = G >> 1 picks the granule (rows 32 h ..), G & 1 the 16-column half of the
+    // 32-column block; the read of row group q (rows 8 q .. 8 q + 7 of the granule) is the immediate offset q * 2048
+    const int t16 = lane & 15, G = lane >> 4, hh = G >> 1, cb = G & 1;
+    auto frag_off = [&](int colbase) {
+        const int c = (colbase >> 4) + cb;                                  // logical 16-byte chunk of the row
+        return hh * GRAN + (t16 >> 1) * 256 + ((c ^ (t16 & 14)) << 4) + (t16 & 1) * 8;
+    };
+    unsigned offA[MI], offB[2];
+    const unsigned smem_lds = (unsigned)(size_t)(LDS_AS const char*)smem;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) offA[i] = smem_lds + frag_off(wr * (MI * 32) + i * 32);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) offB[j] = smem_lds + 2 * GRAN + frag_off(wc * 64 + j * 32);
+
+    dma(0);
+    if (nst > 1) dma(1);
+    for (int t = 0; t < nst; ++t) {
+        if (t + 1 < nst) wait_vm<4>(); else wait_vm<0>();                  // stage t has landed (this wave's part); stage t + 1 stays in flight
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                      // ... everybody's part; and everybody is done reading stage t - 1
+        asm volatile("" ::: "memory");
+        const unsigned sb = (t % NBUF) * STAGE;
+        unsigned long long fa[MI][4], fb[2][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const unsigned ad = offA[i] + sb;
+            asm volatile("ds_read_b64_tr_b8 %0, %4\n\tds_read_b64_tr_b8 %1, %4 offset:2048\n\tds_read_b64_tr_b8 %2, %4 offset:4096\n\tds_read_b64_tr_b8 %3, %4 offset:6144"
+                         : "=&v"(fa[i][0]), "=&v"(fa[i][1]), "=&v"(fa[i][2]), "=&v"(fa[i][3]) : "v"(ad) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned ad = offB[j] + sb;
+            asm volatile("ds_read_b64_tr_b8 %0, %4\n\tds_read_b64_tr_b8 %1, %4 offset:2048\n\tds_read_b64_tr_b8 %2, %4 offset:4096\n\tds_read_b64_tr_b8 %3, %4 offset:6144"
+                         : "=&v"(fb[j][0]), "=&v"(fb[j][1]), "=&v"(fb[j][2]), "=&v"(fb[j][3]) : "v"(ad) : "memory");
+        }
+        if (t + 2 < nst) dma(t + 2);                                       // into the buffer stage t - 1 was read from (all waves are past the barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const i32x8 av = {(int)fa[i][0], (int)(fa[i][0] >> 32), (int)fa[i][1], (int)(fa[i][1] >> 32), (int)fa[i][2], (int)(fa[i][2] >> 32),
+                              (int)fa[i][3], (int)(fa[i][3] >> 32)};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const i32x8 bv = {(int)fb[j][0], (int)(fb[j][0] >> 32), (int)fb[j][1], (int)(fb[j][1] >> 32), (int)fb[j][2], (int)(fb[j][2] >> 32),
+                                  (int)fb[j][3], (int)(fb[j][3] >> 32)};
+                // cbsz = 1: the first operand (the gradient) is e5m2; blgp = 0: the second (the activation) e4m3; unscaled
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 1, 0, 0, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n2 = n2_0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n1 = n1_0 + wr * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                atomicAdd(a.C + (size_t)n1 * a.ldc + n2, alpha * acc[i][j][r]);
+            }
+        }
+}
+
+// up to three fp8 weight gradients over the same M token rows: Ci[N1_i, N2_i] += Ai^T . Bi / (scale_a scale_b), Ai e5m2 [M, N1_i], Bi e4m3
+// [M, N2_i] (both allocated and ZERO up to the next multiple of 64 rows), qai / qbi their device records; every N a multiple of 256
+extern "C" int avs_gemm_tn_fp8_group3(const uint8_t* A0, long long lda0, const uint8_t* B0, long long ldb0, float* C0, int N1_0, int N2_0, const float* qa0, const float* qb0,
+                                      const uint8_t* A1, long long lda1, const uint8_t* B1, long long ldb1, float* C1, int N1_1, int N2_1, const float* qa1, const float* qb1,
+                                      const uint8_t* A2, long long lda2, const uint8_t* B2, long long ldb2, float* C2, int N1_2, int N2_2, const float* qa2, const float* qb2,
+                                      int M, hipStream_t stream) {
+    const uint8_t* As[3] = {A0, A1, A2};
+    const uint8_t* Bs[3] = {B0, B1, B2};
+    float* Cs[3] = {C0, C1, C2};
+    const float* qas[3] = {qa0, qa1, qa2};
+    const float* qbs[3] = {qb0, qb1, qb2};
+    const long long las[3] = {lda0, lda1, lda2}, lbs[3] = {ldb0, ldb1, ldb2};
+    const int n1s[3] = {N1_0, N1_1, N1_2}, n2s[3] = {N2_0, N2_1, N2_2};
+    AVS_CHECK_ARG(A0 && M > 0, "gemm_tn_fp8_group3: the first problem must exist");
+    GemmTn8Args g{};
+    int n = 0, tiles = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (!As[i]) continue;
+        AVS_CHECK_ARG(Bs[i] && Cs[i] && qas[i] && qbs[i] && n1s[i] > 0 && n2s[i] > 0 && (las[i] % 16) == 0 && (lbs[i] % 16) == 0 && las[i] >= n1s[i] && lbs[i] >= n2s[i],
+                      "gemm_tn_fp8_group3: bad operands of problem %d", i);
+        AVS_CHECK_ARG((n1s[i] % 256) == 0 && (n2s[i] % 256) == 0, "gemm_tn_fp8_group3: N1 and N2 must be multiples of 256 (problem %d: %d x %d)", i, n1s[i], n2s[i]);
+        g.p[n] = TnProb8{As[i], las[i], Bs[i], lbs[i], Cs[i], (long long)n2s[i], qas[i], qbs[i], n1s[i], n2s[i], tiles};
+        tiles += (n1s[i] / 256) * (n2s[i] / 256);
+        ++n;
+    }
+    const int nstages = ceil_div(M, 64);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_tn8f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) != hipSuccess) {
+            avs_set_error("gemm_tn_fp8_group3: hipFuncSetAttribute failed");
+            return -1;
+        }
+        attr_done = true;
+    }
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    }
+    int splits = ncu / tiles;                              // one resident round, rounded DOWN (as avs_gemm_tn_bf16_group3)
+    if (splits < 1) splits = 1;
+    if (splits > nstages / 2) splits = nstages / 2 > 0 ? nstages / 2 : 1;
+    const int per = ceil_div(nstages, splits);
+    splits = ceil_div(nstages, per);
+    g.nprob = n; g.tiles = tiles; g.M = M; g.stages_per_split = per;
+    gemm_tn8f_kernel<<<tiles * splits, 512, 98304, stream>>>(g);
+    AVS_LAUNCH_CHECK("gemm_tn_fp8_group3");
+    return 0;
+}
+
 extern "C" int avs_gemm_tn_bf16_group3(const bf16_t* A0, long long lda0, const bf16_t* B0, long long ldb0, float* C0, int N1_0, int N2_0,
                                        const bf16_t* A1, long long lda1, const bf16_t* B1, long long ldb1, float* C1, int N1_1, int N2_1,
                                        const bf16_t* A2, long long lda2, const bf16_t* B2, long long ldb2, float* C2, int N1_2, int N2_2,

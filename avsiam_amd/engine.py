@@ -218,8 +218,12 @@ class Stack:
         self.inference = inference
         self.nrecomp = 0 if inference else recompute_blocks(nblocks)     # blocks [0, nrecomp) keep no activations (one shared set)
         self.recompute = self.nrecomp > 0
-        self.fp8 = FP8 in ("1", "2") and D % 256 == 0 and hidden % 256 == 0 and D >= 256     # the fp8 GEMM's tile constraints (N % 256, K % 128)
-        self.fp8_bwd = self.fp8 and FP8 == "2" and not inference
+        self.fp8 = FP8 in ("1", "2", "3") and D % 256 == 0 and hidden % 256 == 0 and D >= 256     # the fp8 GEMM's tile constraints (N % 256, K % 128)
+        self.fp8_bwd = self.fp8 and FP8 in ("2", "3") and not inference
+        # FP8 = 3 (round 4): the four weight gradients of a block on fp8 operands too (ops.gemm_tn_fp8_group: e5m2 gradient copies x
+        # e4m3 activation copies).  The e4m3 copy of an activation is then KEPT per block (one more byte per element beside the bf16
+        # copy the attention / LayerNorm backward still read) instead of living in one buffer per stack.
+        self.fp8_wgrad = self.fp8_bwd and FP8 == "3"
         if self.fp8:
             r8 = ops.pad_rows(rows, 256)
             self.a8 = torch.zeros((r8, max(D, hidden)), dtype=U8, device=dev)      # calibration step only: an activation quantised by a pass
@@ -230,9 +234,16 @@ class Stack:
             self.w8_off = {"qkv": 0, "proj": 3 * D * D, "fc1": 4 * D * D, "fc2": 4 * D * D + D * hidden}
             self.w8_per_blk = per_blk
             self.w8_batch = None                                                   # built after the calibration forward
-            self.ln8 = torch.zeros((r8, D), dtype=U8, device=dev)                  # e4m3 copy a LayerNorm writes for qkv / fc1
-            self.att8 = torch.zeros((r8, D), dtype=U8, device=dev)                 # ... the attention epilogue for proj
-            self.act8 = torch.zeros((r8, hidden), dtype=U8, device=dev)            # ... and fc1's GELU epilogue for fc2
+            def blocks8(cols, shared=None):     # per block when the weight gradients read them (recomputed blocks share one, like their bf16 copies)
+                if not self.fp8_wgrad:
+                    one = shared if shared is not None else torch.zeros((r8, cols), dtype=U8, device=dev)
+                    return [one] * nblocks
+                one = torch.zeros((r8, cols), dtype=U8, device=dev) if self.nrecomp else None
+                return [one if i < self.nrecomp else torch.zeros((r8, cols), dtype=U8, device=dev) for i in range(nblocks)]
+            self.ln1_8 = blocks8(D)                                                # e4m3 copy a LayerNorm writes for qkv ...
+            self.ln2_8 = blocks8(D, None if self.fp8_wgrad else self.ln1_8[0])     # ... and for fc1 (one buffer serves both unless they are kept)
+            self.att8 = blocks8(D)                                                 # ... the attention epilogue for proj
+            self.act8 = blocks8(hidden)                                            # ... and fc1's GELU epilogue for fc2
             self.f8 = ops.Fp8Records(nblocks * 12, dev)                            # per block: 4 GEMMs x (activation, weight, second weight set)
             self.f8_seen = set()                                                   # (block, gemm) whose records hold a calibrated scale
         if self.fp8_bwd:
@@ -377,17 +388,21 @@ class Stack:
         x, st = self.x[i], self.stats[i]
         seen = lambda name: (i, name) in self.f8_seen
         r = lambda name: self._rec(i, name)
-        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod, y8=self.ln8 if seen("qkv") else None,
+        l1, l2, at8, ac8 = self.ln1_8[i], self.ln2_8[i], self.att8[i], self.act8[i]
+        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod, y8=l1 if seen("qkv") else None,
                 q8_dev=r("qkv") if seen("qkv") else None)
-        self._gemm_fp8(i, "qkv", self.ln1[i], self.ln8, bp.qkv, b2.qkv if b2 else None, split, self.qkv[i], scale_cols=self.D, col_scale=self.q_scale)
-        ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i], **({"out8": self.att8, "q8": r("proj")} if seen("proj") else {}))
-        self._gemm_fp8(i, "proj", self.att[i], self.att8, bp.proj, b2.proj if b2 else None, split, self.xmid[i], res=x)
-        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod, y8=self.ln8 if seen("fc1") else None,
+        self._gemm_fp8(i, "qkv", self.ln1[i], l1, bp.qkv, b2.qkv if b2 else None, split, self.qkv[i], scale_cols=self.D, col_scale=self.q_scale)
+        ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i], **({"out8": at8, "q8": r("proj")} if seen("proj") else {}))
+        self._gemm_fp8(i, "proj", self.att[i], at8, bp.proj, b2.proj if b2 else None, split, self.xmid[i], res=x)
+        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod, y8=l2 if seen("fc1") else None,
                 q8_dev=r("fc1") if seen("fc1") else None)
-        o8 = {"out8": self.act8, "q8": r("fc2")} if (seen("fc2") and last_gemm) else {}
-        self._gemm_fp8(i, "fc1", self.ln2[i], self.ln8, bp.fc1, b2.fc1 if b2 else None, split, self.fc1[i], out2=self.act[i], act=1, **o8)
+        # (the fc2 weight gradient reads the e4m3 copy of gelu(x) too: with fp8 weight gradients it is written even when fc2 itself is skipped)
+        o8 = {"out8": ac8, "q8": r("fc2")} if (seen("fc2") and (last_gemm or self.fp8_wgrad)) else {}
+        self._gemm_fp8(i, "fc1", self.ln2[i], l2, bp.fc1, b2.fc1 if b2 else None, split, self.fc1[i], out2=self.act[i], act=1, **o8)
         if last_gemm:
-            self._gemm_fp8(i, "fc2", self.act[i], self.act8, bp.fc2, b2.fc2 if b2 else None, split, self.x[i + 1], res=self.xmid[i])
+            self._gemm_fp8(i, "fc2", self.act[i], ac8, bp.fc2, b2.fc2 if b2 else None, split, self.x[i + 1], res=self.xmid[i])
+        elif self.fp8_wgrad and not seen("fc2"):
+            raise RuntimeError("fp8 weight gradients: a recomputed block met an uncalibrated fc2 record")
 
     def _gemm_fp8(self, i, name, A, a8, lin, lin2, split, out, **kw):
         """One forward GEMM on e4m3 operands.  a8: where this GEMM's activation lives in e4m3 once its producer writes it."""
@@ -403,7 +418,10 @@ class Stack:
                 ops.absmax_into(W2, rw2)
             self.f8.update(first=(i * 4 + self._G8[name]) * 3, count=3)
             self.f8_seen.add((i, name))
-            a8 = self.a8[:A.shape[0], :K] if self.a8.shape[1] == K else self.a8.view(-1)[:A.shape[0] * K].view(A.shape[0], K)
+            if self.fp8_wgrad:                     # the block's own e4m3 copy: the weight gradient of this step reads it
+                a8 = a8[:A.shape[0]]
+            else:
+                a8 = self.a8[:A.shape[0], :K] if self.a8.shape[1] == K else self.a8.view(-1)[:A.shape[0] * K].view(A.shape[0], K)
             ops.quantize_fp8(A, 1.0, out=a8, q=ra)
         w8 = self._w8(i, name, 0)
         w8b = self._w8(i, name, 1) if W2 is not None else None
@@ -504,6 +522,18 @@ class Stack:
         def wgrads(blk, key, *jobs):
             def fn():      # the jobs of one call share their token rows: one grouped launch per row range (ops.gemm_tn_group)
                 for lo, hi, bl in ranges:
+                    if self.fp8_wgrad:
+                        # fp8 mode 3: the e5m2 copy of the gradient (written by its producer or by the input-gradient GEMM's quantising
+                        # pass just before) x the block's e4m3 copy of the layer input, with the two operands' device records
+                        src = {"fc2": (self.dx8[0], "dbo", self.act8), "fc1": (self.dfc1_8, "dfc1", self.ln2_8), "proj": (self.dx8[1], "dbm", self.att8),
+                               "qkv": (self.dqkv8, "dqkv", self.ln1_8)}
+                        jobs8 = []
+                        for a, b, name in jobs:
+                            g8buf, gname, x8 = src[name]
+                            assert (blk, gname) in self.g8_seen and (blk, name) in self.f8_seen
+                            jobs8.append((g8buf[lo:], x8[blk][lo:], getattr(bl[blk], name).gw, self.g8.rec(blk * 4 + G8[gname]), self._rec(blk, name, 0)))
+                        ops.gemm_tn_fp8_group(jobs8, hi - lo)
+                        continue
                     trip = [(a[lo:], b[lo:], getattr(bl[blk], name).gw) for a, b, name in jobs]
                     if WGRAD_GROUP:
                         ops.gemm_tn_group(trip, hi - lo)

@@ -370,6 +370,23 @@ def gemm_tn_group(jobs, M):
     _launch("gemm_tn", flops, "avs_gemm_tn_bf16_group3", *args, M, _stream())
 
 
+def gemm_tn_fp8_group(jobs, M):
+    """jobs: 1-3 tuples (A8 [M,N1] e5m2 gradient copy, B8 [M,N2] e4m3 activation copy, C [N1*N2] fp32, qa, qb) over the same M token rows:
+    C += A8^T @ B8 / (scale_a * scale_b) in ONE launch of the fp8 weight-gradient kernel (avs_gemm_tn_fp8_group3; fp8 mode 3)"""
+    assert 1 <= len(jobs) <= 3
+    need = pad_rows(M, 64)
+    args, flops = [], 0.0
+    for A, B, C, qa, qb in jobs:
+        _chk(A, U8, "wgrad8.A", 2); _chk(B, U8, "wgrad8.B", 2); _chk(C, F32, "wgrad8.C")
+        N1, N2 = A.shape[1], B.shape[1]
+        assert A.shape[0] >= need and B.shape[0] >= need, "wgrad operands must be allocated (zero) to a multiple of 64 rows"
+        assert C.numel() == N1 * N2 and N1 % 256 == 0 and N2 % 256 == 0
+        args += [A, A.stride(0), B, B.stride(0), C, N1, N2, _qrec(qa), _qrec(qb)]
+        flops += 2.0 * M * N1 * N2
+    args += [None, 0, None, 0, None, 0, 0, None, None] * (3 - len(jobs))
+    _launch("gemm_tn_fp8", flops, "avs_gemm_tn_fp8_group3", *args, M, _stream())
+
+
 # ---------------------------------------------------------------------------------------------------
 class AttnTiles:
     """(sequence start, length, q0) per tile of `tile_rows` (128 or 64) rows for a packed batch of sequences."""

@@ -258,7 +258,8 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) forward GEMMs (engine.FP8): configs[4]'s fp8 MFMA path as an extra data point; "
                     "the line then says dtype fp8-forward/bf16-backward and is NOT the headline metric")
-    ap.add_argument("--fp8-dgrad", action="store_true", help="with --fp8: the fc2 / fc1 / proj input-gradient GEMMs on e5m2 gradient operands too (engine.FP8 = 2)")
+    ap.add_argument("--fp8-dgrad", action="store_true", help="with --fp8: the four input-gradient GEMMs of a block on e5m2 gradient operands too (engine.FP8 = 2)")
+    ap.add_argument("--fp8-wgrad", action="store_true", help="with --fp8: input gradients AND the four weight gradients of a block on fp8 operands (engine.FP8 = 3)")
     ap.add_argument("--recompute", nargs="?", const="1", default=None, metavar="FRACTION",
                     help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved activations do not fit the GPU, e.g. "
                          "--model vit_huge14 at batch 64; with a FRACTION (0.375) only that share of every stack's blocks is recomputed and "
@@ -338,7 +339,7 @@ def main():
             _engine.recompute_blocks(1, args.recompute)       # validates the value
             _engine.RECOMPUTE = args.recompute
         if args.fp8:
-            _engine.FP8 = "2" if args.fp8_dgrad else "1"
+            _engine.FP8 = "3" if args.fp8_wgrad else "2" if args.fp8_dgrad else "1"
     comm = None
     if share and world > 1:
         from avsiam_amd.comm import HostStagedComm
@@ -442,7 +443,7 @@ def main():
         line = {
             "metric": f"AV pretrain samples/sec ({mname}, 75% mask)", "value": sps, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("fp8(e4m3)-forward/fp8(e5m2 x e4m3)-input-gradients/bf16-weight-gradients" if args.fp8_dgrad else "fp8(e4m3)-forward/bf16-backward") if args.fp8 else "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("fp8(e4m3)-forward/fp8(e5m2 x e4m3)-input-and-weight-gradients" if args.fp8_wgrad else "fp8(e4m3)-forward/fp8(e5m2 x e4m3)-input-gradients/bf16-weight-gradients" if args.fp8_dgrad else "fp8(e4m3)-forward/bf16-backward") if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"AVSiam pretrain step (contrastive + MAE passes, 2x Adam), {mname}, {args.frames} frames x{cfg.video_tokens} + "
                                    f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
@@ -504,6 +505,8 @@ def main():
             more = [
                 fam(("gemm_tn",), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s", "gemm_tn8_kernel / gemm_tn_kernel (weight-gradient bf16 MFMA GEMMs, 2*M*N1*N2 FLOP per launch)",
                     traffic=pmc_traffic(args, "gemm.hip", "gemm_tn"), pmc=pmc_busy(args, "gemm.hip", "gemm_tn")),
+                fam(("gemm_tn_fp8",), "mfma", PEAK_FP8_TFLOPS, "TFLOP/s", "gemm_tn8f_kernel (--fp8-wgrad: a block's weight gradients on e5m2 gradient x e4m3 activation "
+                    "operands, v_mfma_f32_32x32x64_f8f6f4 on ds_read_b64_tr_b8 fragments; against the fp8 peak)"),
                 fam(("attn_fwd_hd32", "attn_bwd_hd32"), "mfma", PEAK_BF16_TFLOPS, "TFLOP/s",
                     "attn_fwd / attn_bwd_* <32> (decoder attention, hd 32; 4 / 8 * sum L^2 * D algorithmic FLOP per forward / backward launch - the "
                     "backward's recomputation of S is not counted)",

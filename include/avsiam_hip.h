@@ -137,6 +137,15 @@ int avs_gemm_tn_bf16_group3(const avs_bf16* A0, long long lda0, const avs_bf16* 
                             const avs_bf16* A2, long long lda2, const avs_bf16* B2, long long ldb2, float* C2, int N1_2, int N2_2,
                             int M, avs_stream_t stream);
 
+/* the same three-problem launch on fp8 operands (fp8 mode 3): Ai = the e5m2 copy of the output gradient [M, N1_i], Bi = the e4m3 copy of
+ * the layer input [M, N2_i] (both ZERO up to the next multiple of 64 rows; leading dimensions in bytes, multiples of 16), qai / qbi the two
+ * operands' device records (the product is de-quantised with qa[1] * qb[1]); every N a multiple of 256.  v_mfma_f32_32x32x64_f8f6f4 on
+ * fragments read with ds_read_b64_tr_b8; fp32 atomics into the gradient arena like the bf16 form. */
+int avs_gemm_tn_fp8_group3(const uint8_t* A0, long long lda0, const uint8_t* B0, long long ldb0, float* C0, int N1_0, int N2_0, const float* qa0, const float* qb0,
+                           const uint8_t* A1, long long lda1, const uint8_t* B1, long long ldb1, float* C1, int N1_1, int N2_1, const float* qa1, const float* qb1,
+                           const uint8_t* A2, long long lda2, const uint8_t* B2, long long ldb2, float* C2, int N1_2, int N2_2, const float* qa2, const float* qb2,
+                           int M, avs_stream_t stream);
+
 /* ---- varlen attention (F.scaled_dot_product_attention in Attention.forward, cav_mae_base.py:60-68) on the packed
  * qkv matrix [rows, 3*D] (q|k|v, head h at columns h*hd); one (tile_start, tile_len, tile_q0) triple per tile of
  * tile_rows (128: 4-wave workgroups; 64: 2-wave workgroups, twice as many resident per CU - for short sequences) rows.

@@ -437,6 +437,105 @@ def test_attention_bwd_fused_matches_two_kernel_form(H, hd):
         r0 += L
 
 
+@pytest.mark.parametrize("M", [640, 1000, 20001])
+def test_gemm_tn_fp8_weight_gradients(M):
+    """avs_gemm_tn_fp8_group3 (fp8 mode 3): C += A8^T . B8 / (sa sb) with A8 = e5m2 gradient copies and B8 = e4m3 activation copies, up to
+    three problems over the same token rows in one launch (v_mfma_f32_32x32x64_f8f6f4 on ds_read_b64_tr_b8 fragments, split over the rows,
+    fp32 atomics).  EXACT arithmetic given the operands: against the fp64 product of the de-quantised copies (fp32 accumulation error only),
+    accumulating onto what C already holds, rows beyond M (zero by contract) not contributing, and every split configuration of the three
+    shapes of a block (fc2 768 x 3072, fc1 3072 x 768, proj 768 x 768) plus the single-problem call (qkv 2304 x 768)."""
+    o = ops()
+    rp = o.pad_rows(M, 256)
+    gen = torch.Generator(device=DEV).manual_seed(M)
+
+    def operand(N, e5m2, scale):
+        x = torch.randn(M, N, device=DEV, generator=gen) * (0.02 if e5m2 else 1.0)
+        q = torch.zeros(rp, N, device=DEV, dtype=torch.uint8)
+        fmt = torch.float8_e5m2 if e5m2 else torch.float8_e4m3fn
+        q[:M] = (x * scale).to(fmt).view(torch.uint8)
+        return q, q[:M].view(fmt).double() / scale
+
+    recs = o.Fp8Records(8, DEV)
+    jobs, want = [], []
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    for k, (N1, N2) in enumerate(shapes):
+        sa, sb = 2.0 ** (10 + k), 2.0 ** (4 - k)           # powers of two: the de-quantised values are exact in bf16 (last check)
+        recs.q[2 * k, 0], recs.q[2 * k, 1] = sa, 1.0 / sa
+        recs.q[2 * k + 1, 0], recs.q[2 * k + 1, 1] = sb, 1.0 / sb
+        A8, Ad = operand(N1, True, sa)
+        B8, Bd = operand(N2, False, sb)
+        C = torch.randn(N1 * N2, device=DEV) * 0.1
+        want.append(C.double().view(N1, N2) + Ad.t() @ Bd)
+        jobs.append((A8, B8, C, recs.rec(2 * k), recs.rec(2 * k + 1)))
+    o.gemm_tn_fp8_group(jobs[:3], M)
+    o.gemm_tn_fp8_group(jobs[3:], M)
+    for (A8, B8, C, _, _), w, (N1, N2) in zip(jobs, want, shapes):
+        e = rel_err(C.view(N1, N2), w)
+        assert e < 5e-5, ((N1, N2), e)            # measured ~1e-5: the fp8 MFMA's internal summation (the fp8 nt GEMM shows the same, 1.4e-5)
+    # against the bf16 weight-gradient kernel on the same (de-quantised) operands: the same matrix up to bf16 operand rounding
+    A8, B8, C, qa, qb = jobs[2]
+    Ab = torch.zeros(rp, 768, device=DEV, dtype=torch.bfloat16); Bb = torch.zeros(rp, 768, device=DEV, dtype=torch.bfloat16)
+    Ab[:M] = (A8[:M].view(torch.float8_e5m2).float() / float(qa[0])).to(torch.bfloat16)
+    Bb[:M] = (B8[:M].view(torch.float8_e4m3fn).float() / float(qb[0])).to(torch.bfloat16)
+    C2 = torch.zeros(768 * 768, device=DEV)
+    o.gemm_tn(Ab, Bb, C2, M)
+    C3 = torch.zeros(768 * 768, device=DEV)
+    o.gemm_tn_fp8_group([(A8, B8, C3, qa, qb)], M)
+    assert rel_err(C3, C2) < 5e-5          # e5m2 / e4m3 values are exact in bf16: the two kernels multiply the same numbers
+
+
+@pytest.mark.parametrize("H,hd", [(2, 64), (3, 32), (2, 80)])
+def test_attention_bwd_writes_the_e5m2_copy_of_dqkv(H, hd):
+    """fp8 backward (engine.FP8 = 2): avs_attn_bwd_q8 / avs_attn_bwd_fused_q8 also write e5m2(dqkv * scale) - the gradient operand of the
+    fp8 qkv input-gradient GEMM - and fold max |dqkv| into the device record.  The bf16 output must be BIT-identical to the plain call,
+    the e5m2 copy must be the e5m2 rounding of what the kernels hold in fp32 (checked against the bf16 output: within one e5m2 step, 2^-2
+    relative, plus the bf16 rounding), untouched outside the sequences' rows, and the record's amax must equal max |dqkv|."""
+    o = ops()
+    D = H * hd
+    lens = [39, 200, 64, 130, 128, 300, 7] if hd != 80 else [200, 130, 300, 129]       # hd 80: no fused kernel, two-kernel form only
+    rows = sum(lens)
+    rp = o.pad_rows(rows, 256)
+    qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(rows, 3 * D, device=DEV)
+    x[:, :D] *= o.attn_q_scale(hd)
+    qkv[:rows] = bf(x)
+    tr = 128 if hd == 80 else 64
+    fwd_tiles = o.AttnTiles(lens, DEV, tile_rows=tr)
+    out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(H, rp, device=DEV)
+    o.attn_fwd(qkv, fwd_tiles, H, out, lse)
+    dout = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    dout[:rows] = bf(torch.randn(rows, D, device=DEV))
+    cut = 0 if hd == 80 else 128
+    tiles = o.AttnTiles(lens, DEV, tile_rows=tr, min_len=cut)
+    fused = [] if hd == 80 else [sq for sq in (o.AttnSeqs(lens, DEV, 0, 64), o.AttnSeqs(lens, DEV, 64, 128)) if sq.nseq]
+
+    def run(d8=None, rec=None):
+        dq = torch.zeros_like(qkv)
+        delta = torch.zeros_like(lse)
+        kw = {} if d8 is None else {"dqkv8": d8, "q8": rec}
+        o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dq, **kw)
+        for sq in fused:
+            o.attn_bwd_fused(qkv, sq, H, out, dout, lse, dq, **kw)
+        return dq
+
+    plain = run()
+    recs = o.Fp8Records(1, DEV, fmax=o.BF8_MAX)
+    amax = float(plain[:rows].float().abs().max())
+    scale = 0.25 * o.BF8_MAX / amax
+    recs.q[0, 0], recs.q[0, 1] = scale, 1.0 / scale
+    d8 = torch.full((rp, 3 * D), 0x7B, device=DEV, dtype=torch.uint8)                    # 0x7B = 57344 in e5m2: a value no gradient takes
+    got = run(d8, recs.rec(0))
+    assert torch.equal(got, plain)
+    deq = d8[:rows].view(torch.float8_e5m2).float() / scale
+    ref = plain[:rows].float()
+    err = (deq - ref).abs()
+    assert float((err / (ref.abs() + 1e-3 * amax)).max()) < 0.14, float((err / (ref.abs() + 1e-3 * amax)).max())   # half an e5m2 step (2^-3) + bf16
+    assert rel_err(deq, ref) < 0.08
+    assert bool((d8[rows:] == 0x7B).all())                                               # pad rows are not this kernel's
+    assert abs(recs.amax(0) - amax) <= 2.0 ** -7 * amax                                  # the record saw the fp32 values (bf16-rounded in `plain`)
+
+
 @pytest.mark.parametrize("H,hd,L,spike", [(2, 64, 200, 8.0), (2, 64, 200, 2.5), (4, 32, 300, 40.0), (4, 32, 300, 4.0)])
 def test_attention_spiked_scores(H, hd, L, spike):
     """Large score spread: the forward keeps the first key tile's row max as its reference and moves it only when a later

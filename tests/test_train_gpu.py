@@ -79,9 +79,12 @@ def test_train_loop_and_validate(tmp_path):
     assert torch.equal(m2._params["decoder_embed.weight"].cpu(), m._params["decoder_embed.weight"].cpu())
 
 
-def test_fp8_forward_with_recompute_trains_at_the_14x14_geometry():
-    """The combination behind the configs[4]-like bench line (ViT-H/14 geometry, fp8 forward GEMMs, per-layer activation recompute,
-    device-drawn plans): a few training steps on one fixed batch stay finite and reduce the MAE loss."""
+@pytest.mark.parametrize("mode,recompute", [("1", "1"), ("3", "1"), ("3", "0.5")])
+def test_fp8_forward_with_recompute_trains_at_the_14x14_geometry(mode, recompute):
+    """The combination behind the configs[4]-like bench line (ViT-H/14 geometry, fp8 GEMMs, per-layer activation recompute - whole or a
+    fraction of every stack -, device-drawn plans): a few training steps on one fixed batch stay finite and reduce the MAE loss.
+    mode "1": fp8 forward; mode "3": fp8 forward, input gradients and weight gradients (the recomputed blocks re-write the e4m3 copies the
+    weight gradients read)."""
     from avsiam_amd import engine
     from avsiam_amd.config import vit_huge14
     from avsiam_amd.models import CAVMAE_BASE
@@ -90,7 +93,7 @@ def test_fp8_forward_with_recompute_trains_at_the_14x14_geometry():
     a, v = synth_inputs(cfg, 4, 41)
     a, v = a.cuda(), v.cuda()
     try:
-        engine.FP8, engine.RECOMPUTE = "1", "1"
+        engine.FP8, engine.RECOMPUTE = mode, recompute
         m = CAVMAE_BASE(cfg=cfg, init_seed=7, init_mode="random", verbose=False, plan_seed=9).cuda()
         m.publish_grads = False
         hist, sat = [], []
