@@ -49,11 +49,17 @@ fi
 if has fp8; then
   python bench.py --no-cpu-baseline --steps 10 --fp8 > $OUT/b_vitb_fp8_bench.json 2> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 10 --fp8 --fp8-dgrad > $OUT/b_vitb_fp8_dgrad_bench.json 2>> $OUT/fp8.err
+  python bench.py --no-cpu-baseline --steps 10 --fp8 --fp8-wgrad > $OUT/b_vitb_fp8_wgrad_bench.json 2>> $OUT/fp8.err
+  python bench.py --no-cpu-baseline --steps 10 > $OUT/b_vitb_bf16_same_box_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute > $OUT/h_vit_huge14_b64_recompute_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 > $OUT/h_vit_huge14_b64_recompute_fp8_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute_fp8_dgrad_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.375 > $OUT/h_vit_huge14_b64_recompute0375_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.375 --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute0375_fp8_dgrad_bench.json 2>> $OUT/fp8.err
+  # fp8 weight gradients keep a fourth byte per activation element: 3/8 recomputed leaves 2 GiB of the card, so the data point is taken at 1/2
+  python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.5 --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute05_fp8_wgrad_bench.json 2>> $OUT/fp8.err
+  python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.5 --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute05_fp8_dgrad_bench.json 2>> $OUT/fp8.err
+  python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute_fp8_wgrad_bench.json 2>> $OUT/fp8.err
   python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/[bh]_*bench.json")):
