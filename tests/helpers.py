@@ -127,3 +127,10 @@ def ft_outputs_as_dict(d, out):
 
 
 from avsiam_amd.comm import HostStagedComm  # noqa: E402,F401  (gloo through the host: several ranks on the one GPU of the test box)
+
+
+class _Waited:
+    """a handle whose collective has already completed (test doubles of the comm interface)"""
+
+    def wait(self):
+        pass

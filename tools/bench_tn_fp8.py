@@ -1,3 +1,5 @@
+"""fp8 weight-gradient kernel (avs_gemm_tn_fp8_group3) against the bf16 8-phase kernel at the step's shapes: a block's fc2 | fc1 | proj
+gradients in one launch, and the qkv gradient alone (us per launch, TFLOP/s).  python tools/bench_tn_fp8.py"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 from avsiam_amd import ops as o
