@@ -1353,8 +1353,8 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
 // the bf16 kernel is bound by exactly those.  Conflict-free image: the 16-byte chunk c of row r sits at position c ^ ((r & 7) << 1) (applied
 // to the DMA source address and to the read), so the 8 rows of a transposing read fall on 8 different bank groups.
 // Three stage buffers of 32 KB: [A rows 0-31 | A rows 32-63 | B rows 0-31 | B rows 32-63], each 8-KB granule one 16-byte LDS-DMA per thread;
-// stage t + 2 is requested when stage t's reads are issued, the wait in front of a stage's barrier leaves the next stage's four DMAs in
-// flight.  (No two-group phase offset yet: one barrier per stage, every wave in the same phase.)
+// stage t + 2 is requested when stage t's reads are issued, the counted wait leaves its four DMAs in flight; the two wave groups run one
+// barrier apart (see the loop).
 struct TnProb8 {
     const uint8_t* A; long long lda;         // e5m2 gradient [M, N1]
     const uint8_t* B; long long ldb;         // e4m3 activation [M, N2]
@@ -1424,13 +1424,23 @@ __global__ __launch_bounds__(512) void gemm_tn8f_kernel(GemmTn8Args g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) offB[j] = smem_lds + 2 * GRAN + frag_off(wc * 64 + j * 32);
 
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // The two wave groups (wr = 0 / 1: one wave of each per SIMD) run the same two-barrier stage loop ONE barrier apart, so a group's 24
+    // fragment reads, its LDS-DMA issue and its waits run under the other group's eight MFMAs (512 matrix-pipe cycles) instead of beside
+    // its own reads.  Barrier k of group 0 is X1(k / 2) or X2(k / 2), of group 1 the extra one, then X1, X2, ...:
+    //   X1(t): stage t is complete in LDS - every wave waited for its own part of it in front of the previous barrier (prologue for t = 0);
+    //   then reads(t), the DMAs of stage t + 2 (into the buffer of stage t - 1: whichever group issues them, both have finished reading it -
+    //   the other group is one barrier behind or ahead and drained its reads in front of its X2), drain the reads, wait for the own part of
+    //   stage t + 1; X2(t); MFMAs(t).
     dma(0);
-    if (nst > 1) dma(1);
+    if (nst > 1) { dma(1); wait_vm<4>(); } else wait_vm<0>();
+    if (wr == 1) bar();
     for (int t = 0; t < nst; ++t) {
-        if (t + 1 < nst) wait_vm<4>(); else wait_vm<0>();                  // stage t has landed (this wave's part); stage t + 1 stays in flight
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                      // ... everybody's part; and everybody is done reading stage t - 1
-        asm volatile("" ::: "memory");
+        bar();                                                             // X1(t)
         const unsigned sb = (t % NBUF) * STAGE;
         unsigned long long fa[MI][4], fb[2][4];
 #pragma unroll
@@ -1445,8 +1455,10 @@ __global__ __launch_bounds__(512) void gemm_tn8f_kernel(GemmTn8Args g) {
             asm volatile("ds_read_b64_tr_b8 %0, %4\n\tds_read_b64_tr_b8 %1, %4 offset:2048\n\tds_read_b64_tr_b8 %2, %4 offset:4096\n\tds_read_b64_tr_b8 %3, %4 offset:6144"
                          : "=&v"(fb[j][0]), "=&v"(fb[j][1]), "=&v"(fb[j][2]), "=&v"(fb[j][3]) : "v"(ad) : "memory");
         }
-        if (t + 2 < nst) dma(t + 2);                                       // into the buffer stage t - 1 was read from (all waves are past the barrier)
+        if (t + 2 < nst) dma(t + 2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 2 < nst) wait_vm<4>(); else wait_vm<0>();                  // this wave's part of stage t + 1 has landed (stage t + 2 stays in flight)
+        bar();                                                             // X2(t)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1464,6 +1476,7 @@ __global__ __launch_bounds__(512) void gemm_tn8f_kernel(GemmTn8Args g) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (wr == 0) bar();                                                    // pairs with the other group's last X2
 
     const int h = lane >> 5;
 #pragma unroll

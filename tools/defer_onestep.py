@@ -2,6 +2,7 @@
 two runs of the SAME schedule, and of a deferred vs an undeferred run?  (diagnostic for tests/test_dp_gpu.py part A)
     python tools/defer_onestep.py [--procs 2] [--lr 1e-6]"""
 import argparse
+import math
 import os
 import sys
 
@@ -72,7 +73,7 @@ def worker(rank, world, port, args, q):
         b12, end = m.arena.range[P2]
         m1 = m._opt_state[P1]["m"].clone() if P1 in m._opt_state else None      # 0.05 x the contrastive pass's reduced gradient
         snaps.append((defer, m.arena.g[:end].clone(), m1))
-        names = [(n, m.arena.offset[n], m.arena.offset[n] + m.arena.info[n].shape.numel() if hasattr(m.arena.info[n].shape, "numel") else m.arena.offset[n] + int(__import__("math").prod(m.arena.info[n].shape))) for n in m.arena.names if m.arena.info[n].live]
+        names = [(n, m.arena.offset[n], m.arena.offset[n] + math.prod(m.arena.info[n].shape)) for n in m.arena.names if m.arena.info[n].live]
         del m
     rel = lambda x, y: float((x.double() - y.double()).norm() / x.double().norm())
     if True:
