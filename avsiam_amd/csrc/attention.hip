@@ -129,6 +129,57 @@ __device__ __forceinline__ void tile_store(const TileRegs<HD, NTH>& t, char* til
     }
 }
 
+// One 32-column block of an accumulator tile -> a row of the output.  A lane holds 16 values of ONE row (its query / key): four
+// consecutive columns at column 8 t + 4 hh for t = 0..3; lanes l and l + 32 hold the two halves of the same row.  Stored as they stand
+// that is four 8-byte pieces per lane and block (four 4-byte pieces for an fp8 copy), and the per-CU store path is issue-bound (cf. the
+// GEMM epilogue).  v_permlane32_swap hands each lane its partner's half of a 16-column pair instead: two 16-byte stores (two 8-byte
+// ones for fp8) of 8 consecutive columns.  ATTN_WIDE_STORE=0 (diagnostic builds) keeps the narrow form for A/B.
+#ifndef ATTN_WIDE_STORE
+#define ATTN_WIDE_STORE 1
+#endif
+template <int HG, bool BF8>
+__device__ __forceinline__ void store_block(bf16_t* rowp, int d, int hh, const f32x16& acc, float mul, uint8_t* rowp8, float s8, float& gmax) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    auto q8 = [&](float a, float b, float c, float e) {          // four values -> one dword of fp8 (e5m2 for gradients, e4m3 for activations)
+        gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(e)));
+        constexpr float M = BF8 ? 57344.f : 448.f;
+        int w;
+        if (BF8) {
+            w = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(a * s8, -M, M), __builtin_amdgcn_fmed3f(b * s8, -M, M), 0, false);
+            w = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(c * s8, -M, M), __builtin_amdgcn_fmed3f(e * s8, -M, M), w, true);
+        } else {
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a * s8, -M, M), __builtin_amdgcn_fmed3f(b * s8, -M, M), 0, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c * s8, -M, M), __builtin_amdgcn_fmed3f(e * s8, -M, M), w, true);
+        }
+        return (uint32_t)w;
+    };
+#if ATTN_WIDE_STORE
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (d * 32 + 16 * u >= HG) continue;                       // (HG is a multiple of 16: a pair is valid or not as a whole)
+        const float e0 = acc[8 * u + 0] * mul, e1 = acc[8 * u + 1] * mul, e2 = acc[8 * u + 2] * mul, e3 = acc[8 * u + 3] * mul;      // t = 2u
+        const float o0 = acc[8 * u + 4] * mul, o1 = acc[8 * u + 5] * mul, o2 = acc[8 * u + 6] * mul, o3 = acc[8 * u + 7] * mul;      // t = 2u + 1
+        // lanes 0-31 keep their t = 2u piece and receive the partner's (columns 16u .. 16u + 7); lanes 32-63 receive the partner's t = 2u + 1
+        // piece and keep theirs (columns 16u + 8 .. 16u + 15)
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pack_bf2(e0, e1), pack_bf2(o0, o1), false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pack_bf2(e2, e3), pack_bf2(o2, o3), false, false);
+        *reinterpret_cast<u32x4*>(rowp + d * 32 + 16 * u + 8 * hh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        if (rowp8) {
+            const auto r8 = __builtin_amdgcn_permlane32_swap(q8(e0, e1, e2, e3), q8(o0, o1, o2, o3), false, false);
+            *reinterpret_cast<uint2*>(rowp8 + d * 32 + 16 * u + 8 * hh) = make_uint2(r8[0], r8[1]);
+        }
+    }
+#else
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (d * 32 + 8 * t >= HG) continue;
+        const float v0 = acc[4 * t + 0] * mul, v1 = acc[4 * t + 1] * mul, v2 = acc[4 * t + 2] * mul, v3 = acc[4 * t + 3] * mul;
+        *reinterpret_cast<uint2*>(rowp + d * 32 + 8 * t + 4 * hh) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+        if (rowp8) *reinterpret_cast<uint32_t*>(rowp8 + d * 32 + 8 * t + 4 * hh) = q8(v0, v1, v2, v3);
+    }
+#endif
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -326,22 +377,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         bf16_t* orow = a.out + (size_t)(seq0 + qq) * a.ldo + head * HG;
         uint8_t* orow8 = a.out8 ? a.out8 + (size_t)(seq0 + qq) * a.ldo8 + head * HG : nullptr;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (d * 32 + 8 * t >= HG) continue;                    // columns of the image beyond the real head dim
-                const float v0 = o[d][4 * t + 0] * inv, v1 = o[d][4 * t + 1] * inv, v2 = o[d][4 * t + 2] * inv, v3 = o[d][4 * t + 3] * inv;
-                uint2 w;
-                w.x = pack_bf2(v0, v1);
-                w.y = pack_bf2(v2, v3);
-                *reinterpret_cast<uint2*>(orow + d * 32 + 8 * t + 4 * hh) = w;
-                if (orow8) {
-                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
-                    int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v0 * q8s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v1 * q8s, -448.f, 448.f), 0, false);
-                    w8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v2 * q8s, -448.f, 448.f), __builtin_amdgcn_fmed3f(v3 * q8s, -448.f, 448.f), w8, true);
-                    *reinterpret_cast<int*>(orow8 + d * 32 + 8 * t + 4 * hh) = w8;
-                }
-            }
+        for (int d = 0; d < NDB; ++d) store_block<HG, false>(orow, d, hh, o[d], inv, orow8, q8s, omax);      // (columns of the image beyond the real head dim are skipped)
         if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
     if (a.out8) q_amax_update(a.q8, omax, q8seen);
@@ -461,19 +497,9 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : 1) void attn_b
     const int qq = qw + (lane & 31);
     if (qq < L) {
         bf16_t* drow = a.dqkv + (size_t)(seq0 + qq) * a.ld + head * HG;
+        uint8_t* drow8 = G8 ? a.dqkv8 + (size_t)(seq0 + qq) * a.ld8 + head * HG : nullptr;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (d * 32 + 8 * t >= HG) continue;
-                uint2 w;
-                w.x = pack_bf2(dq[d][4 * t + 0] * a.scale, dq[d][4 * t + 1] * a.scale);
-                w.y = pack_bf2(dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale);
-                *reinterpret_cast<uint2*>(drow + d * 32 + 8 * t + 4 * hh) = w;
-                if (G8)
-                    store_bf8x4(a.dqkv8 + (size_t)(seq0 + qq) * a.ld8 + head * HG + d * 32 + 8 * t + 4 * hh, dq[d][4 * t + 0] * a.scale,
-                                dq[d][4 * t + 1] * a.scale, dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale, g8s, g8max);
-            }
+        for (int d = 0; d < NDB; ++d) store_block<HG, true>(drow, d, hh, dq[d], a.scale, drow8, g8s, g8max);
     }
     if (G8) q_amax_update(a.qd8, g8max, g8seen);
 }
@@ -589,25 +615,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     if (kq < L) {
         bf16_t* krow = a.dqkv + (size_t)(seq0 + kq) * a.ld + a.D + head * HG;
         bf16_t* vrow = krow + a.D;
+        uint8_t* krow8 = G8 ? a.dqkv8 + (size_t)(seq0 + kq) * a.ld8 + a.D + head * HG : nullptr;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (d * 32 + 8 * t >= HG) continue;
-                uint2 w;
-                // dK = dS^T . (q * scale) and the staged q is q * scale * log2(e)
-                w.x = pack_bf2(dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2);
-                w.y = pack_bf2(dk[d][4 * t + 2] * LN2, dk[d][4 * t + 3] * LN2);
-                *reinterpret_cast<uint2*>(krow + d * 32 + 8 * t + 4 * hh) = w;
-                w.x = pack_bf2(dv[d][4 * t + 0], dv[d][4 * t + 1]);
-                w.y = pack_bf2(dv[d][4 * t + 2], dv[d][4 * t + 3]);
-                *reinterpret_cast<uint2*>(vrow + d * 32 + 8 * t + 4 * hh) = w;
-                if (G8) {
-                    uint8_t* k8 = a.dqkv8 + (size_t)(seq0 + kq) * a.ld8 + a.D + head * HG + d * 32 + 8 * t + 4 * hh;
-                    store_bf8x4(k8, dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2, dk[d][4 * t + 2] * LN2, dk[d][4 * t + 3] * LN2, g8s, g8max);
-                    store_bf8x4(k8 + a.D, dv[d][4 * t + 0], dv[d][4 * t + 1], dv[d][4 * t + 2], dv[d][4 * t + 3], g8s, g8max);
-                }
-            }
+        for (int d = 0; d < NDB; ++d) {
+            store_block<HG, true>(krow, d, hh, dk[d], LN2, krow8, g8s, g8max);      // dK = dS^T . (q * scale) and the staged q is q * scale * log2(e)
+            store_block<HG, true>(vrow, d, hh, dv[d], 1.0f, G8 ? krow8 + a.D : nullptr, g8s, g8max);
+        }
     }
     if (G8) q_amax_update(a.qd8, g8max, g8seen);
 }
@@ -752,28 +765,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs a) {
         bf16_t* qrow = a.dqkv + (size_t)(seq0 + rl) * a.ld + head * HD;
         bf16_t* krow = qrow + a.D;
         bf16_t* vrow = krow + a.D;
+        uint8_t* q8p = G8 ? a.dqkv8 + (size_t)(seq0 + rl) * a.ld8 + head * HD : nullptr;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                uint2 w;
-                w.x = pack_bf2(dq[d][4 * t + 0] * a.scale, dq[d][4 * t + 1] * a.scale);
-                w.y = pack_bf2(dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale);
-                *reinterpret_cast<uint2*>(qrow + d * 32 + 8 * t + 4 * hh) = w;
-                // dK = dS^T . (q * scale) and the staged q is q * scale * log2(e)
-                w.x = pack_bf2(dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2);
-                w.y = pack_bf2(dk[d][4 * t + 2] * LN2, dk[d][4 * t + 3] * LN2);
-                *reinterpret_cast<uint2*>(krow + d * 32 + 8 * t + 4 * hh) = w;
-                w.x = pack_bf2(dv[d][4 * t + 0], dv[d][4 * t + 1]);
-                w.y = pack_bf2(dv[d][4 * t + 2], dv[d][4 * t + 3]);
-                *reinterpret_cast<uint2*>(vrow + d * 32 + 8 * t + 4 * hh) = w;
-                if (G8) {
-                    uint8_t* q8p = a.dqkv8 + (size_t)(seq0 + rl) * a.ld8 + head * HD + d * 32 + 8 * t + 4 * hh;
-                    store_bf8x4(q8p, dq[d][4 * t + 0] * a.scale, dq[d][4 * t + 1] * a.scale, dq[d][4 * t + 2] * a.scale, dq[d][4 * t + 3] * a.scale, g8s, g8max);
-                    store_bf8x4(q8p + a.D, dk[d][4 * t + 0] * LN2, dk[d][4 * t + 1] * LN2, dk[d][4 * t + 2] * LN2, dk[d][4 * t + 3] * LN2, g8s, g8max);
-                    store_bf8x4(q8p + 2 * a.D, dv[d][4 * t + 0], dv[d][4 * t + 1], dv[d][4 * t + 2], dv[d][4 * t + 3], g8s, g8max);
-                }
-            }
+        for (int d = 0; d < NDB; ++d) {
+            store_block<HD, true>(qrow, d, hh, dq[d], a.scale, q8p, g8s, g8max);
+            store_block<HD, true>(krow, d, hh, dk[d], LN2, G8 ? q8p + a.D : nullptr, g8s, g8max);      // dK = dS^T . (q * scale), the staged q is q * scale * log2(e)
+            store_block<HD, true>(vrow, d, hh, dv[d], 1.0f, G8 ? q8p + 2 * a.D : nullptr, g8s, g8max);
+        }
     }
     if (G8) q_amax_update(a.qd8, g8max, g8seen);
 }
