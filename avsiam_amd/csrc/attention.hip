@@ -163,7 +163,7 @@ __device__ __forceinline__ void store_block(bf16_t* rowp, int d, int hh, const f
         // piece and keep theirs (columns 16u + 8 .. 16u + 15)
         const auto r0 = __builtin_amdgcn_permlane32_swap(pack_bf2(e0, e1), pack_bf2(o0, o1), false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(pack_bf2(e2, e3), pack_bf2(o2, o3), false, false);
-        *reinterpret_cast<u32x4*>(rowp + d * 32 + 16 * u + 8 * hh) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        if (rowp) *reinterpret_cast<u32x4*>(rowp + d * 32 + 16 * u + 8 * hh) = u32x4{r0[0], r1[0], r0[1], r1[1]};      // (NULL: the 8-bit copy only)
         if (rowp8) {
             const auto r8 = __builtin_amdgcn_permlane32_swap(q8(e0, e1, e2, e3), q8(o0, o1, o2, o3), false, false);
             *reinterpret_cast<uint2*>(rowp8 + d * 32 + 16 * u + 8 * hh) = make_uint2(r8[0], r8[1]);
@@ -174,7 +174,7 @@ __device__ __forceinline__ void store_block(bf16_t* rowp, int d, int hh, const f
     for (int t = 0; t < 4; ++t) {
         if (d * 32 + 8 * t >= HG) continue;
         const float v0 = acc[4 * t + 0] * mul, v1 = acc[4 * t + 1] * mul, v2 = acc[4 * t + 2] * mul, v3 = acc[4 * t + 3] * mul;
-        *reinterpret_cast<uint2*>(rowp + d * 32 + 8 * t + 4 * hh) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+        if (rowp) *reinterpret_cast<uint2*>(rowp + d * 32 + 8 * t + 4 * hh) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
         if (rowp8) *reinterpret_cast<uint32_t*>(rowp8 + d * 32 + 8 * t + 4 * hh) = q8(v0, v1, v2, v3);
     }
 #endif
@@ -199,6 +199,8 @@ struct AttnArgs {
                                                 // device record q8 (common.h AVS_Q_*), whose running amax takes the largest |o| written
     uint8_t* dqkv8; long long ld8; float* qd8;  // bwd, fp8 mode (may be NULL): e5m2 copy of dqkv [rows, 3*D] - the gradient operand of the fp8 qkv
                                                 // input-gradient GEMM - scaled by the device record qd8, whose running amax takes the largest |dqkv|
+    int kv16;                                   // bwd with dqkv8: 0 = the key / value thirds of the bf16 dqkv are NOT written (fp8 mode 3: the input- and
+                                                // weight-gradient GEMMs read the e5m2 copy, only the query third's column sum - the bias gradient - reads bf16)
 };
 
 // four consecutive gradient values -> one dword of e5m2 at `dst` (scaled, clamped to the e5m2 range), their |max| folded into gmax
@@ -613,8 +615,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     if (G8) { g8s = a.qd8[AVS_Q_SCALE]; g8seen = a.qd8[AVS_Q_AMAX]; }
     const int kq = kw + (lane & 31);
     if (kq < L) {
-        bf16_t* krow = a.dqkv + (size_t)(seq0 + kq) * a.ld + a.D + head * HG;
-        bf16_t* vrow = krow + a.D;
+        bf16_t* krow = (G8 && !a.kv16) ? nullptr : a.dqkv + (size_t)(seq0 + kq) * a.ld + a.D + head * HG;
+        bf16_t* vrow = krow ? krow + a.D : nullptr;
         uint8_t* krow8 = G8 ? a.dqkv8 + (size_t)(seq0 + kq) * a.ld8 + a.D + head * HG : nullptr;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
@@ -763,8 +765,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs a) {
     if (G8) { g8s = a.qd8[AVS_Q_SCALE]; g8seen = a.qd8[AVS_Q_AMAX]; }
     if (rl < L) {
         bf16_t* qrow = a.dqkv + (size_t)(seq0 + rl) * a.ld + head * HD;
-        bf16_t* krow = qrow + a.D;
-        bf16_t* vrow = krow + a.D;
+        bf16_t* krow = (G8 && !a.kv16) ? nullptr : qrow + a.D;
+        bf16_t* vrow = krow ? krow + a.D : nullptr;
         uint8_t* q8p = G8 ? a.dqkv8 + (size_t)(seq0 + rl) * a.ld8 + head * HD : nullptr;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
@@ -823,7 +825,9 @@ extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const
 extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                                const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
                                const float* lse, float* delta, int rows_total, bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
-                               hipStream_t stream) {
+                               int kv_bf16, hipStream_t stream) {
+    // kv_bf16 == 0 (with dqkv8 only): the key and value thirds of the bf16 dqkv are left unwritten - their only readers take the e5m2 copy
+    AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd: kv_bf16 = 0 needs the e5m2 copy");
     AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 4) == 0)), "attn_bwd: dqkv8 and its record go together, ld8 %% 4 == 0");
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_bwd: tile_rows must be 64 or 128");
     AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_bwd: head dim 80 runs with 128-row tiles only");
@@ -831,7 +835,7 @@ extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
     if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8};
+               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16};
     dim3 grid(ntiles * H);
 #define ATTN_BWD2(K, G)                                                                                     \
     do {                                                                                                    \
@@ -856,13 +860,14 @@ extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const
                             const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
                             const float* lse, float* delta, int rows_total, bf16_t* dqkv, hipStream_t stream) {
     return avs_attn_bwd_q8(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, dout, ldo, lse, delta, rows_total, dqkv, nullptr, 0,
-                           nullptr, stream);
+                           nullptr, 1, stream);
 }
 
 // One workgroup per (sequence, head) for sequences of at most `rows_per_wg` (64 or 128) tokens: seq_start / seq_len [nseq].
 extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
                                      int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
-                                     bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, hipStream_t stream) {
+                                     bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, hipStream_t stream) {
+    AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd_fused: kv_bf16 = 0 needs the e5m2 copy");
     AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 4) == 0)), "attn_bwd_fused: dqkv8 and its record go together, ld8 %% 4 == 0");
     AVS_CHECK_ARG(rows_per_wg == 64 || rows_per_wg == 128, "attn_bwd_fused: rows_per_wg must be 64 or 128");
     const int hd = H > 0 ? D / H : 0;
@@ -870,7 +875,7 @@ extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int
                   "attn_bwd_fused: bad arguments (D=%d H=%d hd=%d ld=%lld nseq=%d)", D, H, hd, ld, nseq);
     AVS_CHECK_ARG(out && dout && lse && dqkv && (ldo % 8) == 0, "attn_bwd_fused: null pointer");
     AttnArgs a{qkv, ld, D, seq_start, seq_len, nullptr, nseq, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8};
+               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16};
     dim3 grid(nseq * H);
 #define ATTN_BWDF(G)                                                                                        \
     do {                                                                                                    \
@@ -891,5 +896,5 @@ extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int
 extern "C" int avs_attn_bwd_fused(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
                                   int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
                                   bf16_t* dqkv, hipStream_t stream) {
-    return avs_attn_bwd_fused_q8(qkv, ld, D, H, seq_start, seq_len, nseq, rows_per_wg, out, dout, ldo, lse, rows_total, dqkv, nullptr, 0, nullptr, stream);
+    return avs_attn_bwd_fused_q8(qkv, ld, D, H, seq_start, seq_len, nseq, rows_per_wg, out, dout, ldo, lse, rows_total, dqkv, nullptr, 0, nullptr, 1, stream);
 }

@@ -274,7 +274,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                         o.x = pack_bf2(v0[0], v0[1]); o.y = pack_bf2(v0[2], v0[3]);
                         o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
                     }
-                    NT_STORE(reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n), (u32x4{o.x, o.y, o.z, o.w}));
+                    // (fp8 input-gradient form: `out` may be NULL - every reader of this gradient takes the e5m2 copy below; the bf16 kernels never test it)
+                    if (Q8 != 2 || a.out) NT_STORE(reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n), (u32x4{o.x, o.y, o.z, o.w}));
                     if (Q8 == 2 && ACT != 1 && a.out8) {
                         // fp8 backward: the e5m2 copy of this output gradient, the operand of the next input-gradient GEMM
                         auto c8 = [&](float x) { q8max = fmaxf(q8max, fabsf(x)); return __builtin_amdgcn_fmed3f(x * q8s, -57344.f, 57344.f); };
@@ -288,7 +289,8 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                         uint4 gq;
                         gq.x = pack_bf2(gelu_erf(v0[0]), gelu_erf(v0[1])); gq.y = pack_bf2(gelu_erf(v0[2]), gelu_erf(v0[3]));
                         gq.z = pack_bf2(gelu_erf(v1[0]), gelu_erf(v1[1])); gq.w = pack_bf2(gelu_erf(v1[2]), gelu_erf(v1[3]));
-                        NT_STORE(reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n), (u32x4{gq.x, gq.y, gq.z, gq.w}));
+                        // (fp8 forward: `out2` may be NULL when fc2 and its weight gradient both read the e4m3 copy)
+                        if (Q8 != 1 || a.out2) NT_STORE(reinterpret_cast<u32x4*>(a.out2 + (size_t)m * a.ldo2 + n), (u32x4{gq.x, gq.y, gq.z, gq.w}));
                         if (Q8 == 1 && a.out8) {
                             const float q = q8s;
                             auto q8 = [&](float x) { const float gx = gelu_erf(x); q8max = fmaxf(q8max, fabsf(gx)); return __builtin_amdgcn_fmed3f(gx * q, -448.f, 448.f); };
@@ -1227,12 +1229,15 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
     AVS_CHECK_ARG(!out8 || ((ldo8 % 8) == 0 && ldo8 >= N && (a_e5m2 ? act != 1 : act == 1)),
                   "gemm_nt_fp8: out8 = e4m3(gelu(x)) goes with act 1, out8 = e5m2(out) with the input-gradient form");
     AVS_CHECK_ARG(M > 0 && N > 0 && K >= 256 && (N % 256) == 0 && (K % 128) == 0, "gemm_nt_fp8: need N%%256==0, K%%128==0, K>=256 (M=%d N=%d K=%d)", M, N, K);
-    AVS_CHECK_ARG(A && B && out && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && (ldo % (out_f32 ? 4 : 8)) == 0,
-                  "gemm_nt_fp8: operands must keep 16-byte alignment");
+    // 8-bit-only outputs: `out` may be NULL in the input-gradient form when out8 is given (the bf16 gradient has no reader left: the next
+    // input-gradient GEMM and the weight gradient take the e5m2 copy, the bias gradient is the fused colsum); `out2` may be NULL with
+    // act 1 when out8 is given (gelu(x) is read by fc2 and its weight gradient only, both in e4m3)
+    AVS_CHECK_ARG(A && B && (out || (out8 && a_e5m2 && !out_f32)) && (lda % 16) == 0 && (ldb % 16) == 0 && lda >= K && ldb >= K && (!out || (ldo % (out_f32 ? 4 : 8)) == 0),
+                  "gemm_nt_fp8: operands must keep 16-byte alignment (out may be NULL only beside an e5m2 out8)");
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt_fp8: the residual add is implemented for fp32 output");
-    AVS_CHECK_ARG((act == 0 && !out2) || (act == 1 && out2 && !out_f32 && (ldo2 % 8) == 0 && !a_e5m2) ||
+    AVS_CHECK_ARG((act == 0 && !out2) || (act == 1 && (out2 || out8) && !out_f32 && (!out2 || (ldo2 % 8) == 0) && !a_e5m2) ||
                   (act == 2 && a_e5m2 && aux && !out2 && !out_f32 && (ldaux % 8) == 0),
-                  "gemm_nt_fp8: act 0; act 1 with a bf16 output pair (forward); act 2 with aux (input-gradient form)");
+                  "gemm_nt_fp8: act 0; act 1 with a bf16 output pair (forward; out2 may be NULL beside out8); act 2 with aux (input-gradient form)");
     AVS_CHECK_ARG(!colsum || (!out_f32 && a_e5m2), "gemm_nt_fp8: the fused column sum goes with the bf16 output of the input-gradient form");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt_fp8: scale_cols must be a multiple of 64 within N");
     AVS_CHECK_ARG((qa == nullptr) == (qw == nullptr), "gemm_nt_fp8: qa and qw go together");

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             uint2 o;
             o.x = pack_bf2(r.x, r.y);
             o.y = pack_bf2(r.z, r.w);
-            reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + (size_t)orow * D)[i * 64 + lane] = o;
+            if (y) reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + (size_t)orow * D)[i * 64 + lane] = o;      // (NULL: the e4m3 copy is the only output)
             if (y8) {
                 ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
                 int w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(r.x * q8, -448.f, 448.f), __builtin_amdgcn_fmed3f(r.y * q8, -448.f, 448.f), 0, false);
@@ -418,7 +418,7 @@ extern "C" int avs_layernorm_fwd_q8(const float* x, const float* g0, const float
     AVS_CHECK_ARG(!(y8 && y_f32), "layernorm_fwd: the fp8 copy goes with the bf16 output");
     // D = 1536: the concatenated audio|video feature of the fusion classification head (forward only)
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280 || D == 1536), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
-    AVS_CHECK_ARG(x && g0 && b0 && y && mean && rstd, "layernorm_fwd: null pointer");
+    AVS_CHECK_ARG(x && g0 && b0 && (y || (y8 && !y_f32)) && mean && rstd, "layernorm_fwd: null pointer (y may be NULL only beside y8)");
     AVS_CHECK_ARG(!row_mod || (g1 && b1), "layernorm_fwd: row_mod given without second affine set");
     dim3 grid(ceil_div(rows, 4)), block(256);
 #define LN_FWD(NV, F) ln_fwd_kernel<NV, F><<<grid, block, 0, stream>>>(x, g0, b0, g1, b1, row_mod, out_map, y, mean, rstd, rows, eps, y8, q8, q8_dev)

@@ -61,6 +61,13 @@ def recompute_blocks(nblocks, setting=None):
 # avs_attn_bwd_fused_q8); own records, fmax 57344 - against the e4m3 copy of the transposed weight (the forward's weight scale).
 # The weight gradients stay bf16.
 FP8 = os.environ.get("AVSIAM_FP8", "0")
+# AVSIAM_FP8=3 only.  With the weight gradients on fp8 operands four bf16 tensors of a block have no reader left once their consumers'
+# records are calibrated: the two LayerNorm outputs and gelu(x) (read by qkv / fc1 / fc2 and their weight gradients - all in e4m3) and
+# the fc2 input gradient (read by fc1's input- and weight-gradient GEMMs in e5m2; fc1's bias gradient is the fused column sum).  "1"
+# (default): their producers write the 8-bit copy ONLY (NULL bf16 output) and the three activations live in one shared buffer per stack
+# instead of one per block - 2 x D + hidden fewer bf16 values written and kept per token and block, and the GEMM epilogues that wrote
+# them (bound by the write burst of all CUs at once) shrink to 3/5 (fc1) and 1/3 (fc2 input gradient) of their bytes.  "0": A/B.
+FP8_LEAN = os.environ.get("AVSIAM_FP8_LEAN", "1") != "0"
 # The residual-GRADIENT stream between the blocks of a stack (AVSIAM_GRAD_STREAM=bf16 | fp32).  bf16 (default): a LayerNorm backward
 # reads the upstream residual gradient from the bf16 copy the previous LayerNorm backward wrote for the GEMMs anyway and writes
 # only its own bf16 copy - 10 instead of 16 bytes per element and call (the kernel is HBM-bound); the sum itself is formed in fp32
@@ -224,6 +231,7 @@ class Stack:
         # e4m3 activation copies).  The e4m3 copy of an activation is then KEPT per block (one more byte per element beside the bf16
         # copy the attention / LayerNorm backward still read) instead of living in one buffer per stack.
         self.fp8_wgrad = self.fp8_bwd and FP8 == "3"
+        self.fp8_lean = self.fp8_wgrad and FP8_LEAN          # (see FP8_LEAN)
         if self.fp8:
             r8 = ops.pad_rows(rows, 256)
             self.a8 = torch.zeros((r8, max(D, hidden)), dtype=U8, device=dev)      # calibration step only: an activation quantised by a pass
@@ -294,13 +302,16 @@ class Stack:
             self.x = [ping[i & 1] for i in range(nblocks + 1)]
         else:
             self.x = [_z((rp, D), F32, dev) for _ in range(nblocks + 1)]     # x[i] = input of block i; x[-1] = output
+        def one_for_all(shape, dtype):                        # fp8 mode 3: a bf16 tensor only the calibration step still writes
+            return [_z(shape, dtype, dev)] * nblocks
+        lean = getattr(self, "fp8_lean", False)
         self.xmid = per_block((rp, D), F32)
-        self.ln1 = per_block((rp, D), BF16)
-        self.ln2 = self.ln1 if inference else per_block((rp, D), BF16)
+        self.ln1 = (one_for_all if lean else per_block)((rp, D), BF16)
+        self.ln2 = self.ln1 if (inference or lean) else per_block((rp, D), BF16)
         self.qkv = per_block((rp, 3 * D), BF16)
         self.att = per_block((rp, D), BF16)
         self.fc1 = per_block((rp, hidden), BF16)          # gelu'(fc1 output): all the backward needs of the pre-activation (gemm act 1 / 2)
-        self.act = per_block((rp, hidden), BF16)
+        self.act = (one_for_all if lean else per_block)((rp, hidden), BF16)
         self.lse = per_block((H, rp), F32)
         nshared = nblocks if inference else self.nrecomp
         st = [_z((rp,), F32, dev) for _ in range(4)] if nshared else None
@@ -389,16 +400,17 @@ class Stack:
         seen = lambda name: (i, name) in self.f8_seen
         r = lambda name: self._rec(i, name)
         l1, l2, at8, ac8 = self.ln1_8[i], self.ln2_8[i], self.att8[i], self.act8[i]
-        _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod, y8=l1 if seen("qkv") else None,
+        lean = self.fp8_lean               # a calibrated consumer reads the e4m3 copy only, and so does its weight gradient: no bf16 output
+        _ln_fwd(x, n1, None if lean and seen("qkv") else self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, self.row_mod, y8=l1 if seen("qkv") else None,
                 q8_dev=r("qkv") if seen("qkv") else None)
         self._gemm_fp8(i, "qkv", self.ln1[i], l1, bp.qkv, b2.qkv if b2 else None, split, self.qkv[i], scale_cols=self.D, col_scale=self.q_scale)
         ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i], **({"out8": at8, "q8": r("proj")} if seen("proj") else {}))
         self._gemm_fp8(i, "proj", self.att[i], at8, bp.proj, b2.proj if b2 else None, split, self.xmid[i], res=x)
-        _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod, y8=l2 if seen("fc1") else None,
+        _ln_fwd(self.xmid[i], n2, None if lean and seen("fc1") else self.ln2[i], st[2], st[3], M, LN_EPS_BLOCK, self.row_mod, y8=l2 if seen("fc1") else None,
                 q8_dev=r("fc1") if seen("fc1") else None)
         # (the fc2 weight gradient reads the e4m3 copy of gelu(x) too: with fp8 weight gradients it is written even when fc2 itself is skipped)
         o8 = {"out8": ac8, "q8": r("fc2")} if (seen("fc2") and (last_gemm or self.fp8_wgrad)) else {}
-        self._gemm_fp8(i, "fc1", self.ln2[i], l2, bp.fc1, b2.fc1 if b2 else None, split, self.fc1[i], out2=self.act[i], act=1, **o8)
+        self._gemm_fp8(i, "fc1", self.ln2[i], l2, bp.fc1, b2.fc1 if b2 else None, split, self.fc1[i], out2=None if lean and o8 else self.act[i], act=1, **o8)
         if last_gemm:
             self._gemm_fp8(i, "fc2", self.act[i], ac8, bp.fc2, b2.fc2 if b2 else None, split, self.x[i + 1], res=self.xmid[i])
         elif self.fp8_wgrad and not seen("fc2"):
@@ -580,7 +592,8 @@ class Stack:
                 side.before_write("dfc1")
             if f8b:
                 o8, r8_ = g8rec(i, "dfc1")
-                self._dgrad_fp8(i, "dbo", "fc2", dbo, self.dx8[0], bp.fc2, b2.fc2 if b2 else None, split, self.dfc1, act=2, aux=self.fc1[i],
+                # (lean mode 3: once the e5m2 copy is written by this epilogue nothing reads the bf16 gradient - no bf16 output)
+                self._dgrad_fp8(i, "dbo", "fc2", dbo, self.dx8[0], bp.fc2, b2.fc2 if b2 else None, split, None if self.fp8_lean and o8 is not None else self.dfc1, act=2, aux=self.fc1[i],
                                 colsum=bp.fc1.gb, colsum2=b2.fc1.gb if b2 else None, **({"out8": o8, "q8": r8_} if o8 is not None else {}))
             else:
                 ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
@@ -619,7 +632,8 @@ class Stack:
             if f8b:                                # the attention backward kernels write the e5m2 copy of dqkv themselves once its record is calibrated
                 d8, q8_ = g8rec(i, "dqkv")
                 if d8 is not None:
-                    a8 = {"dqkv8": d8, "q8": q8_}
+                    # (lean mode 3: the qkv input- and weight-gradient GEMMs read the e5m2 copy; of the bf16 dqkv only the query third has a reader)
+                    a8 = {"dqkv8": d8, "q8": q8_, "kv_bf16": not self.fp8_lean}
             if self.tiles_bwd.ntiles:
                 ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv, **a8)
             for sq in self.fused_bwd:

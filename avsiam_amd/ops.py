@@ -110,22 +110,28 @@ def layernorm_ws(rows, D):
 
 
 def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod=None, out_map=None, y8=None, q8=1.0, q8_dev=None):
+    """y may be None beside y8: the e4m3 copy is then the only output (fp8 mode 3: nothing reads the bf16 one)."""
     D = x.shape[1]
-    _chk(x, F32, "ln.x", 2); _chk(y, y.dtype if y.dtype in (BF16, F32) else BF16, "ln.y", 2); _chk(mean, F32, "ln.mean"); _chk(rstd, F32, "ln.rstd")
+    assert y is not None or y8 is not None
+    _chk(x, F32, "ln.x", 2); _chk(mean, F32, "ln.mean"); _chk(rstd, F32, "ln.rstd")
+    if y is not None:
+        _chk(y, y.dtype if y.dtype in (BF16, F32) else BF16, "ln.y", 2)
+        assert y.shape[1] == D
     _chk(g0, F32, "ln.g0"); _chk(b0, F32, "ln.b0"); _chk(g1, F32, "ln.g1"); _chk(b1, F32, "ln.b1")
     _chk(row_mod, U8, "ln.row_mod"); _chk(out_map, I32, "ln.out_map")
-    assert x.shape[0] >= rows and mean.numel() >= rows and rstd.numel() >= rows and y.shape[1] == D
+    assert x.shape[0] >= rows and mean.numel() >= rows and rstd.numel() >= rows
     assert g0.numel() == D and b0.numel() == D
     if row_mod is not None:
         assert row_mod.numel() >= rows and g1 is not None and b1 is not None and g1.numel() == D
     if out_map is not None:
         assert out_map.numel() >= rows
     else:
-        assert y.shape[0] >= rows
+        assert y is None or y.shape[0] >= rows
     if y8 is not None:
         _chk(y8, U8, "ln.y8", 2)
-        assert y8.shape[1] == D and y8.shape[0] >= rows and y.dtype == BF16 and out_map is None
-    _launch("layernorm_fwd", float(rows) * D * (4 + y.element_size()), "avs_layernorm_fwd_q8", x, g0, b0, g1, b1, row_mod, out_map, y, 1 if y.dtype == F32 else 0, mean, rstd, rows, D,
+        assert y8.shape[1] == D and y8.shape[0] >= rows and (y is None or y.dtype == BF16) and out_map is None
+    ysz = (y.element_size() if y is not None else 0) + (1 if y8 is not None else 0)
+    _launch("layernorm_fwd", float(rows) * D * (4 + ysz), "avs_layernorm_fwd_q8", x, g0, b0, g1, b1, row_mod, out_map, y, 1 if (y is not None and y.dtype == F32) else 0, mean, rstd, rows, D,
               float(eps), y8, float(q8), _qrec(q8_dev), _stream())
 
 
@@ -323,12 +329,15 @@ def gemm_nt_fp8(A8, B8, out, M, alpha=1.0, bias=None, res=None, out2=None, act=0
     then receives e5m2(out) for the next input-gradient GEMM."""
     _chk(A8, U8, "gemm8.A", 2); _chk(B8, U8, "gemm8.B", 2); _chk(bias, F32, "gemm8.bias"); _chk(res, F32, "gemm8.res", 2); _chk(out2, BF16, "gemm8.out2", 2)
     _chk(out8, U8, "gemm8.out8", 2); _chk(aux, BF16, "gemm8.aux", 2); _chk(colsum, F32, "gemm8.colsum")
-    assert out.dtype in (BF16, F32) and out.dim() == 2 and out.is_contiguous()
     N, K = B8.shape
-    assert A8.shape[1] == K and A8.shape[0] >= M and out.shape[0] >= M and out.shape[1] == N
+    # 8-bit-only outputs (fp8 mode 3): out=None in the input-gradient form beside out8; out2=None with act 1 beside out8
+    assert out is not None or (grad and out8 is not None)
+    assert out is None or (out.dtype in (BF16, F32) and out.dim() == 2 and out.is_contiguous() and out.shape[0] >= M and out.shape[1] == N)
+    assert A8.shape[1] == K and A8.shape[0] >= M
     assert (qa is None) == (qw is None)
     assert act in (0, 1, 2) and (act != 2 or (grad and aux is not None and aux.shape[0] >= M and aux.shape[1] == N)) and (act != 1 or not grad)
-    assert colsum is None or (grad and colsum.numel() == N and out.dtype == BF16)
+    assert act != 1 or out2 is not None or out8 is not None
+    assert colsum is None or (grad and colsum.numel() == N and (out is None or out.dtype == BF16))
     assert out8 is None or (out8.shape[0] >= M and out8.shape[1] == N)
     m_split, B2, bias2, qw2, colsum2 = (tuple(dual) + (None,))[:5] if dual is not None else (0, None, None, None, None)
     if dual is not None:
@@ -336,7 +345,7 @@ def gemm_nt_fp8(A8, B8, out, M, alpha=1.0, bias=None, res=None, out2=None, act=0
         assert B2.shape == B8.shape and B2.stride(0) == B8.stride(0) and 0 < m_split < M and m_split % 256 == 0 and qa is not None and qw2 is not None
         assert (bias2 is None) == (bias is None) and (colsum2 is None) == (colsum is None)
     _launch("gemm_nt_fp8", 2.0 * M * N * K, "avs_gemm_nt_fp8", A8, A8.stride(0), B8, B8.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
-            out, out.stride(0), 1 if out.dtype == F32 else 0, out2, out2.stride(0) if out2 is not None else 0, float(alpha), int(act), int(scale_cols),
+            out, out.stride(0) if out is not None else 0, 1 if (out is not None and out.dtype == F32) else 0, out2, out2.stride(0) if out2 is not None else 0, float(alpha), int(act), int(scale_cols),
             float(col_scale), out8, out8.stride(0) if out8 is not None else 0, float(out8_scale), _qrec(qa), _qrec(qw), _qrec(q8),
             int(m_split), B2, bias2, _qrec(qw2), 1 if grad else 0, aux, aux.stride(0) if aux is not None else 0, colsum, colsum2, _stream())
 
@@ -433,9 +442,11 @@ def attn_fwd(qkv, tiles, H, out, lse, out8=None, q8=None):
             lse, lse.shape[1], out8, out8.stride(0) if out8 is not None else 0, _qrec(q8), _stream())
 
 
-def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None):
+def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None, kv_bf16=True):
     """dqkv8 / q8 (fp8 backward): also write the e5m2 copy of dqkv - the gradient operand of the fp8 qkv input-gradient GEMM - scaled by
-    the device record q8, whose running amax takes the largest |dqkv| written"""
+    the device record q8, whose running amax takes the largest |dqkv| written.  kv_bf16=False (with dqkv8): the key / value thirds of
+    the bf16 dqkv are not written."""
+    assert kv_bf16 or dqkv8 is not None
     _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2); _chk(dqkv8, U8, "attnb.dqkv8", 2)
     assert (dqkv8 is None) == (q8 is None) and (dqkv8 is None or (dqkv8.shape[0] >= tiles.max_row and dqkv8.shape[1] == qkv.shape[1]))
     _chk(lse, F32, "attnb.lse", 2); _chk(delta, F32, "attnb.delta", 2); _chk(dqkv, BF16, "attnb.dqkv", 2)
@@ -446,7 +457,7 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None):
     # kernels pay instead of keeping an L x L tensor is NOT counted.  Algorithmic HBM bytes of the two kernels: dQ
     # reads q, k, v, o, dO and writes dq (+ delta); dK/dV reads q, k, v, dO and writes dk, dv
     _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd_q8", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
-            out.stride(0), lse, delta, lse.shape[1], dqkv, dqkv8, dqkv8.stride(0) if dqkv8 is not None else 0, _qrec(q8), _stream())
+            out.stride(0), lse, delta, lse.shape[1], dqkv, dqkv8, dqkv8.stride(0) if dqkv8 is not None else 0, _qrec(q8), 1 if kv_bf16 else 0, _stream())
 
 
 class AttnSeqs:
@@ -465,7 +476,7 @@ class AttnSeqs:
         self.sum_sq = float(sum(L * L for L in lens))
 
 
-def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv, dqkv8=None, q8=None):
+def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv, dqkv8=None, q8=None, kv_bf16=True):
     """dq, dk, dv of the sequences in `seqs` (each at most seqs.max_len = 64 | 128 tokens) in one kernel: one read of q, k, v, o, dO and
     one evaluation of S per (sequence, head).  Rows of other sequences are not touched."""
     _chk(qkv, BF16, "attnf.qkv", 2); _chk(out, BF16, "attnf.out", 2); _chk(dout, BF16, "attnf.dout", 2)
@@ -478,7 +489,7 @@ def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv, dqkv8=None, q8=None):
     # algorithmic work: 8 * sum L^2 * D FLOP; q, k, v, o, dO read and dq, dk, dv written once (bf16), lse read
     _launch("attn_bwd_hd%d" % (D // H), (8.0 * seqs.sum_sq * D, seqs.rows * (16.0 * D + 4.0 * H)), "avs_attn_bwd_fused_q8", qkv, qkv.stride(0), D, H, seqs.start,
             seqs.len, seqs.nseq, seqs.max_len, out, dout, out.stride(0), lse, lse.shape[1], dqkv, dqkv8, dqkv8.stride(0) if dqkv8 is not None else 0,
-            _qrec(q8), _stream())
+            _qrec(q8), 1 if kv_bf16 else 0, _stream())
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -453,6 +453,8 @@ def main():
                        **({"collectives": {"backend": dist.get_backend(), "library": "gloo, staged through the host (rehearsal)" if share else "RCCL (torch.distributed 'nccl' on ROCm)", "group_world_size": dist.get_world_size(),
                                            "comm": "host-staged" if share else os.environ.get("AVSIAM_COMM", "torch"), "allreduce_messages_last_backward": model.last_reduce_messages}}
                           if world > 1 else {}), **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
+                       **({"fp8_8bit_only_outputs": __import__("avsiam_amd.engine", fromlist=["FP8_LEAN"]).FP8_LEAN} if args.fp8_wgrad else {}),
+                       "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        **({"rehearsal": "AVSIAM_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo + host-staged collectives - not a throughput figure"} if share else {}),
                        **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
                                         "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "defer_mae_only": os.environ.get("AVSIAM_DP_DEFER", "0"),

@@ -163,11 +163,12 @@ int avs_attn_bwd(const avs_bf16* qkv, long long ld, int D, int H, const int* til
                  const float* lse, float* delta, int rows_total, avs_bf16* dqkv, avs_stream_t stream);
 /* the same, also writing dqkv8 = e5m2(clamp(dqkv * qd8[0], +-57344)) [rows, 3*D] / ld8 - the gradient operand of the fp8 qkv input-gradient
  * GEMM (fp8 mode 2: every input-gradient GEMM of a block on e5m2 x e4m3) - and folding max |dqkv| into the device record qd8; both NULL =
- * avs_attn_bwd */
+ * avs_attn_bwd.  kv_bf16 = 0 (with dqkv8 only; fp8 mode 3): the key / value thirds of the bf16 dqkv are not written - the input- and
+ * weight-gradient GEMMs read the e5m2 copy; the query third (column sum = bias gradient) always is */
 int avs_attn_bwd_q8(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                     const int* tile_q0, int ntiles, int tile_rows, const avs_bf16* out, const avs_bf16* dout, long long ldo,
                     const float* lse, float* delta, int rows_total, avs_bf16* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
-                    avs_stream_t stream);
+                    int kv_bf16, avs_stream_t stream);
 /* the same backward for sequences of at most rows_per_wg (64 | 128) tokens, in ONE kernel: a workgroup per (sequence, head) reads q, k,
  * v, dO, o once, evaluates S and its exponentials once and writes dq, dk and dv (hd 32 | 64).  seq_start / seq_len: [nseq] */
 int avs_attn_bwd_fused(const avs_bf16* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
@@ -175,7 +176,7 @@ int avs_attn_bwd_fused(const avs_bf16* qkv, long long ld, int D, int H, const in
                        avs_bf16* dqkv, avs_stream_t stream);
 int avs_attn_bwd_fused_q8(const avs_bf16* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
                           int rows_per_wg, const avs_bf16* out, const avs_bf16* dout, long long ldo, const float* lse, int rows_total,
-                          avs_bf16* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, avs_stream_t stream);
+                          avs_bf16* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, avs_stream_t stream);
 
 /* ---- input normalisation on the device (what the reference dataloader does per sample on the host: dataloader.py:505-513
  * fbank = (fbank - norm_mean) / norm_std [+ rand * amp, roll(shift) when `noise`]; :461-462,152-155 frame / 255 then

@@ -510,10 +510,10 @@ def test_attention_bwd_writes_the_e5m2_copy_of_dqkv(H, hd):
     tiles = o.AttnTiles(lens, DEV, tile_rows=tr, min_len=cut)
     fused = [] if hd == 80 else [sq for sq in (o.AttnSeqs(lens, DEV, 0, 64), o.AttnSeqs(lens, DEV, 64, 128)) if sq.nseq]
 
-    def run(d8=None, rec=None):
+    def run(d8=None, rec=None, kv_bf16=True):
         dq = torch.zeros_like(qkv)
         delta = torch.zeros_like(lse)
-        kw = {} if d8 is None else {"dqkv8": d8, "q8": rec}
+        kw = {} if d8 is None else {"dqkv8": d8, "q8": rec, "kv_bf16": kv_bf16}
         o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dq, **kw)
         for sq in fused:
             o.attn_bwd_fused(qkv, sq, H, out, dout, lse, dq, **kw)
@@ -534,6 +534,10 @@ def test_attention_bwd_writes_the_e5m2_copy_of_dqkv(H, hd):
     assert rel_err(deq, ref) < 0.08
     assert bool((d8[rows:] == 0x7B).all())                                               # pad rows are not this kernel's
     assert abs(recs.amax(0) - amax) <= 2.0 ** -7 * amax                                  # the record saw the fp32 values (bf16-rounded in `plain`)
+    # kv_bf16=False (fp8 mode 3): the same e5m2 copy, the query third of the bf16 dqkv as before, its key / value thirds not written
+    d8b = torch.full_like(d8, 0x7B)
+    lean = run(d8b, recs.rec(0), kv_bf16=False)
+    assert torch.equal(d8b, d8) and torch.equal(lean[:, :D], plain[:, :D]) and float(lean[:, D:].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("H,hd,L,spike", [(2, 64, 200, 8.0), (2, 64, 200, 2.5), (4, 32, 300, 40.0), (4, 32, 300, 4.0)])
@@ -918,6 +922,10 @@ def test_fp8_delayed_scaling_records():
     assert float((deq - act.float()).abs().max()) <= 2 ** -4 * act.float().abs().max().item() + 1e-3       # e4m3: 3 mantissa bits
     assert rel_err(deq, act) < 0.04
     assert abs(rec.amax(3) - act.float().abs().max().item()) <= 1e-2 * act.float().abs().max().item()
+    # 8-bit-only output (fp8 mode 3, engine.FP8_LEAN): no bf16 gelu(x) - the e4m3 copy and gelu'(x) are the same bits
+    act8b, dact2 = torch.zeros_like(act8), torch.zeros_like(dact)
+    o.gemm_nt_fp8(A8, W8, dact2, M, bias=b, out2=None, act=1, qa=ra, qw=rw, out8=act8b, q8=r8)
+    assert torch.equal(act8b, act8) and torch.equal(dact2, dact)
     # LayerNorm writing the e4m3 copy with a record
     D, rows = 768, 777
     x = torch.randn(rows, D, device=DEV, generator=g) * 3
@@ -932,6 +940,9 @@ def test_fp8_delayed_scaling_records():
     sl = rec.q[4, 0].item()
     assert rel_err(y8.view(torch.float8_e4m3fn).float() / sl, y) < 0.04
     assert abs(rec.amax(4) - y.float().abs().max().item()) <= 1e-2 * y.float().abs().max().item()
+    y8b, mean2, rstd2 = torch.zeros_like(y8), torch.empty_like(mean), torch.empty_like(rstd)
+    o.layernorm_fwd(x, gm, bt, None, mean2, rstd2, rows, 1e-5, y8=y8b, q8_dev=rl)           # the e4m3 copy as the only output
+    assert torch.equal(y8b, y8) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
     # attention epilogue writing the proj operand
     Dm, H, L = 768, 12, 200
     qkv = bf(torch.randn(2 * L, 3 * Dm, device=DEV, generator=g) * 0.5)
@@ -976,6 +987,9 @@ def test_fp8_delayed_scaling_records():
     assert rel_err(dX, want2) < 3e-3 and rel_err(cs, 1 + want2.sum(0)) < 2e-3
     s2 = grec.q[1, 0].item()
     assert rel_err(out8g.view(torch.float8_e5m2).float() / s2, want2) < 0.08
+    out8h, cs2 = torch.zeros_like(out8g), torch.ones(N, device=DEV)
+    o.gemm_nt_fp8(dY8, W8, None, M, qa=rg, qw=rw, grad=True, act=2, aux=aux, colsum=cs2, out8=out8h, q8=rg2)      # the e5m2 copy as the only output
+    assert torch.equal(out8h, out8g) and rel_err(cs2, cs) < 1e-5
     # LayerNorm backward writing the e5m2 copy of dx
     dyl = bf(torch.randn(rows, D, device=DEV, generator=g) * 1e-2)
     dxb_ = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
