@@ -50,21 +50,25 @@ if has fp8; then
   python bench.py --no-cpu-baseline --steps 10 --fp8 > $OUT/b_vitb_fp8_bench.json 2> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 10 --fp8 --fp8-dgrad > $OUT/b_vitb_fp8_dgrad_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 10 --fp8 --fp8-wgrad > $OUT/b_vitb_fp8_wgrad_bench.json 2>> $OUT/fp8.err
+  AVSIAM_FP8_LEAN=0 python bench.py --no-cpu-baseline --steps 10 --fp8 --fp8-wgrad > $OUT/b_vitb_fp8_wgrad_bf16copies_bench.json 2>> $OUT/fp8.err      # A/B: every bf16 copy still written
   python bench.py --no-cpu-baseline --steps 10 > $OUT/b_vitb_bf16_same_box_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute > $OUT/h_vit_huge14_b64_recompute_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 > $OUT/h_vit_huge14_b64_recompute_fp8_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute_fp8_dgrad_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.375 > $OUT/h_vit_huge14_b64_recompute0375_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.375 --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute0375_fp8_dgrad_bench.json 2>> $OUT/fp8.err
-  # fp8 weight gradients keep a fourth byte per activation element: 3/8 recomputed leaves 2 GiB of the card, so the data point is taken at 1/2
+  # fp8 weight gradients: with every bf16 copy kept (AVSIAM_FP8_LEAN=0) 3/8 recomputed leaves 2 GiB of the card, so that A/B point is taken at 1/2;
+  # with 8-bit-only outputs (default) 1/4 recomputed fits with a tenth of the card free (the --recompute auto policy)
+  AVSIAM_FP8_LEAN=0 python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.5 --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute05_fp8_wgrad_bf16copies_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.5 --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute05_fp8_wgrad_bench.json 2>> $OUT/fp8.err
+  python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.25 --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute025_fp8_wgrad_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.5 --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute05_fp8_dgrad_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute_fp8_wgrad_bench.json 2>> $OUT/fp8.err
   python - <<PY
 import json, glob
 for f in sorted(glob.glob("$OUT/[bh]_*bench.json")):
     try:
-        d = json.load(open(f)); print(f.split("/")[-1], round(d["value"], 2), round(d["ms_per_step"], 2), "bf16 frac", round(d["roofline"]["frac"], 3), "fp8 frac", d.get("roofline_fp8", {}).get("frac"))
+        d = json.load(open(f)); print(f.split("/")[-1], round(d["value"], 2), round(d["ms_per_step"], 2), "bf16 frac", round(d["roofline"]["frac"], 3), "fp8 frac", d.get("roofline_fp8", {}).get("frac"), "GiB", d["config"].get("peak_memory_gib"))
     except Exception as e:
         print(f, "ERR", e)
 PY
