@@ -479,10 +479,10 @@ def main():
             if "gemm_nt_fp8" in s:              # --fp8: the e4m3 forward GEMMs are a kernel family of their own, against the fp8 peak
                 x = s["gemm_nt_fp8"]
                 a8 = x["rate"] / 1e12
-                line["roofline_fp8"] = {"bound": "mfma", "kernel": "gemm_nt8_kernel<., FP8> (forward GEMMs on e4m3 operands, v_mfma_f32_16x16x128_f8f6f4)",
+                line["roofline_fp8"] = {"bound": "mfma", "kernel": "gemm_nt8_kernel<., FP8> (forward GEMMs on e4m3 operands" + (" and input-gradient GEMMs on e5m2 x e4m3" if (args.fp8_dgrad or args.fp8_wgrad) else "") + ", v_mfma_f32_16x16x128_f8f6f4)",
                                         "achieved": a8, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s", "frac": a8 / PEAK_FP8_TFLOPS, "traffic": None,
                                         "launches": x["launches"], "avg_launch_us": x["avg_us"], "flops_per_launch": x["work"] / x["launches"]}
-                line["roofline"]["kernel"] += " - the bf16 launches of the fp8 mode (backward; forward GEMMs without an fp8 instantiation)"
+                line["roofline"]["kernel"] += (" - the bf16 launches of the fp8 mode (patch embedding, decoder embedding, prediction heads: no fp8 instantiation)" if (args.fp8_dgrad or args.fp8_wgrad) else " - the bf16 launches of the fp8 mode (backward; forward GEMMs without an fp8 instantiation)")
             line["kernels"] = {k: {"launches": x["launches"], "total_ms": round(x["total_ms"], 3), "avg_us": round(x["avg_us"], 2),
                                    "rate_T_per_s": round(x["rate"] / 1e12, 3)} for k, x in sorted(s.items())}
         if prof2 is not None:
