@@ -535,6 +535,31 @@ extern "C" int avs_quantize_fp8_batched(const long long* desc, const int* cmap, 
     return 0;
 }
 
+// Many small regions zeroed by ONE launch: desc[d] = {address (16-byte aligned), bytes / 16}; chunk c of 64 KB belongs to descriptor
+// cmap[2c] and starts at 16-byte group cmap[2c + 1].  The pad rows (beyond the token rows, up to the 64- / 128- / 256-row granule the
+// GEMMs read) of a stack's buffers when the passes of a step SHARE one activation pool (engine.BufferPool): another pass has written
+// there since, and the weight-gradient GEMMs contract over those rows.
+__global__ __launch_bounds__(256) void zero_batched_kernel(const long long* __restrict__ desc, const int* __restrict__ cmap) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    const int d = cmap[2 * blockIdx.x];
+    const size_t g0 = (size_t)cmap[2 * blockIdx.x + 1];
+    u32x4* dst = reinterpret_cast<u32x4*>(desc[2 * d]);
+    const size_t n16 = (size_t)desc[2 * d + 1];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const size_t i = g0 + (size_t)it * 256 + threadIdx.x;
+        if (i >= n16) break;
+        dst[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
+extern "C" int avs_zero_batched(const long long* desc, const int* cmap, int nchunks, hipStream_t stream) {
+    AVS_CHECK_ARG(desc && cmap && nchunks > 0, "zero_batched: bad args");
+    zero_batched_kernel<<<nchunks, 256, 0, stream>>>(desc, cmap);
+    AVS_LAUNCH_CHECK("zero_batched");
+    return 0;
+}
+
 extern "C" int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax, hipStream_t stream) {
     AVS_CHECK_ARG(fmax == 448.0f || fmax == 57344.0f, "fp8_scale_update: fmax is 448 (e4m3) or 57344 (e5m2)");
     AVS_CHECK_ARG(q && hist && n > 0 && nhist > 0 && pos >= 0 && pos < nhist && margin >= 1.0f && first >= 0 && count > 0 && first + count <= n,

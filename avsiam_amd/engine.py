@@ -81,6 +81,49 @@ def _z(shape, dtype, dev):
     return torch.zeros(shape, dtype=dtype, device=dev)
 
 
+class BufferPool:
+    """One activation pool for ALL passes of a model (opt-in: CAVMAE_BASE(share_pass_buffers=True) / AVSIAM_SHARE_PASS_BUFFERS=1).
+    The training step runs its two passes one after the other (traintest_cavmae_base.py:131-152: pass 1 forward / backward / Adam, then
+    pass 2), so pass 1's activations are dead when pass 2 starts - yet each pass's stacks own their buffers for the life of the model,
+    and at ViT-H/14, batch 64 x 10 frames, it is the SUM of the two that does not fit the card without recomputing blocks.  With a pool
+    every pass bump-allocates the buffers of its stacks from offset 0 of the same chunks of memory: the card holds the LARGER pass.
+    Consequences, all handled in Stack: a buffer is zero at allocation only - another pass has written over it since - so the pad rows the
+    GEMMs read beyond the token rows are re-zeroed (one launch, ops.ZeroTable) at the start of every Stack.forward; nothing in a pooled
+    buffer survives into the other pass (results leave a pass as clones); and a backward over BOTH passes of one forward (the combined
+    loss with gradients) is refused by the model."""
+
+    CHUNK = 64 << 20          # smallest chunk; a chunk is at least 8 x the request that opens it (bump allocation: <= 1/8 lost at its end)
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.chunks = []
+        self.owner = None                      # the pass whose forward ran last (its activations are what the memory holds)
+        self.rewind()
+
+    def rewind(self):
+        """the next pass starts over at the first byte of every chunk"""
+        self.offs = [0] * len(self.chunks)
+
+    def alloc(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) & ~255
+        for i, c in enumerate(self.chunks):                # first fit: a later, smaller request may still use the room a larger one left
+            if self.offs[i] + nbytes <= c.numel():
+                break
+        else:
+            self.chunks.append(torch.zeros((max(self.CHUNK, 8 * nbytes),), dtype=U8, device=self.dev))
+            self.offs.append(0)
+            i, c = len(self.chunks) - 1, self.chunks[-1]
+        t = c[self.offs[i]:self.offs[i] + nbytes].view(dtype)[:n].view(shape)
+        self.offs[i] += nbytes
+        return t
+
+    def nbytes(self):
+        return sum(c.numel() for c in self.chunks)
+
+
 class Linear:
     """Arena views of one nn.Linear: bf16 weight [N,K], transposed copy [K,N], fp32 bias, gradient views."""
 
@@ -216,10 +259,22 @@ class _Inline:
 class Stack:
     """`nblocks` transformer blocks over a packed [rows, D] fp32 residual stream with saved activations."""
 
-    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None, inference=False):
+    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None, inference=False, pool=None):
         """inference=True: forward only - no activation is kept, every block reuses one set of buffers (the residual stream
-        ping-pongs between two) and the backward scratch is not allocated."""
+        ping-pongs between two) and the backward scratch is not allocated.
+        pool (BufferPool): the stack's per-token buffers come from the model's shared activation pool instead of torch.zeros."""
         assert sum(seq_lens) == rows
+        assert pool is None or not inference
+        self.pool = pool
+        self._pads = ops.ZeroTable() if pool is not None else None
+
+        def _z(shape, dtype, dev_):          # (shadows the module's _z for every allocation below)
+            if pool is None:
+                return torch.zeros(shape, dtype=dtype, device=dev_)
+            t = pool.alloc(shape, dtype)
+            if len(shape) == 2 and shape[0] > rows:                          # [token rows + pad, columns]: the pad rows must read as zeros
+                self._pads.add(t[rows:])
+            return t
         self.rows, self.D, self.H, self.hidden, self.nblocks = rows, D, H, hidden, nblocks
         self.row_mod = row_mod
         self.inference = inference
@@ -234,7 +289,7 @@ class Stack:
         self.fp8_lean = self.fp8_wgrad and FP8_LEAN          # (see FP8_LEAN)
         if self.fp8:
             r8 = ops.pad_rows(rows, 256)
-            self.a8 = torch.zeros((r8, max(D, hidden)), dtype=U8, device=dev)      # calibration step only: an activation quantised by a pass
+            self.a8 = _z((r8, max(D, hidden)), U8, dev)      # calibration step only: an activation quantised by a pass
             # persistent e4m3 copies of the stack's weights (two sets: the MAE pass's second tower), re-quantised with the step's scales by
             # ONE batched launch per forward once every GEMM is calibrated (ops.Fp8Batch); per block: qkv | proj | fc1 | fc2
             per_blk = 4 * D * D + 2 * D * hidden
@@ -244,10 +299,10 @@ class Stack:
             self.w8_batch = None                                                   # built after the calibration forward
             def blocks8(cols, shared=None):     # per block when the weight gradients read them (recomputed blocks share one, like their bf16 copies)
                 if not self.fp8_wgrad:
-                    one = shared if shared is not None else torch.zeros((r8, cols), dtype=U8, device=dev)
+                    one = shared if shared is not None else _z((r8, cols), U8, dev)
                     return [one] * nblocks
-                one = torch.zeros((r8, cols), dtype=U8, device=dev) if self.nrecomp else None
-                return [one if i < self.nrecomp else torch.zeros((r8, cols), dtype=U8, device=dev) for i in range(nblocks)]
+                one = _z((r8, cols), U8, dev) if self.nrecomp else None
+                return [one if i < self.nrecomp else _z((r8, cols), U8, dev) for i in range(nblocks)]
             self.ln1_8 = blocks8(D)                                                # e4m3 copy a LayerNorm writes for qkv ...
             self.ln2_8 = blocks8(D, None if self.fp8_wgrad else self.ln1_8[0])     # ... and for fc1 (one buffer serves both unless they are kept)
             self.att8 = blocks8(D)                                                 # ... the attention epilogue for proj
@@ -257,9 +312,9 @@ class Stack:
         if self.fp8_bwd:
             self.g8 = ops.Fp8Records(nblocks * 4, dev, fmax=ops.BF8_MAX)           # per block: the e5m2 operands dbo (fc2), dfc1 (fc1), dbm (proj)
             self.g8_seen, self.g8_have = set(), set()
-            self.dx8 = [torch.zeros((r8, D), dtype=U8, device=dev) for _ in range(2)]      # e5m2 copies of dbo / dbm
-            self.dfc1_8 = torch.zeros((r8, hidden), dtype=U8, device=dev)
-            self.dqkv8 = torch.zeros((r8, 3 * D), dtype=U8, device=dev)           # e5m2 copy of dqkv, written by the attention backward kernels
+            self.dx8 = [_z((r8, D), U8, dev) for _ in range(2)]      # e5m2 copies of dbo / dbm
+            self.dfc1_8 = _z((r8, hidden), U8, dev)
+            self.dqkv8 = _z((r8, 3 * D), U8, dev)           # e5m2 copy of dqkv, written by the attention backward kernels
             per_blk_t = 4 * D * D + 2 * D * hidden                                # transposed copies the fp8 input-gradient GEMMs read: fc2 | fc1 | proj | qkv
             self.wt8_flat = torch.zeros((2 * nblocks * per_blk_t,), dtype=U8, device=dev)
             self.wt8_off = {"fc2": 0, "fc1": D * hidden, "proj": 2 * D * hidden, "qkv": 2 * D * hidden + D * D}
@@ -336,6 +391,10 @@ class Stack:
         """blocks2 / split: rows [split, rows) run through a SECOND set of blocks (the MAE pass's visual tower next to its
         audio tower, cav_mae_base.py:487,489) in the same launches - every GEMM takes both weight sets
         (ops.gemm_nt(dual=...)), the LayerNorm picks the affine per row (row_mod: 0 below split, 1 from it)."""
+        if self._pads is not None:            # pooled buffers: another pass has written over them since this stack last ran
+            if self._pads.desc is None and self._pads.entries:
+                self._pads.build(self.x[0].device)
+            self._pads.run()
         if self.fp8:
             self.f8.update()                   # delayed scaling: last forward's amax -> history -> this forward's scales (one launch)
             nsets = 2 if blocks2 is not None else 1
@@ -724,9 +783,12 @@ def _fold_frames(imgs, T):
 class ContrastivePass:
     """Pass 1 (forward_encoder_mmixed + forward_contrastive, cav_mae_base.py:508-594,641-661)."""
 
-    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, world=1, rank=0, comm=None):
+    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, world=1, rank=0, comm=None, pool=None):
         self.arena, self.cfg, self.B, self.dev, self.world, self.rank = arena, cfg, batch, dev, world, rank
         self.comm = comm
+        self.pool = pool
+        if pool is not None:
+            pool.rewind()                      # (BufferPool: this pass's stacks start at the first byte, over the other pass's)
         assert world == 1 or comm is not None, "data parallel needs a collective (model.set_distributed)"
         self.dp = comm is not None and getattr(comm, "active", world > 1)
         T, D = cfg.frames, cfg.embed_dim
@@ -740,7 +802,7 @@ class ContrastivePass:
         rows = self.rows_a + self.rows_v
         self.rows = rows
         row_mod = torch.cat([torch.zeros(self.rows_a, dtype=U8), torch.ones(self.rows_v, dtype=U8)]).to(dev)
-        self.stack = Stack(dev, rows, D, cfg.num_heads, D * cfg.mlp_ratio, lens_a + lens_v, cfg.depth, row_mod)
+        self.stack = Stack(dev, rows, D, cfg.num_heads, D * cfg.mlp_ratio, lens_a + lens_v, cfg.depth, row_mod, pool=pool)
         self.blocks = [BlockParams(arena, f"vit_base.blocks.{i}", "_a", "_v") for i in range(cfg.depth)]
         self.final = [Norm(arena, "vit_base.norm_a"), Norm(arena, "vit_base.norm")]
         self.row_src_all, self.row_tok_all = _z((rows,), I32, dev), _z((rows,), I32, dev)
@@ -888,6 +950,8 @@ class ContrastivePass:
         plan: a ContrastivePlan to inject, or None when draw_device() already filled the index arrays.
         xf: (audio, frames) input transforms when the inputs are raw (ops.InputXf), else None."""
         cfg, st = self.cfg, self.stack
+        if self.pool is not None:
+            self.pool.owner = self             # (whose activations the shared memory holds: checked by backward)
         if plan is not None:
             self._set_plan(plan)
         x0 = st.x[0]
@@ -913,6 +977,8 @@ class ContrastivePass:
         """gout: [1] fp32 device tensor (d loss / d loss_c_weighted); weight = contrast_loss_weight.
         accumulate: the gradient arena already holds the other pass's contribution (Stack.backward)."""
         cfg, st = self.cfg, self.stack
+        if self.pool is not None and self.pool.owner is not self:
+            raise RuntimeError("shared activation pool: another pass ran its forward since this one's - its activations are gone")
         B, W, D, N = self.B, self.world, cfg.embed_dim, self.N
         ops.infonce_dlogits(self.total, self.nstats, gout, weight, self.dtotal)
         ops.gemm_f32_small(self.dtotal, self.Vn, self.dAn, N, D, N, (N, 1), (D, 1), 1.0 / cfg.temperature)
@@ -935,8 +1001,11 @@ class MaePass:
     """Pass 2 (forward_encoder + mm layers + forward_decoder + forward_mae_loss, cav_mae_base.py:441-504,597-638,
     663-683,694-707)."""
 
-    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev):
+    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, pool=None):
         self.arena, self.cfg, self.B, self.dev = arena, cfg, batch, dev
+        self.pool = pool
+        if pool is not None:
+            pool.rewind()
         B, T, D, Dd = batch, cfg.frames, cfg.embed_dim, cfg.dec_dim
         ka, kv, La, Lv = cfg.keep_a, cfg.keep_v, cfg.audio_tokens, cfg.video_tokens
         self.rows_a, self.rows_v = B * ka, B * T * kv
@@ -949,13 +1018,13 @@ class MaePass:
         self.grouped = self.rows_a % 256 == 0 and os.environ.get("AVSIAM_GROUP_TOWERS", "1") != "0"      # env: A/B measurements
         if self.grouped:
             row_mod = torch.cat([torch.zeros(self.rows_a, dtype=U8), torch.ones(self.rows_v, dtype=U8)]).to(dev)
-            self.st_t = Stack(dev, self.rows_a + self.rows_v, D, cfg.num_heads, hid, [ka] * B + [kv] * (B * T), cfg.depth, row_mod)
+            self.st_t = Stack(dev, self.rows_a + self.rows_v, D, cfg.num_heads, hid, [ka] * B + [kv] * (B * T), cfg.depth, row_mod, pool=pool)
             self.st_a = self.st_v = None
         else:
-            self.st_a = Stack(dev, self.rows_a, D, cfg.num_heads, hid, [ka] * B, cfg.depth)
-            self.st_v = Stack(dev, self.rows_v, D, cfg.num_heads, hid, [kv] * (B * T), cfg.depth)
-        self.st_mm = Stack(dev, B * self.n_enc, D, cfg.num_heads, hid, [self.n_enc] * B, 2)
-        self.st_dec = Stack(dev, B * self.Ltot, Dd, cfg.dec_heads, Dd * cfg.mlp_ratio, [self.Ltot] * B, cfg.dec_depth)
+            self.st_a = Stack(dev, self.rows_a, D, cfg.num_heads, hid, [ka] * B, cfg.depth, pool=pool)
+            self.st_v = Stack(dev, self.rows_v, D, cfg.num_heads, hid, [kv] * (B * T), cfg.depth, pool=pool)
+        self.st_mm = Stack(dev, B * self.n_enc, D, cfg.num_heads, hid, [self.n_enc] * B, 2, pool=pool)
+        self.st_dec = Stack(dev, B * self.Ltot, Dd, cfg.dec_heads, Dd * cfg.mlp_ratio, [self.Ltot] * B, cfg.dec_depth, pool=pool)
         self.blk_a = [BlockParams(arena, f"ast_base.blocks.{i}", "") for i in range(cfg.depth)]      # :489
         self.blk_v = [BlockParams(arena, f"vit_base.blocks.{i}", "_v") for i in range(cfg.depth)]   # :487
         self.blk_mm = [BlockParams(arena, "mm_layer_1", "_a"), BlockParams(arena, "mm_layer_2", "_a")]   # :699-700
@@ -1063,6 +1132,8 @@ class MaePass:
         xf: (audio, frames) input transforms when the inputs are raw (ops.InputXf), else None."""
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         La, Lv = cfg.audio_tokens, cfg.video_tokens
+        if self.pool is not None:
+            self.pool.owner = self
         if plan is not None:
             self._set_plan(plan)
         self.audio, self.imgs, self.xf = audio, _fold_frames(imgs, T), xf
@@ -1102,6 +1173,8 @@ class MaePass:
 
     def backward(self, gout, reducer=None, accumulate=False):
         cfg, B, T = self.cfg, self.B, self.cfg.frames
+        if self.pool is not None and self.pool.owner is not self:
+            raise RuntimeError("shared activation pool: another pass ran its forward since this one's - its activations are gone")
         La, Lv, D, Dd = cfg.audio_tokens, cfg.video_tokens, cfg.embed_dim, cfg.dec_dim
         ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a, xf=self.xf[0], stride=cfg.st)
         ops.mae_loss_bwd(self.p_v, self.imgs, self.mask_v.view(-1), gout, self.dp_v, False, Lv, self.nmask_v, xf=self.xf[1], stride=cfg.st)

@@ -148,8 +148,13 @@ class CAVMAE_BASE(nn.Module):
     def __init__(self, img_size=224, audio_length=1024, patch_size=16, in_chans=3, embed_dim=768,
                  modality_specific_depth=23, num_heads=16, decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16,
                  mlp_ratio=4., norm_layer=nn.LayerNorm, norm_pix_loss=False, tr_pos=False, opt=None, *,
-                 cfg: AVSiamConfig = None, init_seed=0, init_mode="init", plan_seed=None, verbose=True):
+                 cfg: AVSiamConfig = None, init_seed=0, init_mode="init", plan_seed=None, verbose=True, share_pass_buffers=None):
         super().__init__()
+        # engine.BufferPool: the two passes of the training step (run one after the other) take their activation buffers from the SAME
+        # memory - the card holds the larger pass, not the sum.  Opt-in (None: AVSIAM_SHARE_PASS_BUFFERS=1); a combined-loss forward WITH
+        # gradients (both passes alive until one backward) is then refused.
+        self.share_pass_buffers = (os.environ.get("AVSIAM_SHARE_PASS_BUFFERS", "0") == "1") if share_pass_buffers is None else bool(share_pass_buffers)
+        self._pool = None
         if verbose:
             print('A CAV-MAE Model')                              # reference prints (:224-226)
             print('Use norm_pix_loss: ', norm_pix_loss)
@@ -272,10 +277,13 @@ class CAVMAE_BASE(nn.Module):
         if key not in self._engines:
             from ..engine import ContrastivePass, MaePass
             dev = self.arena.p.device
+            if self.share_pass_buffers and self._pool is None:
+                from ..engine import BufferPool
+                self._pool = BufferPool(dev)
             if which == "mae":
-                self._engines[key] = MaePass(self.arena, self.cfg, batch, dev)
+                self._engines[key] = MaePass(self.arena, self.cfg, batch, dev, pool=self._pool)
             else:
-                self._engines[key] = ContrastivePass(self.arena, self.cfg, batch, dev, self._world, self._rank, self._comm)
+                self._engines[key] = ContrastivePass(self.arena, self.cfg, batch, dev, self._world, self._rank, self._comm, pool=self._pool)
             pend = getattr(self, "_fp8_pending", None)
             if pend:                                    # a restored run continues with the quantisation grids it was saved with
                 for name, st in self._fp8_stacks(which, self._engines[key]):
@@ -397,6 +405,10 @@ class CAVMAE_BASE(nn.Module):
         else:
             imgs = imgs.to(self.arena.p.device, torch.float32).contiguous()
         do_m, do_c = mae_loss_weight != 0, contrast_loss_weight != 0
+        if self.share_pass_buffers and do_m and do_c and torch.is_grad_enabled():
+            raise RuntimeError("share_pass_buffers: the two passes use the same activation memory, so a combined-loss forward with gradients "
+                               "(both alive until one backward) is not available - run the passes one after the other (train_step) or build "
+                               "the model without share_pass_buffers")
         if do_m:
             self.flush_deferred()                            # the MAE pass reads the parameters a deferred update still owes
         plan_m = plan_c = None

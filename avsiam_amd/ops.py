@@ -320,6 +320,38 @@ class Fp8Batch:
         _call("avs_quantize_fp8_batched", self.desc, self.cmap, self.nchunks, self.records.q, 1 if self.e5m2 else 0, _stream())
 
 
+class ZeroTable:
+    """Regions (row slices of contiguous 2-D tensors) zeroed together by one launch (avs_zero_batched)."""
+
+    def __init__(self):
+        self.entries, self.keep = [], []
+        self.desc = self.cmap = None
+
+    def add(self, t):
+        assert self.desc is None, "table already built"
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0:
+            return
+        assert t.is_contiguous() and t.data_ptr() % 16 == 0 and nbytes % 16 == 0, "zero table: 16-byte aligned regions"
+        self.entries.append((t.data_ptr(), nbytes // 16))
+        self.keep.append(t)
+
+    nchunks = 0
+
+    def build(self, dev):
+        cmap = []
+        for d, (_, n16) in enumerate(self.entries):
+            cmap += [[d, g] for g in range(0, n16, 4096)]
+        self.nchunks = len(cmap)
+        if self.nchunks:
+            self.desc = torch.tensor(self.entries, dtype=torch.int64, device=dev)
+            self.cmap = torch.tensor(cmap, dtype=I32, device=dev)
+
+    def run(self):
+        if self.nchunks:
+            _call("avs_zero_batched", self.desc, self.cmap, self.nchunks, _stream())
+
+
 def gemm_nt_fp8(A8, B8, out, M, alpha=1.0, bias=None, res=None, out2=None, act=0, scale_cols=0, col_scale=1.0, out8=None, out8_scale=1.0,
                 qa=None, qw=None, q8=None, dual=None, grad=False, aux=None, colsum=None):
     """x = alpha * (A8[M, K] @ B8[N, K]^T) + bias (+ res); act 0: out = x; act 1: out = gelu'(x), out2 = gelu(x) (like gemm_nt).

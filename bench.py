@@ -260,6 +260,8 @@ def main():
                     "the line then says dtype fp8-forward/bf16-backward and is NOT the headline metric")
     ap.add_argument("--fp8-dgrad", action="store_true", help="with --fp8: the four input-gradient GEMMs of a block on e5m2 gradient operands too (engine.FP8 = 2)")
     ap.add_argument("--fp8-wgrad", action="store_true", help="with --fp8: input gradients AND the four weight gradients of a block on fp8 operands (engine.FP8 = 3)")
+    ap.add_argument("--share-pass-buffers", action="store_true", help="the two passes of the step take their activation buffers from one pool "
+                    "(CAVMAE_BASE(share_pass_buffers=True)): the card holds the larger pass instead of the sum - shapes that otherwise need --recompute")
     ap.add_argument("--recompute", nargs="?", const="1", default=None, metavar="FRACTION",
                     help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved activations do not fit the GPU, e.g. "
                          "--model vit_huge14 at batch 64; with a FRACTION (0.375) only that share of every stack's blocks is recomputed and "
@@ -352,7 +354,7 @@ def main():
     a, v = a.to(dev), v.to(dev)
 
     def build():
-        m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank).to(dev)
+        m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank, share_pass_buffers=args.share_pass_buffers).to(dev)
         m.set_distributed(world, rank, comm)
         m.publish_grads = False
         return m
@@ -455,6 +457,7 @@ def main():
                           if world > 1 else {}), **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
                        **({"fp8_8bit_only_outputs": __import__("avsiam_amd.engine", fromlist=["FP8_LEAN"]).FP8_LEAN} if args.fp8_wgrad else {}),
                        "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       **({"share_pass_buffers": True} if args.share_pass_buffers else {}),
                        **({"rehearsal": "AVSIAM_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo + host-staged collectives - not a throughput figure"} if share else {}),
                        **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
                                         "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "defer_mae_only": os.environ.get("AVSIAM_DP_DEFER", "0"),

@@ -94,6 +94,10 @@ int avs_quantize_fp8(const void* x, int is_f32, uint8_t* y, long long n, float s
 /* many bf16 tensors in one launch (all weights of a stack, once per forward): desc [n][4] = {src, dst, numel / 4, record index}, cmap
  * [nchunks][2] = {descriptor, first 4-element group} per chunk of 8192 elements; scales from / amax into the records q [.][1024] */
 int avs_quantize_fp8_batched(const long long* desc, const int* cmap, int nchunks, float* q, int e5m2, avs_stream_t stream);
+/* many small regions zeroed by one launch: desc [n][2] = {address (16-byte aligned), bytes / 16}, cmap [nchunks][2] = {descriptor, first
+ * 16-byte group} per chunk of 64 KB.  No reference counterpart (torch allocates every activation afresh); used for the pad rows of a stack's
+ * buffers when the two passes of a step share one activation pool (engine.BufferPool) */
+int avs_zero_batched(const long long* desc, const int* cmap, int nchunks, avs_stream_t stream);
 int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int pos, float margin, int first, int count, float fmax, avs_stream_t stream);
 /* the same GEMM over TWO weight sets in one launch: rows [0, m_split) of A meet B / bias / colsum, rows [m_split, M) meet
  * B2 / bias2 / colsum2 (same shapes and leading dimension; m_split a multiple of 256).  Replaces the two nn.Linear calls the

@@ -121,3 +121,60 @@ def test_fp8_forward_with_recompute_trains_at_the_14x14_geometry(mode, recompute
         engine.FP8, engine.RECOMPUTE = "0", "0"
     assert all(x == x and abs(x) < 1e4 for h in hist for x in h), hist
     assert hist[-1][0] < hist[0][0], (hist[0], hist[-1])          # loss_mae
+
+
+@pytest.mark.parametrize("mode", ["0", "3"])
+def test_shared_activation_pool_is_the_same_training(mode):
+    """CAVMAE_BASE(share_pass_buffers=True) (engine.BufferPool): both passes of the step take their activation buffers from the same
+    memory.  From the second step on every pooled buffer of a pass holds the OTHER pass's data when its forward starts, pad rows included
+    (the weight-gradient GEMMs contract over them, the fp8 calibration takes their |max|): at lr = 0 - identical weights in every step -
+    the gradients of both passes must be the ones of a model with private buffers, step after step; the pool must be smaller than the
+    private buffers; misuse (a combined-loss forward with gradients, a backward after the other pass's forward) must raise."""
+    from avsiam_amd import engine
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.traintest_cavmae_base import train_step
+    cfg = AVSiamConfig(audio_tokens=128, frames=2)
+    B = 5                                            # 5 x (32 + 2 x 49) rows etc.: no stack's row count is a multiple of 64
+    a, v = synth_inputs(cfg, B, 17)
+    a, v = a.cuda(), v.cuda()
+    gen = torch.Generator().manual_seed(4)
+    pm, pc = make_mae_plan(cfg, B, gen), make_contrastive_plan(cfg, B, gen, random.Random(4))
+    try:
+        engine.FP8 = mode
+        grads = {}
+        for shared in (False, True):
+            m = CAVMAE_BASE(cfg=cfg, init_seed=3, init_mode="random", verbose=False, share_pass_buffers=shared).cuda()
+            m.publish_grads = False
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()                  # (parameters, gradients: everything but the passes' buffers)
+            out = []
+            for step in range(3):
+                o = train_step(m, a, v, 0.0, plans=(pm, pc))
+                out.append([float(x.item()) for x in o])
+                assert all(x == x for x in out[-1]), (shared, step, out[-1])
+            torch.cuda.synchronize()
+            grads[shared] = (m.arena.g.detach().clone(), out, torch.cuda.memory_allocated() - base)
+            if shared:
+                assert m._pool is not None and m._pool.nbytes() > 0
+                with pytest.raises(RuntimeError, match="share_pass_buffers"):
+                    m(a, v, mae_loss_weight=1, contrast_loss_weight=0.01)               # combined loss with gradients
+                lc = m(a, v, mae_loss_weight=0, contrast_loss_weight=0.01, mask_plan=pc)[0]
+                m(a, v, mae_loss_weight=1, contrast_loss_weight=0, mask_plan=pm)        # the MAE pass takes the memory over
+                with pytest.raises(RuntimeError, match="shared activation pool"):
+                    lc.backward()
+                with torch.no_grad():                                                   # without gradients the combined forward is fine
+                    both = m(a, v, mae_loss_weight=1, contrast_loss_weight=0.01, mask_plan={"mae": pm, "contrastive": pc})
+                assert abs(both[1].item() - out[-1][0]) <= 2e-3 * abs(out[-1][0]), (both[1].item(), out[-1][0])
+                assert abs(both[4].item() - 0.01 * out[-1][3]) <= 2e-3 * 0.01 * abs(out[-1][3]) + 1e-7, (both[4].item(), out[-1][3])      # (train_step's pass 1 has weight 1)
+            del m
+        g0, o0, mem0 = grads[False]
+        g1, o1, mem1 = grads[True]
+        # (fp8: the first step calibrates, later steps run on delayed scales - step by step the two models still do the same thing)
+        for s0, s1 in zip(o0, o1):
+            for x, y in zip(s0, s1):
+                assert abs(x - y) <= 1e-3 * abs(x) + 1e-7, (o0, o1)
+        rel = float((g0 - g1).double().norm() / g0.double().norm())
+        assert rel < (2e-2 if mode == "3" else 1e-4), rel          # bf16: the order of the fp32 atomics; fp8: amax atomics may move a scale by an ulp
+        assert mem1 < 0.8 * mem0, (mem0, mem1)                    # the passes' buffers: the larger pass (+ chunk slack) instead of the sum
+    finally:
+        engine.FP8 = "0"

@@ -63,6 +63,9 @@ if has fp8; then
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.5 --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute05_fp8_wgrad_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.25 --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute025_fp8_wgrad_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute 0.5 --fp8 --fp8-dgrad > $OUT/h_vit_huge14_b64_recompute05_fp8_dgrad_bench.json 2>> $OUT/fp8.err
+  # both passes' activations from one pool (the card holds the larger pass, not the sum): nothing is recomputed (--recompute auto lands on 0)
+  python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute auto --share-pass-buffers > $OUT/h_vit_huge14_b64_pooled_bench.json 2>> $OUT/fp8.err
+  python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute auto --share-pass-buffers --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_pooled_fp8_wgrad_bench.json 2>> $OUT/fp8.err
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_recompute_fp8_wgrad_bench.json 2>> $OUT/fp8.err
   python - <<PY
 import json, glob
