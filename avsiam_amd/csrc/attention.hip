@@ -154,6 +154,7 @@ __device__ __forceinline__ void store_block(bf16_t* rowp, int d, int hh, const f
         return (uint32_t)w;
     };
 #if ATTN_WIDE_STORE
+    uint32_t p8[2][2] = {{0u, 0u}, {0u, 0u}};                      // the 8-bit copy: [u] = {columns 16u + 8hh .. + 3, .. + 4 .. + 7} after the first exchange
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (d * 32 + 16 * u >= HG) continue;                       // (HG is a multiple of 16: a pair is valid or not as a whole)
@@ -166,8 +167,23 @@ __device__ __forceinline__ void store_block(bf16_t* rowp, int d, int hh, const f
         if (rowp) *reinterpret_cast<u32x4*>(rowp + d * 32 + 16 * u + 8 * hh) = u32x4{r0[0], r1[0], r0[1], r1[1]};      // (NULL: the 8-bit copy only)
         if (rowp8) {
             const auto r8 = __builtin_amdgcn_permlane32_swap(q8(e0, e1, e2, e3), q8(o0, o1, o2, o3), false, false);
-            *reinterpret_cast<uint2*>(rowp8 + d * 32 + 16 * u + 8 * hh) = make_uint2(r8[0], r8[1]);
+            p8[u][0] = r8[0]; p8[u][1] = r8[1];
         }
+    }
+    if (rowp8) {
+        if (d * 32 + 16 < HG) {
+            // both 16-column pairs exist: a second exchange (pair 0 of the upper lanes against pair 1 of the lower ones) leaves lanes 0-31 with
+            // columns 0 .. 15 and lanes 32-63 with 16 .. 31 of the block - ONE 16-byte store per lane instead of two 8-byte ones (these copies
+            // cost the short-sequence kernels 20 - 35 % as 8-byte pieces)
+            const auto xa = __builtin_amdgcn_permlane32_swap(p8[0][0], p8[1][0], false, false);
+            const auto xb = __builtin_amdgcn_permlane32_swap(p8[0][1], p8[1][1], false, false);
+            *reinterpret_cast<u32x4*>(rowp8 + d * 32 + 16 * hh) = u32x4{xa[0], xb[0], xa[1], xb[1]};
+        } else if (d * 32 < HG) {
+            *reinterpret_cast<uint2*>(rowp8 + d * 32 + 8 * hh) = make_uint2(p8[0][0], p8[0][1]);      // (hd 80: the last block has one pair)
+        }
+        // one block's conversions at a time: scheduled across blocks, the temporaries of the 8-bit copies cost the hd-64 kernels an occupancy
+        // step (dq<64,2> 164 -> 174 registers, fused<64,2> 166 -> 186: two waves per SIMD instead of three)
+        __builtin_amdgcn_sched_barrier(0);
     }
 #else
 #pragma unroll
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
 // extra epilogue costs the bf16 instantiations registers they do not have (hd 32: a spill under the 128-register bound; hd 64, 2 waves:
 // 172 instead of 164, an occupancy step).
 template <int HD, int NW, int HG = HD, bool G8 = false>
-__global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : (HD == 64 && NW == 2 && G8) ? 3 : 1) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int NTH = 64 * NW;
     constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2];
@@ -638,7 +654,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 //     written from the key fragments the wave already holds, into the space of the Q image; the dS image written in phase 1).
 // No atomics, no second pass; per (sequence, head) the arithmetic and its order equal the two-kernel form's.
 template <int HD, int NW, bool G8 = false>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, (HD == 64 && NW == 2 && G8) ? 3 : 1) void attn_bwd_fused_kernel(AttnArgs a) {
     constexpr int R = 32 * NW;                            // rows (queries = keys) a workgroup holds
     constexpr int NKK = HD / 16, NDB = HD / 32;
     constexpr int IMG = R * HD * 2;                       // bytes of a [R][HD] bf16 image
@@ -792,7 +808,7 @@ static int check_common(const char* name, const void* qkv, long long ld, int D, 
 extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                                const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
                                uint8_t* out8, long long ldo8, float* q8, hipStream_t stream) {
-    AVS_CHECK_ARG((out8 == nullptr) == (q8 == nullptr) && (!out8 || (ldo8 >= D && (ldo8 % 4) == 0)), "attn_fwd: out8 and q8 go together, ldo8 %% 4 == 0");
+    AVS_CHECK_ARG((out8 == nullptr) == (q8 == nullptr) && (!out8 || (ldo8 >= D && (ldo8 % 16) == 0)), "attn_fwd: out8 and q8 go together, ldo8 %% 16 == 0");
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_fwd: tile_rows must be 64 or 128");
     AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_fwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
@@ -828,7 +844,7 @@ extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
                                int kv_bf16, hipStream_t stream) {
     // kv_bf16 == 0 (with dqkv8 only): the key and value thirds of the bf16 dqkv are left unwritten - their only readers take the e5m2 copy
     AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd: kv_bf16 = 0 needs the e5m2 copy");
-    AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 4) == 0)), "attn_bwd: dqkv8 and its record go together, ld8 %% 4 == 0");
+    AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 16) == 0)), "attn_bwd: dqkv8 and its record go together, ld8 %% 16 == 0");
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_bwd: tile_rows must be 64 or 128");
     AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_bwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
@@ -868,7 +884,7 @@ extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int
                                      int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
                                      bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, hipStream_t stream) {
     AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd_fused: kv_bf16 = 0 needs the e5m2 copy");
-    AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 4) == 0)), "attn_bwd_fused: dqkv8 and its record go together, ld8 %% 4 == 0");
+    AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 16) == 0)), "attn_bwd_fused: dqkv8 and its record go together, ld8 %% 16 == 0");
     AVS_CHECK_ARG(rows_per_wg == 64 || rows_per_wg == 128, "attn_bwd_fused: rows_per_wg must be 64 or 128");
     const int hd = H > 0 ? D / H : 0;
     AVS_CHECK_ARG(qkv && seq_start && seq_len && nseq > 0 && H > 0 && (hd == 32 || hd == 64) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0,

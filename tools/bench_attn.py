@@ -39,6 +39,15 @@ def run_case(name, H, hd, lens, dev, tile_rows=(128, 64)):
         tb = timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv), 10)
         msg += (f"  [tile {tr}] fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF/s {rows*8.0*D/tf/1e9:6.0f} GB/s"
                 f"  bwd {tb*1e6:7.1f} us {2.5*fl/tb/1e12:6.1f} TF/s {rows*24.0*D/tb/1e9:6.0f} GB/s")
+        if "--g8" in sys.argv:          # the fp8 modes' variants: e4m3 copy of the output / e5m2 copy of dqkv written as well (and, lean, no bf16 dK / dV)
+            rec = ops.Fp8Records(2, dev, fmax=ops.BF8_MAX)
+            rec.q[:, 0], rec.q[:, 1], rec.q[:, 2] = 1000.0, 1e-3, 1e30      # (scale, 1 / scale, amax seen: as in a calibrated step no wave issues the amax atomic)
+            o8 = torch.zeros(rp, D, device=dev, dtype=torch.uint8)
+            d8 = torch.zeros(rp, 3 * D, device=dev, dtype=torch.uint8)
+            tf8 = timeit(lambda: ops.attn_fwd(qkv, tiles, H, out, lse, out8=o8, q8=rec.rec(0)), 10)
+            tb8 = timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=d8, q8=rec.rec(1)), 10)
+            tb8l = timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=d8, q8=rec.rec(1), kv_bf16=False), 10)
+            msg += f"  [+8-bit copies] fwd {tf8*1e6:7.1f} us  bwd {tb8*1e6:7.1f} us  bwd without bf16 dK/dV {tb8l*1e6:7.1f} us"
     if hd in (32, 64) and min(lens) <= 128:
         # the backward as the engine runs it: sequences of at most 128 tokens through the fused kernel, the rest through the two kernels
         f = [sq for sq in (ops.AttnSeqs(lens, dev, 0, 64), ops.AttnSeqs(lens, dev, 64, 128)) if sq.nseq]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 artefacts for the current build (GPU box, repo root):  bash tools/round4_profile.sh [part ...]   parts: bench prof pmc dp fp8 big ln rehearsal
+# Round-4 artefacts for the current build (GPU box, repo root):  bash tools/round4_profile.sh [part ...]   parts: bench prof prof8 pmc dp fp8 big ln rehearsal
 # (in the build container first: git rev-parse HEAD > HEAD_COMMIT - the PMC summaries stamp it)
 # Everything goes to gpurun_out/r04/ (copy what is to be judged into profiles/r04/).
 set -e
@@ -75,6 +75,15 @@ for f in sorted(glob.glob("$OUT/[bh]_*bench.json")):
     except Exception as e:
         print(f, "ERR", e)
 PY
+fi
+if has prof8; then
+  # kernel trace of the fp8 mode 3 step (ViT-B): the evidence behind roofline_fp8 and the fp8 weight-gradient family
+  cd /tmp && export TMPDIR=/tmp
+  AVSIAM_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof8 -o k -- python3 $REPO/bench.py --steps 4 --warmup 3 --no-cpu-baseline --roofline-steps 0 --fp8 --fp8-wgrad > $OUT/b_vitb_fp8_wgrad_s0_bench_rocprof.json 2> $OUT/b_rocprof.err
+  cd $REPO
+  find $OUT/prof8 -name "*kernel_stats.csv" -exec cp {} $OUT/b_vitb_fp8_wgrad_s0_kernel_stats.csv \;
+  rm -rf $OUT/prof8
+  echo "prof8 done"; head -8 $OUT/b_vitb_fp8_wgrad_s0_kernel_stats.csv
 fi
 if has big; then
   python bench.py --no-cpu-baseline --steps 5 --warmup 2 --model vit_large > $OUT/l_vit_large_bench.json 2> $OUT/big.err
