@@ -17,7 +17,7 @@ def pytest_configure(config):
 # the path against the reference's golden vectors and the oracle -> fine-tuned-model modes -> training step / optimizer ->
 # the full-size property tests -> boundary (entry point, checkpoints, launcher) -> multi-process schedules.  Within a file the
 # order of definition is kept.
-_ORDER = ["test_abi_cpu", "test_oracle_golden", "test_ft_oracle_golden", "test_bench_launcher_cpu", "test_dp_gloo",
+_ORDER = ["test_abi_cpu", "test_oracle_golden", "test_ft_oracle_golden", "test_bench_launcher_cpu", "test_pool_cpu", "test_dp_gloo",
           "test_kernels_gpu", "test_parity_gpu", "test_ft_gpu", "test_train_gpu", "test_fullsize_gpu", "test_fullsize_large_gpu",
           "test_boundary_gpu", "test_dp_gpu"]
 
