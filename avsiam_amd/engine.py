@@ -92,7 +92,9 @@ class BufferPool:
     buffer survives into the other pass (results leave a pass as clones); and a backward over BOTH passes of one forward (the combined
     loss with gradients) is refused by the model."""
 
-    CHUNK = 64 << 20          # smallest chunk; a chunk is at least 8 x the request that opens it (bump allocation: <= 1/8 lost at its end)
+    CHUNK = 64 << 20          # smallest chunk
+    GROW = 1 << 30            # a chunk is 8 x the request that opens it, but never more than the request + GROW: a late 0.75-GB request
+                              # (ViT-H) opens 1.75 GB, not 6 GB that may stay empty (ADVICE r4)
 
     def __init__(self, dev):
         self.dev = dev
@@ -113,7 +115,14 @@ class BufferPool:
             if self.offs[i] + nbytes <= c.numel():
                 break
         else:
-            self.chunks.append(torch.zeros((max(self.CHUNK, 8 * nbytes),), dtype=U8, device=self.dev))
+            want = max(self.CHUNK, min(8 * nbytes, nbytes + self.GROW))
+            try:
+                chunk = torch.zeros((want,), dtype=U8, device=self.dev)
+            except torch.OutOfMemoryError:                 # the request itself may still fit: an exact-size chunk
+                if want == nbytes:
+                    raise
+                chunk = torch.zeros((nbytes,), dtype=U8, device=self.dev)
+            self.chunks.append(chunk)
             self.offs.append(0)
             i, c = len(self.chunks) - 1, self.chunks[-1]
         t = c[self.offs[i]:self.offs[i] + nbytes].view(dtype)[:n].view(shape)
@@ -122,6 +131,14 @@ class BufferPool:
 
     def nbytes(self):
         return sum(c.numel() for c in self.chunks)
+
+    def used(self):
+        """bytes handed out since the last rewind (the live requests of the pass that owns the pool now)"""
+        return sum(self.offs)
+
+    def release(self):
+        """give the memory back (every engine built on this pool must be dropped by the caller: CAVMAE_BASE.release_buffers)"""
+        self.chunks, self.offs, self.owner = [], [], None
 
 
 class Linear:

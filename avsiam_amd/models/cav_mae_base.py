@@ -231,6 +231,18 @@ class CAVMAE_BASE(nn.Module):
         self._dp = getattr(self._comm, "active", world > 1)        # collectives on the path (always at world > 1)
         self._engines.clear()
 
+    def release_buffers(self):
+        """Drop every pass engine (activation buffers, saved plans, fp8 records: `fp8_state()` first if they are to survive) and the
+        shared activation pool's memory.  Engines are keyed by (pass, batch): with `share_pass_buffers` an engine of ANOTHER batch size
+        (validation between training steps) rewinds the same pool, so a pending forward of the first one must not be backpropagated
+        afterwards (the pool's owner check raises) - call this between phases that use different batch sizes when memory is tight."""
+        self.flush_deferred()
+        self._engines.clear()
+        if self._pool is not None:
+            self._pool.release()
+        if self.arena.p.is_cuda:
+            torch.cuda.empty_cache()
+
     def _make_reducer(self, lo, hi, overlap=None, boundary=None):
         from ..comm import GradReducer
         # the bf16 wire buffer (AVSIAM_DP_WIRE=bf16) is kept across steps and shared by the passes' reducers: it spans the whole live

@@ -6,9 +6,10 @@ import math
 import pytest
 import torch
 
-from avsiam_amd.maskplan import MaePlan, make_mae_plan
-from avsiam_amd.param_spec import P2
+from avsiam_amd.maskplan import ContrastivePlan, MaePlan, make_contrastive_plan, make_mae_plan
+from avsiam_amd.param_spec import P1, P2
 from avsiam_amd.weights import synth_inputs
+from tests.helpers import record_margin
 from tests.test_fullsize_gpu import B, T, _run, _same_direction
 
 pytestmark = pytest.mark.gpu
@@ -66,3 +67,99 @@ def test_vit_huge14_full_size_mae_equals_mean_of_halves():
     batch 64 x 10 frames with per-layer activation recompute."""
     from avsiam_amd.config import vit_huge14
     _halves_property(vit_huge14(frames=T), 22, recompute=True)
+
+
+def test_vit_large_full_size_contrastive_is_order_invariant():
+    """configs[3]'s shape, the CONTRASTIVE pass (round 5; cav_mae_base.py:508-594, 641-661): re-ordering the 64 clips of the batch with
+    their plans changes neither the loss, the accuracy nor the 300 M-element gradient - 95 630 packed rows x 24 layers x 1024 wide, the
+    largest contrastive stack the driver-run suite builds.  Same tolerances as the ViT-B form (tests/test_fullsize_gpu.py)."""
+    import gc
+    import random
+    from avsiam_amd.config import vit_large
+    from avsiam_amd.models import CAVMAE_BASE
+    cfg = vit_large(frames=T)
+    try:
+        m = CAVMAE_BASE(cfg=cfg, init_seed=23, init_mode="random", verbose=False).cuda()
+        m.publish_grads = False
+        a, v = synth_inputs(cfg, B, 9)
+        a, v = a.cuda(), v.cuda()
+        plan = make_contrastive_plan(cfg, B, torch.Generator().manual_seed(4), random.Random(4))
+        out, g = _run(m, a, v, plan, P1)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(9))
+        pl = perm.tolist()
+        plan_p = ContrastivePlan(plan.a_group[perm], plan.v_group[perm], [plan.a_keep[i] for i in pl], [plan.v_keep[i] for i in pl])
+        dperm = perm.cuda()
+        out_p, g_p = _run(m, a[dperm].contiguous(), v[dperm].contiguous(), plan_p, P1)
+        assert math.isfinite(out[4].item()) and 0.0 <= out[7].item() <= 1.0
+        assert abs(out_p[4].item() - out[4].item()) <= 1e-5 * abs(out[4].item()), (out_p[4].item(), out[4].item())
+        assert out_p[7].item() == out[7].item()
+        _same_direction(g_p, g)
+        del m, g, g_p
+    finally:
+        gc.collect(); torch.cuda.empty_cache()
+
+
+# configs[4] AT THE SIZE AND PRECISION IT NAMES (round 5): ViT-H/14, fp8 mode 3 (e4m3 forward operands, e5m2 gradient operands for the
+# input AND weight gradients), batch 64 x 10 frames, one activation pool, nothing recomputed (198 GiB).  The oracle is out of reach, so:
+# (1) three training steps with device-drawn plans stay finite and NO tensor leaves the range of the delayed scale it was quantised with
+#     (fp8_saturation_events() == 0: the margin-2 scales of engine.FP8 hold at the size the mode is meant for);
+# (2) the MAE pass over 64 clips equals the mean of its two 32-clip halves run with the same per-clip plans.  In bf16 that holds to fp32
+#     summation order (1e-5); in fp8 every quantised tensor of the 32-clip engines carries its OWN delayed scale (amax over other rows),
+#     so the operands round on slightly different grids: the stated tolerance is the fp8 noise, at ~3x the measurement
+#     (profiles/r05/parity_margins.json, vit_huge14_fp8_fullsize): loss rel 3e-3, whole flat gradient cosine >= 0.99, norm within 5 %.
+#     An indexing error at these sizes (row offsets beyond 2^31 bytes, pool aliasing) gives cosines near 0, far outside.
+FP8_FULL_LOSS_RTOL, FP8_FULL_COS_MIN, FP8_FULL_RATIO_TOL = 3e-3, 0.99, 0.05
+
+
+def test_vit_huge14_fp8_mode3_full_size_trains_and_mae_equals_mean_of_halves():
+    import gc
+    from avsiam_amd import engine
+    from avsiam_amd.config import vit_huge14
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.traintest_cavmae_base import train_step
+    cfg = vit_huge14(frames=T)
+    old = (engine.FP8, engine.RECOMPUTE)
+    engine.FP8, engine.RECOMPUTE = "3", "0"
+    try:
+        m = CAVMAE_BASE(cfg=cfg, init_seed=24, init_mode="random", verbose=False, plan_seed=5, share_pass_buffers=True).cuda()
+        m.publish_grads = False
+        a, v = synth_inputs(cfg, B, 7)
+        a, v = a.cuda(), v.cuda()
+        hist = []
+        for _ in range(3):
+            out = train_step(m, a, v, 1e-4)
+            hist.append([float(x.item()) for x in out])
+        sat = m.fp8_saturation_events()
+        pool_gib = m._pool.nbytes() / 2 ** 30
+        assert all(math.isfinite(x) and abs(x) < 1e4 for h in hist for x in h), hist
+        assert sat == 0, (sat, hist)
+        plan = make_mae_plan(cfg, B, torch.Generator().manual_seed(13))
+        out, g = _run(m, a, v, plan, P2)                 # the batch-64 MAE engine: calibrated, three steps of amax history
+        assert out[5].shape == (B, cfg.audio_tokens) and out[6].shape == (B, T * cfg.video_tokens)
+        full = [out[i].item() for i in (1, 2, 3)]
+        masks = (out[5].clone(), out[6].clone())
+        del out
+        m.release_buffers()                              # the pool (198 GiB) makes room for the batch-32 engine
+        acc = torch.zeros_like(g)
+        means = [0.0, 0.0, 0.0]
+        for s in (slice(0, B // 2), slice(B // 2, B)):
+            p = MaePlan(plan.ids_keep_a[s], plan.ids_restore_a[s], plan.ids_keep_v[s], plan.ids_restore_v[s])
+            ah, vh = a[s].contiguous(), v[s].contiguous()
+            _run(m, ah, vh, p, P2)                       # calibration step of the batch-32 records (scales from this very batch) ...
+            o, gh = _run(m, ah, vh, p, P2)               # ... and the step on delayed scales, like the batch-64 run above
+            assert torch.equal(o[5], masks[0][s]) and torch.equal(o[6], masks[1][s])
+            acc += 0.5 * gh
+            for k, i in enumerate((1, 2, 3)):
+                means[k] += 0.5 * o[i].item()
+        worst = max(abs(f - mn) / abs(mn) for f, mn in zip(full, means))
+        gd, rd = g.double(), acc.double()
+        cos = float(torch.dot(gd, rd) / (gd.norm() * rd.norm()))
+        ratio = float(gd.norm() / rd.norm())
+        record_margin("vit_huge14_fp8_fullsize", loss_rel=worst, grad_cos=cos, grad_norm_ratio_err=abs(ratio - 1), saturation_events=sat,
+                      pool_gib=pool_gib, losses_step0=hist[0], losses_step2=hist[-1])
+        assert worst <= FP8_FULL_LOSS_RTOL, (full, means)
+        assert cos >= FP8_FULL_COS_MIN and abs(ratio - 1) <= FP8_FULL_RATIO_TOL, (cos, ratio)
+        del m, g, acc
+    finally:
+        engine.FP8, engine.RECOMPUTE = old
+        gc.collect(); torch.cuda.empty_cache()
