@@ -65,11 +65,41 @@ def load():
         fn.restype = ctypes.c_char_p if ret == "str" else ctypes.c_longlong if ret == "ll" else ctypes.c_int
         fn.argtypes = [_CT[k] for k in kinds]
     _lib = lib
+    # the library never reads the environment (include/avsiam_hip.h): the AVSIAM_* tuning variables are applied HERE, once
+    for env, knob in _ENV_KNOBS.items():
+        v = os.environ.get(env)
+        if v is not None and v != "":
+            tuning_set(knob, int(v))
     return lib
+
+
+_ENV_KNOBS = {"AVSIAM_GEMM_TILE": "gemm_tile", "AVSIAM_GEMM_NT8": "gemm_nt8", "AVSIAM_NT_TILE_H": "nt_tile_h", "AVSIAM_NT_GRID": "nt_grid",
+              "AVSIAM_CU_RESERVE": "cu_reserve", "AVSIAM_LN_DMA": "ln_dma", "AVSIAM_LN_RPW": "ln_rpw", "AVSIAM_ATTN_RING": "attn_ring"}
+
+
+def tuning_set(name, value):
+    lib = load()
+    rc = lib.avs_tuning_set(name.encode(), int(value))
+    if rc != 0:
+        raise AvsiamHipError(f"avs_tuning_set({name}, {value}) failed ({rc}): {lib.avs_last_error().decode()}")
+
+
+def tuning_get(name):
+    lib = load()
+    out = ctypes.c_int(0)
+    rc = lib.avs_tuning_get(name.encode(), ctypes.byref(out))
+    if rc != 0:
+        raise AvsiamHipError(f"avs_tuning_get({name}) failed ({rc}): {lib.avs_last_error().decode()}")
+    return out.value
+
+
+calls = 0          # entry-point calls so far (graph_step counts the launches a captured step holds)
 
 
 def call(name, *args):
     """Invoke an entry point; torch tensors are passed as their data_ptr(), None as NULL."""
+    global calls
+    calls += 1
     lib = load()
     fn = getattr(lib, name)
     conv = []

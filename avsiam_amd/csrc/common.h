@@ -127,6 +127,30 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- process-wide tuning knobs (api.cpp).  Set ONLY through the C ABI (avs_tuning_set and the avs_gemm_set_* wrappers) - the host
+// binding reads the AVSIAM_* environment once at load and calls them; no launcher reads the environment or initialises anything
+// lazily.  Launchers only READ this struct (plain ints, written before any kernel is queued).
+struct AvsTuning {
+    int gemm_tile;         // 0 auto | 128 | 256: force the nt / tn GEMM tile (tuning + tests)                       AVSIAM_GEMM_TILE
+    int gemm_persistent;   // 1: 256^2 nt tiles run as persistent workgroups (0: one workgroup per tile, A/B tests)
+    int gemm_nt8;          // 1: 256^2 GEMMs run the 8-phase kernels                                                 AVSIAM_GEMM_NT8
+    int nt_tile_h;         // 8-phase nt kernel tile heights: 0 automatic | 256 | 224 | 240 (half and half)          AVSIAM_NT_TILE_H
+    int nt_grid;           // > 0: cap of the persistent nt grid (tools/bench_stagger.py)                            AVSIAM_NT_GRID
+    int cu_reserve;        // CUs every PERSISTENT kernel (gemm_nt8 / gemm_nt 256^2, gemm_tn8, gemm_tn8f, fp8 nt) leaves free: their grids
+                           // and split factors are sized for (CUs - cu_reserve), so that a collective's kernels (RCCL) find CUs WHILE a
+                           // GEMM runs instead of only at kernel boundaries.  0 on one GPU; the host sets 8 when world > 1 and the
+                           // gradient all-reduce overlaps the backward (comm.py)                                    AVSIAM_CU_RESERVE
+    int ln_dma;            // 1: LayerNorm backward by the LDS-DMA kernel where it applies | 0 never | 2 automatic per launch context
+                           // (avs_layernorm_bwd's `busy_lds` hint)                                                  AVSIAM_LN_DMA
+    int ln_rpw;            // rows per wave of the LayerNorm backward: 0 automatic | 4 | 8 | 16                      AVSIAM_LN_RPW
+    int attn_ring;         // 1: attention K/V (Q/dO) tiles by LDS-DMA ring where built (hd 32 / 64) | 0: register-staged kernels  AVSIAM_ATTN_RING
+};
+AvsTuning& avs_tuning();
+extern "C" int avs_tuning_set(const char* name, int value);
+extern "C" int avs_device_cu_count(void);
+// compute units a persistent kernel may fill: the device's CU count minus cu_reserve (never below 8)
+int avs_persistent_slots();
+
 // ---- fp8 (e4m3) per-tensor quantisation record, on the DEVICE (engine.FP8; delayed scaling): q[0] = scale (x -> x * scale -> e4m3),
 // q[1] = 1 / scale, q[2] = running max |x| of the values quantised since the last avs_fp8_scale_update, q[3] = number of updates that
 // found q[2] * scale > 448 (the tensor saturated under the scale it was quantised with).  Producers of an e4m3 operand read q[0]

@@ -305,6 +305,42 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// The same update with the step count in DEVICE memory (a training step replayed from a captured hipGraph: kernel arguments are frozen at
+// capture, so what changes from step to step - this count, the mask-plan seeds - lives in memory the graph's own nodes advance).
+// step_dev[0] >= 1 is the count of THIS update; the bias corrections are evaluated in double, as torch.optim.Adam and avs_adam do.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                bf16_t* __restrict__ pb, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                const int* __restrict__ step_dev, float gscale) {
+    const double t = (double)step_dev[0];
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    const size_t n4 = n / 4;
+    const float step = lr / bc1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = gp[k] * gscale + wd * pp[k];
+            mp[k] = b1 * mp[k] + (1.f - b1) * gg;
+            vp[k] = b2 * vp[k] + (1.f - b2) * gg * gg;
+            pp[k] -= step * mp[k] / (sqrtf(vp[k]) / bc2_sqrt + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (pb) {
+            uint2 o;
+            o.x = pack_bf2(pv.x, pv.y);
+            o.y = pack_bf2(pv.z, pv.w);
+            reinterpret_cast<uint2*>(pb)[i] = o;
+        }
+    }
+}
+
 // ===================================================================================================
 static inline int grid_1d(size_t n, int block) {
     size_t g = (n + block - 1) / block;
@@ -669,5 +705,13 @@ extern "C" int avs_adam(float* p, const float* g, float* m, float* v, bf16_t* p_
     adam_kernel<<<grid_1d(n / 4, 256), 256, 0, stream>>>(p, g, m, v, p_bf16, (size_t)n, lr, beta1, beta2, eps, weight_decay,
                                                          (float)bc1, (float)sqrt(bc2), grad_scale);
     AVS_LAUNCH_CHECK("adam");
+    return 0;
+}
+
+extern "C" int avs_adam_dev(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, long long n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, const int* step_dev, float grad_scale, hipStream_t stream) {
+    AVS_CHECK_ARG(n > 0 && (n % 4) == 0 && step_dev && p && g && m && v, "adam_dev: n must be a positive multiple of 4, step_dev a device pointer");
+    adam_dev_kernel<<<grid_1d(n / 4, 256), 256, 0, stream>>>(p, g, m, v, p_bf16, (size_t)n, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale);
+    AVS_LAUNCH_CHECK("adam_dev");
     return 0;
 }

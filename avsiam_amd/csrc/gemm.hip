@@ -1051,35 +1051,20 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(GemmTnGroupArgs g) {
 }
 
 // ===================================================================================================
-static int g_force_tile = -1;          // -1: read AVSIAM_GEMM_TILE once; 0 auto; 128 / 256 force a tile (tuning + tests)
-static int g_persistent = 1;           // 256^2 nt tiles: persistent workgroups (0: one workgroup per tile, for A/B tests)
+// Tuning knobs live in api.cpp (common.h AvsTuning; set through avs_tuning_set / the wrappers below, never read from the environment here).
+#define g_force_tile (avs_tuning().gemm_tile)
+#define g_persistent (avs_tuning().gemm_persistent)
+#define g_nt8 (avs_tuning().gemm_nt8)
+#define g_force_h (avs_tuning().nt_tile_h)
 
-extern "C" int avs_gemm_set_persistent(int on) {
-    g_persistent = on ? 1 : 0;
-    return 0;
-}
+extern "C" int avs_gemm_set_persistent(int on) { return avs_tuning_set("gemm_persistent", on ? 1 : 0); }
 
-static long long g_nt_dispatches = 0;      // kernel dispatches issued by avs_gemm_nt_bf16 so far (a call is one or two)
+static long long g_nt_dispatches = 0;      // kernel dispatches issued by avs_gemm_nt_bf16 so far (a call is one or two): a counter, not a knob
 extern "C" long long avs_gemm_nt_dispatches(void) { return g_nt_dispatches; }
 
-static int g_nt8 = -1;                     // 1: 256^2 GEMMs run the 8-phase kernels (AVSIAM_GEMM_NT8 / avs_gemm_set_nt8)
-extern "C" int avs_gemm_set_nt8(int on) {
-    g_nt8 = on ? 1 : 0;
-    return 0;
-}
-
-static int g_force_h = -1;                 // tile heights of the 8-phase nt kernel: 0 automatic | 256 | 224 | 240 = half the row tiles of each (AVSIAM_NT_TILE_H / avs_gemm_set_tile_height)
-extern "C" int avs_gemm_set_tile_height(int h) {
-    AVS_CHECK_ARG(h == 0 || h == 256 || h == 224 || h == 240, "gemm_set_tile_height: 0 (auto), 256, 224, or 240 (both, half and half)");
-    g_force_h = h;
-    return 0;
-}
-
-extern "C" int avs_gemm_set_tile(int tile) {
-    AVS_CHECK_ARG(tile == 0 || tile == 128 || tile == 256, "gemm_set_tile: tile must be 0 (auto), 128 or 256");
-    g_force_tile = tile;
-    return 0;
-}
+extern "C" int avs_gemm_set_nt8(int on) { return avs_tuning_set("gemm_nt8", on ? 1 : 0); }
+extern "C" int avs_gemm_set_tile_height(int h) { return avs_tuning_set("nt_tile_h", h); }
+extern "C" int avs_gemm_set_tile(int tile) { return avs_tuning_set("gemm_tile", tile); }
 
 static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
                           const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
@@ -1098,7 +1083,6 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M,
                  m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
     // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
-    if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     const int force = g_force_tile;
     const int big_tiles = ceil_div(M, 256) * (N / 256);
     const bool big = force == 256 ? (N % 256) == 0 : force == 128 ? false : ((N % 256) == 0 && big_tiles >= 224);
@@ -1128,11 +1112,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     };
     if (big) {
         // persistent: one 128-KiB-LDS workgroup per CU walks the tiles (grid = min(tiles, CUs))
-        static int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        }
+        const int ncu = avs_persistent_slots();      // CUs a persistent grid may fill (device CUs - the cu_reserve knob)
         // Two-buffer kernel (8-phase kernels switched off): with T tiles on C CUs the last of ceil(T/C) rounds may be nearly
         // empty (1122 tiles -> 4.4 rounds cost 5).  When the last round would be less than half full, the row panels that fill
         // floor(T/C) rounds stay 256^2 tiles and the remaining rows become 128 x 256 tiles of the SAME launch.
@@ -1142,7 +1122,6 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
             const int rows_full = ((big_tiles / ncu) * ncu) / nt_n;              // row panels inside whole rounds
             if (rows_full >= 1 && rows_full < nt_m && (big_tiles % ncu) * 2 <= ncu) b.m_full = rows_full * 256;
         }
-        if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
         if (g_nt8 >= 1 && K >= 128 && g_persistent && g_force_tile == 0) {
             // 8-phase kernel, one dispatch: a partial last round costs it the same as handing the leftover rows to the half-height-tile
             // kernel in a second dispatch (measured: 185.7 vs 186.0 ms/step).  What it can do about a badly filled last round: the R rounds
@@ -1151,7 +1130,6 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
             // profiles/r03/gemm_tile_height_by_shape.log) - e.g. 1122 tiles = 4.4 rounds of N = 768 become 21 + 1257 tiles in 5 full rounds:
             // 4.6 tile-times per CU instead of 5.  Two weight sets: their row split is a multiple of 256, so the 256-row class must cover
             // the first set entirely (every 224-row tile then lies in the second).
-            if (g_force_h < 0) { const char* e = getenv("AVSIAM_NT_TILE_H"); g_force_h = e ? atoi(e) : 0; }
             const bool one_set = m_split >= M || m_split <= 0;
             const int unit = nt_n * 8 / std::gcd(nt_n, 8);      // the first class holds whole row tiles and a multiple of 8 tiles (XCD classes)
             int tb = -1;                                          // -1: every tile 256 rows (the one-class kernel)
@@ -1179,7 +1157,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
             const int tiles8 = tb < 0 ? nt_m * nt_n : tb + ceil_div(M - (tb / nt_n) * 256 > 0 ? M - (tb / nt_n) * 256 : 0, 224) * nt_n;
             int grid8 = tiles8 < ncu ? tiles8 : ncu;
             // AVSIAM_NT_GRID: cap the persistent grid (tools/bench_stagger.py: two half-chip GEMMs side by side on two streams)
-            { static int gcap = -1; if (gcap < 0) { const char* e = getenv("AVSIAM_NT_GRID"); gcap = e ? atoi(e) : 0; } if (gcap > 0 && gcap < grid8) grid8 = gcap; }
+            { const int gcap = avs_tuning().nt_grid; if (gcap > 0 && gcap < grid8) grid8 = gcap; }
 #define NT8_LAUNCH(ACT_)                                                                          \
     do {                                                                                          \
         if (tb >= 0) gemm_nt8_kernel<ACT_, 0, 4, 3><<<grid8, 512, 131072, stream>>>(a);           \
@@ -1259,11 +1237,7 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
                  out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M, dual ? m_split : 0x7fffffff,
                  dual ? reinterpret_cast<const bf16_t*>(B2) : nullptr, dual ? bias2 : nullptr, dual ? colsum2 : nullptr,
                  out8, ldo8, out8_scale, qa, qw, dual ? qw2 : qw, q8, 0.f};
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-    }
+    const int ncu = avs_persistent_slots();      // CUs a persistent grid may fill (device CUs - the cu_reserve knob)
     const int tiles = ceil_div(M, 256) * (N / 256);
     const int grid = tiles < ncu ? tiles : ncu;
     if (a_e5m2) {
@@ -1293,7 +1267,6 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
                                 int M, int N1, int N2, int splits, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && (N1 % 128) == 0 && (N2 % 128) == 0, "gemm_tn: need N1%%128==0 and N2%%128==0 (N1=%d N2=%d)", N1, N2);
     AVS_CHECK_ARG(A && B && C && (lda % 8) == 0 && (ldb % 8) == 0, "gemm_tn: bad operands");
-    if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
@@ -1310,7 +1283,6 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
     // 256^2 tiles need a long contraction to amortise their 256 KiB atomic epilogue per split
     // ... and enough output tiles that the splits (each adds a full-tile atomic epilogue) stay few
     // (8-phase kernel: from 12 tiles - the decoder's 1536x512 / 2048x512 gradients gain 14-18 % on it; 9 tiles and fewer lose)
-    if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
     const int min_tiles = g_nt8 >= 1 ? 12 : 24;
     const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256 && (N1 / 256) * (N2 / 256) >= min_tiles);
     const int T = big ? 256 : 128;
@@ -1319,11 +1291,7 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
         // one resident round: 256^2 tiles hold 128 KiB of LDS (1 workgroup per CU), 128^2 tiles 64 KiB (2 per CU).  A grid
         // slightly LARGER than the resident slots would add a second, almost empty round that doubles the critical path,
         // so round the split count DOWN (e.g. 27 tiles -> 9 splits = 243 workgroups on 256 CUs).
-        static int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-        }
+        const int ncu = avs_persistent_slots();      // CUs a persistent grid may fill (device CUs - the cu_reserve knob)
         const int slots = big ? ncu : 2 * ncu;
         splits = slots / tiles;
         if (splits < 1) splits = 1;
@@ -1531,11 +1499,7 @@ extern "C" int avs_gemm_tn_fp8_group3(const uint8_t* A0, long long lda0, const u
         }
         attr_done = true;
     }
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-    }
+    const int ncu = avs_persistent_slots();      // CUs a persistent grid may fill (device CUs - the cu_reserve knob)
     int splits = ncu / tiles;                              // one resident round, rounded DOWN (as avs_gemm_tn_bf16_group3)
     if (splits < 1) splits = 1;
     if (splits > nstages / 2) splits = nstages / 2 > 0 ? nstages / 2 : 1;
@@ -1557,8 +1521,6 @@ extern "C" int avs_gemm_tn_bf16_group3(const bf16_t* A0, long long lda0, const b
     const long long las[3] = {lda0, lda1, lda2}, lbs[3] = {ldb0, ldb1, ldb2};
     const int n1s[3] = {N1_0, N1_1, N1_2}, n2s[3] = {N2_0, N2_1, N2_2};
     AVS_CHECK_ARG(A0 && M > 0, "gemm_tn_group3: the first problem must exist");
-    if (g_nt8 < 0) { const char* e8 = getenv("AVSIAM_GEMM_NT8"); g_nt8 = e8 ? atoi(e8) : 1; }
-    if (g_force_tile < 0) { const char* e = getenv("AVSIAM_GEMM_TILE"); g_force_tile = e ? atoi(e) : 0; }
     GemmTnGroupArgs g{};
     int n = 0, tiles = 0;
     bool ok = true;
@@ -1585,11 +1547,7 @@ extern "C" int avs_gemm_tn_bf16_group3(const bf16_t* A0, long long lda0, const b
         }
         attr_done = true;
     }
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-    }
+    const int ncu = avs_persistent_slots();      // CUs a persistent grid may fill (device CUs - the cu_reserve knob)
     int splits = ncu / tiles;                              // one resident round, rounded DOWN (see avs_gemm_tn_bf16)
     if (splits < 1) splits = 1;
     if (splits > nstages / 2) splits = nstages / 2 > 0 ? nstages / 2 : 1;

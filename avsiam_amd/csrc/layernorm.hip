@@ -409,8 +409,8 @@ __global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, 
 
 extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, 4 * LN_MIN_ROWS_PER_WAVE) * LN_SETS * D; }
 
-static int g_ln_dma = -1;                   // 1: the LDS-DMA backward kernel where it applies (default); 0: never (AVSIAM_LN_DMA, A/B)
-static int g_ln_rpw = -1;                   // rows per wave of the backward kernel: 0 automatic; 4 / 8 / 16 forced (AVSIAM_LN_RPW, tuning)
+// knobs (api.cpp, common.h AvsTuning): ln_dma - 1: the LDS-DMA backward kernel where it applies (default), 0: never (A/B);
+// ln_rpw - rows per wave of the backward kernel: 0 automatic, 4 / 8 / 16 forced (tuning)
 
 extern "C" int avs_layernorm_fwd_q8(const float* x, const float* g0, const float* b0, const float* g1, const float* b1,
                                     const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
@@ -455,17 +455,15 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(dy && x && mean && rstd && g0 && (dx || dx_bf16) && ws, "layernorm_bwd: null pointer");
     AVS_CHECK_ARG(!(dres && dres_bf16 && (const void*)dx_bf16 == dres), "layernorm_bwd: dx_bf16 must not alias a bf16 dres");
-    if (g_ln_rpw < 0) { const char* e = getenv("AVSIAM_LN_RPW"); g_ln_rpw = e ? atoi(e) : 0; }
     // A block of 4 waves x RPW rows writes one slab of parameter-gradient partial sums; fewer rows per wave = more blocks
     // (helps only when 16 rows leave most CUs with a single block) and more slab traffic.
-    int rpw = g_ln_rpw;
+    int rpw = avs_tuning().ln_rpw;
     if (rpw != 4 && rpw != 8 && rpw != 16) rpw = rows >= 16384 ? 16 : 8;        // measured (tools/bench_ln.py): 8 wins only on the 8192-row audio tower
     const int nblocks = ceil_div(rows, 4 * rpw);
     dim3 grid(nblocks), block(256);
-    if (g_ln_dma < 0) { const char* e = getenv("AVSIAM_LN_DMA"); g_ln_dma = e ? atoi(e) : 1; }
     // the step's common case - bf16 dy, bf16 residual-gradient stream in, bf16 dx out only - takes the LDS-DMA kernel (D <= 1024:
     // two slots per wave must leave room for at least two blocks per CU); AVSIAM_LN_DMA=0: the register-load kernel for everything (A/B)
-    if (g_ln_dma && !dy_f32 && dres && dres_bf16 && !dx && dx_bf16 && !dx8 && D <= 1024) {
+    if (avs_tuning().ln_dma && !dy_f32 && dres && dres_bf16 && !dx && dx_bf16 && !dx8 && D <= 1024) {
 #define LN_DMA(NV)                                                                                                                              \
     do {                                                                                                                                        \
         if (rpw == 16) ln_bwd_dma_kernel<NV, 16><<<grid, block, 0, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows); \

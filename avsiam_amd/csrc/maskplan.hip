@@ -47,9 +47,15 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const PlanSeq* __restric
                                                         const unsigned* __restrict__ tmask_hi, const unsigned* __restrict__ fmask,
                                                         unsigned seed_lo, unsigned seed_hi, int* __restrict__ row_src,
                                                         int* __restrict__ row_tok, int* __restrict__ src_row,
-                                                        float* __restrict__ mask_out, int* __restrict__ ids_out) {
+                                                        float* __restrict__ mask_out, int* __restrict__ ids_out,
+                                                        const unsigned long long* __restrict__ seed_dev) {
     __shared__ float key[1024];
     __shared__ short idx[1024];
+    if (seed_dev) {                             // the key lives in device memory (a step replayed from a captured hipGraph: avs_mask_plan_dev)
+        const unsigned long long sd = seed_dev[0];
+        seed_lo = (unsigned)sd;
+        seed_hi = (unsigned)(sd >> 32);
+    }
     const int sq = blockIdx.x;
     const PlanSeq s = seqs[sq];
     int n2 = 64;
@@ -104,7 +110,19 @@ extern "C" int avs_mask_plan(const int* seqs, int nseq, const unsigned* tmask_lo
                              hipStream_t stream) {
     AVS_CHECK_ARG(seqs && nseq > 0 && row_src && row_tok, "mask_plan: bad arguments");
     mask_plan_kernel<<<nseq, 256, 0, stream>>>(reinterpret_cast<const PlanSeq*>(seqs), tmask_lo, tmask_hi, fmask, (unsigned)seed,
-                                               (unsigned)(seed >> 32), row_src, row_tok, src_row, mask_out, ids_out);
+                                               (unsigned)(seed >> 32), row_src, row_tok, src_row, mask_out, ids_out, nullptr);
     AVS_LAUNCH_CHECK("mask_plan");
+    return 0;
+}
+
+// the same with the Philox key read from DEVICE memory (seed_dev[0]) when the kernel runs: kernel arguments are frozen in a captured
+// hipGraph, a key that advances from step to step is advanced by a node of the graph itself
+extern "C" int avs_mask_plan_dev(const int* seqs, int nseq, const unsigned* tmask_lo, const unsigned* tmask_hi, const unsigned* fmask,
+                                 const unsigned long long* seed_dev, int* row_src, int* row_tok, int* src_row, float* mask_out, int* ids_out,
+                                 hipStream_t stream) {
+    AVS_CHECK_ARG(seqs && nseq > 0 && row_src && row_tok && seed_dev, "mask_plan_dev: bad arguments");
+    mask_plan_kernel<<<nseq, 256, 0, stream>>>(reinterpret_cast<const PlanSeq*>(seqs), tmask_lo, tmask_hi, fmask, 0u, 0u, row_src, row_tok, src_row,
+                                               mask_out, ids_out, seed_dev);
+    AVS_LAUNCH_CHECK("mask_plan_dev");
     return 0;
 }

@@ -92,9 +92,10 @@ class BufferPool:
     buffer survives into the other pass (results leave a pass as clones); and a backward over BOTH passes of one forward (the combined
     loss with gradients) is refused by the model."""
 
-    CHUNK = 64 << 20          # smallest chunk
-    GROW = 1 << 30            # a chunk is 8 x the request that opens it, but never more than the request + GROW: a late 0.75-GB request
-                              # (ViT-H) opens 1.75 GB, not 6 GB that may stay empty (ADVICE r4)
+    CHUNK = 64 << 20          # smallest chunk; a chunk is 8 x the request that opens it (bump allocation: <= 1/8 lost at its end - a chunk
+                              # sized request + 1 GiB was tried in round 5 and wasted 45 % at ViT-H, whose requests are all ~1.2 GiB: each
+                              # chunk then holds ONE); when the card cannot give 8 x any more, 2 x and then the request itself are tried
+                              # before the allocation fails (ADVICE r4: a late request must not fail while it would fit)
 
     def __init__(self, dev):
         self.dev = dev
@@ -115,13 +116,14 @@ class BufferPool:
             if self.offs[i] + nbytes <= c.numel():
                 break
         else:
-            want = max(self.CHUNK, min(8 * nbytes, nbytes + self.GROW))
-            try:
-                chunk = torch.zeros((want,), dtype=U8, device=self.dev)
-            except torch.OutOfMemoryError:                 # the request itself may still fit: an exact-size chunk
-                if want == nbytes:
-                    raise
-                chunk = torch.zeros((nbytes,), dtype=U8, device=self.dev)
+            chunk = None
+            for mult in (8, 2, 1):
+                try:
+                    chunk = torch.zeros((max(self.CHUNK if mult == 8 else 0, mult * nbytes),), dtype=U8, device=self.dev)
+                    break
+                except torch.OutOfMemoryError:
+                    if mult == 1:
+                        raise
             self.chunks.append(chunk)
             self.offs.append(0)
             i, c = len(self.chunks) - 1, self.chunks[-1]
@@ -912,9 +914,17 @@ class ContrastivePass:
         src = np.where(s2r < B, r * B + s2r, N + r * B + (s2r - B))           # the same sample's row of dAV (this rank's slice)
         self.slot_maps.copy_(torch.from_numpy(np.stack([s2r, src]).astype(np.int32)), non_blocking=True)
 
-    def draw_device(self, seed, nprng):
+    def draw_device(self, seed, nprng, seed_dev=None, host=True):
         """Draw this step's plan on the device (ops.mask_plan): the host only picks the two batch permutations
-        (torch.chunk(randperm) at cav_mae_base.py:533-538) and the structured time/frequency selections (:415-422)."""
+        (torch.chunk(randperm) at cav_mae_base.py:533-538) and the structured time/frequency selections (:415-422).
+        host=False: the host part (draw_host: numpy draws + three small host-to-device copies) has been done by the caller - a step
+        replayed from a captured graph (graph_step) does it in front of every replay; seed_dev: the Philox key in device memory."""
+        if host:
+            self.draw_host(nprng)
+        ops.mask_plan(self.desc_dev, self.desc_host, seed, self.row_src_all, self.row_tok_all, self.bits_dev[0], self.bits_dev[1], self.bits_dev[2],
+                      ids_out=self.ids_dev, seed_dev=seed_dev)
+
+    def draw_host(self, nprng):
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         t, f = cfg.audio_t, cfg.audio_f
         perm_a, perm_v = nprng.permutation(B), nprng.permutation(B)
@@ -940,8 +950,6 @@ class ContrastivePass:
             d[:B, 9] = (tm[:, 64:] << np.arange(t - 64, dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint32).view(np.int32)
         self.desc_dev.copy_(torch.from_numpy(d), non_blocking=True)
         self.bits_dev.copy_(torch.from_numpy(self.bits_host), non_blocking=True)
-        ops.mask_plan(self.desc_dev, d, seed, self.row_src_all, self.row_tok_all, self.bits_dev[0], self.bits_dev[1], self.bits_dev[2],
-                      ids_out=self.ids_dev)
         self._set_slot_maps(np.concatenate([perm_a, B + perm_v]))
         self.last_perm = (perm_a, perm_v)
 
@@ -1130,10 +1138,13 @@ class MaePass:
         self.mask_a.copy_((ra >= ka).float(), non_blocking=True)                         # :385-388
         self.mask_v.copy_((rv >= kv).float().reshape(B, T * Lv), non_blocking=True)
 
-    def draw_device(self, seed, nprng=None):
-        """75 % unstructured masks of every audio / video sequence, drawn on the device (one launch)."""
+    def draw_device(self, seed, nprng=None, seed_dev=None, host=True):
+        """75 % unstructured masks of every audio / video sequence, drawn on the device (one launch; no host part)."""
         ops.mask_plan(self.desc_dev, self.desc_host, seed, self.row_src_all, self.row_tok_all, src_row=self.src_row,
-                      mask_out=self.mask_all, ids_out=self.ids_dev)
+                      mask_out=self.mask_all, ids_out=self.ids_dev, seed_dev=seed_dev)
+
+    def draw_host(self, nprng=None):
+        pass
 
     def last_plan(self):
         """Rebuild the MaePlan the device drew (tests / debugging; synchronises)."""

@@ -64,7 +64,7 @@ class _HotPath(torch.autograd.Function):
         if plan_m is not False:
             eng = model._engine("mae", B)
             if plan_m is None:
-                eng.draw_device(model._next_seed(), model._np_rng())
+                model._draw(eng)
             lm, la, lv, ma, mv = eng.forward(audio, imgs, plan_m, xf)
             out.update(loss_mae=lm.clone(), la=la.clone(), lv=lv.clone(), mask_a=ma.clone(), mask_v=mv.clone())
         else:
@@ -72,7 +72,7 @@ class _HotPath(torch.autograd.Function):
         if plan_c is not False:
             eng = model._engine("contrastive", B)
             if plan_c is None:
-                eng.draw_device(model._next_seed(), model._np_rng())
+                model._draw(eng)
             lc, acc = eng.forward(audio, imgs, plan_c, contrast_w, xf)    # lc = contrast_loss_weight * nce (:735), from the kernel
             out.update(loss_c=lc.clone(), c_acc=acc.clone())
         else:
@@ -188,6 +188,7 @@ class CAVMAE_BASE(nn.Module):
         self._pyrng = None
         self._plan_seed = plan_seed
         self._shadow_dirty = True
+        self._graph = None                         # graph_step.GraphedTrainStep: {"seed": int64 [1], "steps": {P1: int32 [1], P2: int32 [1]}} on the device
 
     # ---- device management: parameters are views of one flat buffer, so move the buffer and re-point them -------
     def _apply(self, fn, recurse=True):
@@ -230,6 +231,14 @@ class CAVMAE_BASE(nn.Module):
         assert self._comm.world == world and self._comm.rank == rank, "comm does not match (world, rank)"
         self._dp = getattr(self._comm, "active", world > 1)        # collectives on the path (always at world > 1)
         self._engines.clear()
+        # The gradient all-reduce overlaps the backward (comm.GradReducer, AVSIAM_DP_OVERLAP): RCCL's kernels need compute units
+        # WHILE a persistent GEMM holds the chip, so every persistent kernel leaves `cu_reserve` CUs free (include/avsiam_hip.h,
+        # avs_tuning_set) - 8 by default when collectives are on the path (one per XCD; AVSIAM_CU_RESERVE overrides, 0 = none).
+        # One blocking message after the backward (AVSIAM_DP_OVERLAP=0) needs no reservation.  Cost at one rank: DESIGN.md 5e.
+        # (the knob is process-wide, like the device: the last model to call set_distributed decides)
+        if self.arena.p.is_cuda and os.environ.get("AVSIAM_CU_RESERVE") is None:
+            overlap = os.environ.get("AVSIAM_DP_OVERLAP", "1") != "0"
+            _lib.tuning_set("cu_reserve", 8 if (self._dp and overlap) else 0)
 
     def release_buffers(self):
         """Drop every pass engine (activation buffers, saved plans, fp8 records: `fp8_state()` first if they are to survive) and the
@@ -371,6 +380,16 @@ class CAVMAE_BASE(nn.Module):
         self._draws = getattr(self, "_draws", 0) + 1
         return ((self._seed_base & 0xFFFFFFFF) << 32) | (self._draws & 0xFFFFFFFF)
 
+    def _draw(self, eng):
+        """this step's mask plan for `eng`, drawn on the device.  Inside a captured step (graph_step.GraphedTrainStep) the Philox key is
+        read from device memory and advanced by a node of the graph; the host part of the contrastive draw runs in front of each replay."""
+        g = self._graph
+        if g is None:
+            eng.draw_device(self._next_seed(), self._np_rng())
+        else:
+            eng.draw_device(None, None, seed_dev=g["seed"], host=False)
+            g["seed"].add_(1)
+
     def _np_rng(self):
         self._rngs()
         return self._nprng
@@ -482,7 +501,15 @@ class CAVMAE_BASE(nn.Module):
             self._opt_state[which] = st
         if which == P2 and self._deferred is not None and "adam" in self._deferred:
             self.flush_deferred()                                      # a second update before the first was applied: settle it
-        st["step"] += 1
+        g = self._graph
+        if g is None:
+            st["step"] += 1
+            step_dev = None
+        else:                                      # captured step: the count lives in device memory, advanced by this node (the host's copy by GraphedTrainStep.step)
+            if self._deferred is not None:
+                raise RuntimeError("a captured step does not support the deferred MAE-only update (AVSIAM_DP_DEFER)")
+            step_dev = g["steps"][which]
+            step_dev.add_(1)
         owed = {self._grad_scale[name] for name, slo, shi in self._segments(which) if shi > slo}
         if len(owed) > 1:                          # the pass's two segments owe different factors (mixed use): settle them first
             self._average(which)
@@ -494,7 +521,7 @@ class CAVMAE_BASE(nn.Module):
             self._deferred["adam"] = (end, hi, lr, st["step"], beta1, beta2, eps, weight_decay, scale)
         if end > lo:
             ops.adam(a.p[lo:end], a.g[lo:end], st["m"][:end - lo], st["v"][:end - lo], a.pb[lo:end], end - lo, lr, st["step"], beta1, beta2, eps,
-                     weight_decay, scale)
+                     weight_decay, scale, step_dev=step_dev)
         for name, _, _ in self._segments(which):
             self._grad_scale[name] = 1.0
         if end == hi:

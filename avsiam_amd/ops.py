@@ -577,9 +577,10 @@ PLAN_FIELDS = 12      # int32 per sequence descriptor of avs_mask_plan
 
 
 def mask_plan(seqs_dev, seqs_host, seed, row_src, row_tok, tmask_lo=None, tmask_hi=None, fmask=None, src_row=None, mask_out=None,
-              ids_out=None):
+              ids_out=None, seed_dev=None):
     """Draw the random masks of every sequence in `seqs` on the device.  seqs_host (numpy int32 [nseq, 12]) is the host copy
-    of seqs_dev used to validate every offset before the launch."""
+    of seqs_dev used to validate every offset before the launch.  seed_dev (int64 [1] device tensor): the Philox key is read from it
+    when the kernel runs instead of `seed` (graph_step: kernel arguments are frozen in a captured graph)."""
     _chk(seqs_dev, I32, "plan.seqs", 2); _chk(row_src, I32, "plan.row_src"); _chk(row_tok, I32, "plan.row_tok")
     _chk(src_row, I32, "plan.src_row"); _chk(mask_out, F32, "plan.mask"); _chk(ids_out, I32, "plan.ids")
     for t in (tmask_lo, tmask_hi, fmask):
@@ -602,6 +603,10 @@ def mask_plan(seqs_dev, seqs_host, seed, row_src, row_tok, tmask_lo=None, tmask_
         sel = t_p > 0
         # time patches: 64 bits in tmask_lo / tmask_hi + 32 in the descriptor (field 9, PlanSeq.tmask_x); frequency patches: 32 bits
         assert (t_p[sel] <= 96).all() and (L[sel] % t_p[sel] == 0).all() and (L[sel] // t_p[sel] <= 32).all()
+    if seed_dev is not None:
+        assert seed_dev.dtype == torch.int64 and seed_dev.is_cuda and seed_dev.numel() >= 1
+        _call("avs_mask_plan_dev", seqs_dev, nseq, tmask_lo, tmask_hi, fmask, seed_dev, row_src, row_tok, src_row, mask_out, ids_out, _stream())
+        return
     _call("avs_mask_plan", seqs_dev, nseq, tmask_lo, tmask_hi, fmask, int(seed) & 0xFFFFFFFFFFFFFFFF, row_src, row_tok, src_row,
               mask_out, ids_out, _stream())
 
@@ -754,10 +759,16 @@ def cast_bf16(x, y, n):
     _call("avs_cast_bf16", x, y, n, _stream())
 
 
-def adam(p, g, m, v, p_bf16, n, lr, step, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=5e-7, grad_scale=1.0):
+def adam(p, g, m, v, p_bf16, n, lr, step, beta1=0.95, beta2=0.999, eps=1e-8, weight_decay=5e-7, grad_scale=1.0, step_dev=None):
+    """step_dev (int32 [1] device tensor): the step count is read from it when the kernel runs instead of `step` (graph_step)"""
     for t in (p, g, m, v):
         _chk(t, F32, "adam")
     _chk(p_bf16, BF16, "adam.p_bf16")
     assert n % 4 == 0 and all(t.numel() >= n for t in (p, g, m, v)) and (p_bf16 is None or p_bf16.numel() >= n)
+    if step_dev is not None:
+        assert step_dev.dtype == torch.int32 and step_dev.is_cuda and step_dev.numel() >= 1
+        _call("avs_adam_dev", p, g, m, v, p_bf16, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), step_dev,
+              float(grad_scale), _stream())
+        return
     _call("avs_adam", p, g, m, v, p_bf16, n, float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
               float(grad_scale), _stream())

@@ -208,34 +208,146 @@ def launch_ranks(n, argv, dry_run=False):
     CHILD process (never an exec: a process that touched the GPU must not be replaced, and this one stays the parent anyway), relays the
     child's stdout - rank 0's one JSON line - and returns the child's exit code (non-zero if any rank failed: torch.distributed.run
     propagates it).  The reference gets the same shape of launch from its shell script (run_pretrain_base.sh:75 torchrun -> env
-    RANK / WORLD_SIZE / LOCAL_RANK -> utils.py:283-299)."""
+    RANK / WORLD_SIZE / LOCAL_RANK -> utils.py:283-299).
+    The child runs in a process group of its own and never outlives this process: SIGTERM / SIGINT / SIGHUP received here are
+    forwarded to the whole group, and whatever ends the relay (an exception, the driver's timeout killing the parent's wait) terminates the
+    group - SIGTERM, ten seconds of grace, SIGKILL - so that no orphaned rank keeps a GPU for the next `--gpus N` run to collide with.  The
+    rendezvous port is taken by bind-and-close; should another process grab it before torchrun binds (the child then dies within seconds
+    without a line), the launch is repeated on a fresh port, twice at most."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as s:                    # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: without it RCCL's cross-process buffer sharing fails on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     argv = [a for a in argv if a != "--dry-run-launch"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+
+    def command():
+        with socket.socket() as s:                # a free rendezvous port on the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        return port, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                      "--master-port", str(port), os.path.abspath(__file__)] + argv
+
     if dry_run:
+        port, cmd = command()
         print(json.dumps({"launch": cmd, "ranks": n, "env": {k: env[k] for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")},
                           "parent_touched_gpu": bool(torch.cuda.is_initialized())}))
         return 0
-    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks as a child torch.distributed.run (port {port})", file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = []
-    for ln in child.stdout:
-        lines.append(ln)
-        sys.stdout.write(ln)
-        sys.stdout.flush()
-    rc = child.wait()
+
+    def stop(child, sig=signal.SIGTERM, grace=10.0):
+        """end the child's whole process group (torchrun + every rank)"""
+        if child.poll() is not None:
+            return
+        try:
+            os.killpg(child.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            child.wait(timeout=grace)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            child.wait()
+
+    rc = 1
+    for attempt in range(3):
+        port, cmd = command()
+        print(f"[bench] --gpus {n} without a launcher: starting {n} ranks as a child torch.distributed.run (port {port})", file=sys.stderr, flush=True)
+        t0 = time.time()
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        old = {}
+
+        def forward(signum, frame, child=child):
+            stop(child, signal.SIGTERM)
+            raise SystemExit(128 + signum)
+
+        for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            try:
+                old[sg] = signal.signal(sg, forward)
+            except ValueError:                    # not the main thread (a test harness): the finally below still cleans up
+                pass
+        lines = []
+        try:
+            for ln in child.stdout:
+                lines.append(ln)
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+            rc = child.wait()
+        finally:
+            stop(child)
+            for sg, h in old.items():
+                signal.signal(sg, h)
+        if rc != 0 and not lines and time.time() - t0 < 30.0 and attempt < 2:
+            print(f"[bench] the launcher exited with {rc} after {time.time() - t0:.0f} s without a line (rendezvous port {port} taken?): once more on a fresh port",
+                  file=sys.stderr, flush=True)
+            continue
+        break
     if rc == 0 and not any(ln.lstrip().startswith("{") for ln in lines):
         print("[bench] the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
         return 1
     return rc
+
+
+def secondary_shapes(args, dev):
+    """The reference's OWN pre-training shapes on the GPU, after the timed region: the reference trains on ONE frame per
+    clip (/root/reference/src/dataloader.py:471,519) at per-GPU batch 4 (egs/audioset/run_pretrain_base.sh:30-31); the headline workload
+    (10 frames, batch 64) is BASELINE.json's, not the reference's.  Same step (both passes, both Adam updates, device-drawn plans), same
+    kernels; `graph` = the step replayed from a captured hipGraph (avsiam_amd.graph_step.GraphedTrainStep) where the eager step is bound
+    by the host's launch rate.  The CPU legs of `cpu_baseline.survey_configs` time these same shapes on the host."""
+    import gc
+    from avsiam_amd.config import AVSiamConfig
+    from avsiam_amd.flops import gflop_per_sample
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.traintest_cavmae_base import train_step
+    from avsiam_amd.weights import synth_inputs
+    out = []
+    for label, kw, B in (("C2 under the reference's one-frame semantics: batch 64, 1 frame x196 + 512 audio tokens", {"frames": 1, "audio_tokens": 512}, 64),
+                         ("reference launch geometry: batch 4 per GPU, 1 frame x196 + 512 audio tokens (run_pretrain_base.sh:30-31)", {"frames": 1, "audio_tokens": 512}, 4),
+                         ("C1: BASELINE configs[0], batch 4, 1 frame x196 + 128 audio tokens", {"frames": 1, "audio_tokens": 128}, 4)):
+        cfg = AVSiamConfig(**kw)
+        try:
+            m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87).to(dev)
+            m.publish_grads = False
+            a, v = synth_inputs(cfg, B, 87)
+            a, v = a.to(dev), v.to(dev)
+            gf = gflop_per_sample(cfg, B)
+
+            def timed(step_fn, n):
+                for _ in range(3):
+                    step_fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    step_fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n
+
+            dt = timed(lambda: train_step(m, a, v, args.lr), args.secondary_steps)
+            rec = {"workload": label, "batch": B, "frames": 1, "audio_tokens": cfg.audio_tokens, "value": B / dt, "unit": "samples/s",
+                   "ms_per_step": 1e3 * dt, "gflop_per_sample": gf, "mfu": B / dt * gf / 1e3 / PEAK_BF16_TFLOPS, "steps": args.secondary_steps}
+            if B <= 8:
+                try:
+                    from avsiam_amd.graph_step import GraphedTrainStep
+                    gs = GraphedTrainStep(m, a, v, args.lr)
+                    dtg = timed(gs.step, args.secondary_steps)
+                    rec["graph"] = {"value": B / dtg, "ms_per_step": 1e3 * dtg, "mfu": B / dtg * gf / 1e3 / PEAK_BF16_TFLOPS,
+                                    "kernel_nodes": gs.kernel_nodes, "note": "the same step replayed from one captured hipGraph (plans still drawn per step: "
+                                    "seeds and Adam step counts live in device memory)"}
+                except Exception as e:                                  # a report, never a gate
+                    rec["graph"] = {"value": None, "error": repr(e)}
+            out.append(rec)
+            log(f"secondary [{label}]: {rec['value']:.1f} samples/s, {rec['ms_per_step']:.2f} ms/step" +
+                (f"; graph {rec['graph']['ms_per_step']:.2f} ms/step" if rec.get("graph", {}).get("value") else ""))
+        except Exception as e:
+            out.append({"workload": label, "value": None, "error": repr(e)})
+        finally:
+            m = a = v = None
+            gc.collect()
+            torch.cuda.empty_cache()
+    return out
 
 
 def log(msg):
@@ -273,6 +385,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=2, help="steps of the separate single-stream pass that times the other kernel families")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--secondary-steps", type=int, default=10, help="timed steps of each reference-native shape measured after the timed region "
+                    "(`secondary` in the line: one frame at batch 64, and BASELINE configs[0] = batch 4 / one frame / 128 audio tokens); 0 = skip")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="HIP-event timing of every kernel family (default: the dominant kernel, gemm_nt, only - each timed "
                          "launch costs the stream ~5 us)")
@@ -434,10 +548,23 @@ def main():
         torch.cuda.synchronize()
         prof2, ops.prof = ops.prof, None
         _eng.WGRAD_STREAM_MODE = mode
+    # per-rank times of the timed region (a straggler must be visible in the line): max = the metric's clock, min beside it
     tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
+    tmin = tmax.clone()
+    rank_ms = None
     if world > 1 or args.force_dp:
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+        every = [torch.zeros_like(tmax) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, tmax)
+        rank_ms = [round(1e3 * float(t.item()) / args.steps, 3) for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+    dt_min = float(tmin.item())
     dt = float(tmax.item())
+    secondary = None
+    if world == 1 and not args.force_dp and args.secondary_steps > 0 and args.model == "vit_base" and not (args.fp8 or args.recompute):
+        secondary = secondary_shapes(args, dev)
     losses = [float(x.item()) for x in last]
     if rank == 0:
         sps = world * args.batch * args.steps / dt
@@ -457,7 +584,8 @@ def main():
                           if world > 1 else {}), **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
                        **({"fp8_8bit_only_outputs": __import__("avsiam_amd.engine", fromlist=["FP8_LEAN"]).FP8_LEAN} if args.fp8_wgrad else {}),
                        "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-                       **({"share_pass_buffers": True} if args.share_pass_buffers else {}),
+                       **({"share_pass_buffers": True, "activation_pool_gib": round(model._pool.nbytes() / 2 ** 30, 2),
+                           "activation_pool_live_gib_last_pass": round(model._pool.used() / 2 ** 30, 2)} if args.share_pass_buffers and model._pool is not None else {}),
                        **({"rehearsal": "AVSIAM_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo + host-staged collectives - not a throughput figure"} if share else {}),
                        **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
                                         "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "defer_mae_only": os.environ.get("AVSIAM_DP_DEFER", "0"),
@@ -466,6 +594,11 @@ def main():
             "model_tflops": sps * gf / 1e3, "mfu_vs_dense_bf16_peak": sps * gf / 1e3 / (world * PEAK_BF16_TFLOPS),
             "final_losses": {"loss_mae": losses[0], "loss_mae_a": losses[1], "loss_mae_v": losses[2], "loss_c": losses[3], "c_acc": losses[4]},
         }
+        if rank_ms is not None:
+            line["ranks"] = {"world_size_of_group": dist.get_world_size(), "ms_per_step_by_rank": rank_ms,
+                             "ms_per_step_max": round(1e3 * dt / args.steps, 3), "ms_per_step_min": round(1e3 * dt_min / args.steps, 3)}
+        if secondary is not None:
+            line["secondary"] = secondary
         if prof is not None:
             s = prof.summary()
             mm = [k for k in s if k.startswith("gemm_nt") and k != "gemm_nt_fp8"]      # the bf16 launches (all of them without --fp8)

@@ -9,7 +9,9 @@
  *  - all pointers are DEVICE pointers; bf16 tensors are raw uint16_t bits; row-major; leading dimensions in elements
  *  - kernels are enqueued on `stream` and never synchronise, allocate or take ownership
  *  - return 0 on success, -1 runtime/launch error, -2 bad argument; avs_last_error() describes the failure
- *  - re-entrant per stream; the only global state is the thread-local error string
+ *  - re-entrant per stream.  Global state: the thread-local error string, and the process-wide TUNING KNOBS below (avs_tuning_set):
+ *    plain integers the launchers read; they are written only through this ABI (the host binding sets them once at load from the
+ *    AVSIAM_* environment - the library itself never reads the environment and initialises nothing lazily), before kernels are queued
  */
 #ifndef AVSIAM_HIP_H
 #define AVSIAM_HIP_H
@@ -25,6 +27,18 @@ typedef uint16_t avs_bf16;
 const char* avs_last_error(void);
 int avs_abi_version(void);
 int avs_device_cu_count(void);
+
+/* ---- tuning knobs (no reference counterpart: the reference leaves kernel selection to cuBLAS / cuDNN heuristics).  name:
+ *   "gemm_tile" 0 auto | 128 | 256          "gemm_persistent" 0 | 1          "gemm_nt8" 0 | 1 (8-phase 256^2 kernels)
+ *   "nt_tile_h" 0 auto | 256 | 224 | 240    "nt_grid" cap of the persistent nt grid, 0 = none
+ *   "cu_reserve" compute units EVERY persistent kernel (nt / fp8 nt / tn8 / tn8f grids and split factors) leaves free, a multiple of 8
+ *                keeps the XCDs balanced; 0 on one GPU, 8 when a gradient all-reduce overlaps the backward (src/traintest_cavmae_base.py:58-59
+ *                is DDP's overlap; RCCL's kernels need CUs WHILE a GEMM runs)
+ *   "ln_dma" 0 | 1    "ln_rpw" 0 auto | 4 | 8 | 16    "attn_ring" 0 | 1 (attention K/V tiles by LDS-DMA ring)
+ * avs_persistent_cu_slots(): the CUs a persistent grid fills now (device CUs - cu_reserve). */
+int avs_tuning_set(const char* name, int value);
+int avs_tuning_get(const char* name, int* value);
+int avs_persistent_cu_slots(void);
 
 /* ---- LayerNorm with per-row modality affine (Block.norm1/_a/_v, norm2/_a/_v: src/models/cav_mae_base.py:120-122,
  * 135-137,151-152,169-170,190-191; final norms :492,495,563,566,631).  x fp32 [rows,D] -> y bf16.  row_mod (0/1 per
@@ -226,6 +240,11 @@ int avs_im2col_video_xf(const void* v, const int* row_img, const int* row_tok, a
 int avs_mask_plan(const int* seqs, int nseq, const unsigned* tmask_lo, const unsigned* tmask_hi, const unsigned* fmask,
                   unsigned long long seed, int* row_src, int* row_tok, int* src_row, float* mask_out, int* ids_out,
                   avs_stream_t stream);
+/* the same with the Philox key in device memory, read when the kernel runs (a training step replayed from a captured hipGraph
+ * freezes kernel arguments; graph_step.GraphedTrainStep advances the key with a node of the graph) */
+int avs_mask_plan_dev(const int* seqs, int nseq, const unsigned* tmask_lo, const unsigned* tmask_hi, const unsigned* fmask,
+                      const unsigned long long* seed_dev, int* row_src, int* row_tok, int* src_row, float* mask_out, int* ids_out,
+                      avs_stream_t stream);
 int avs_cast_scale_bf16(const float* x, avs_bf16* y, long long n, float alpha, avs_stream_t stream);
 int avs_scatter_add_rows(const avs_bf16* src, const int* idx, float* dst, int rows, int D, float scale, avs_stream_t stream);
 /* out[c] += sum over rows of x[r][c], c < C (C % 64 == 0); ld: leading dimension of x (a column range of a wider matrix is allowed) */
@@ -293,6 +312,10 @@ int avs_transpose_batched(const long long* desc, const int* tile_map, int ntiles
 int avs_cast_bf16(const float* x, avs_bf16* y, long long n, avs_stream_t stream);
 int avs_adam(float* p, const float* g, float* m, float* v, avs_bf16* p_bf16, long long n, float lr, float beta1,
              float beta2, float eps, float weight_decay, int step, float grad_scale, avs_stream_t stream);
+/* the same update with the step count (>= 1, the count of THIS update) read from device memory when the kernel runs - for a step
+ * replayed from a captured hipGraph; bias corrections in double as above */
+int avs_adam_dev(float* p, const float* g, float* m, float* v, avs_bf16* p_bf16, long long n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, const int* step_dev, float grad_scale, avs_stream_t stream);
 
 /* ---- Collectives of the data-parallel path: thin wrappers over RCCL on a stream of the communicator's own, with event hand-off
  * (SURVEY.md 8(b)).  Replace, on the data path, torch.distributed's all_gather / all_reduce in GatherLayer

@@ -134,3 +134,27 @@ class _Waited:
 
     def wait(self):
         pass
+
+
+def correlated_av_batch(cfg, B, seed, rank=8, strength=2.0, shuffle_pairs=False):
+    """AudioSet-shaped synthetic pairs WITH audio<->visual correspondence (a contrastive objective can learn them; i.i.d. Gaussian inputs
+    - weights.synth_inputs - cannot be told apart after the token mean): every clip has a latent z ~ N(0, I_rank); its spectrogram is
+    noise + strength * sum_k z_k E_k with E_k a fixed spectral envelope (constant over time, so every audio token carries it), its frame(s)
+    noise + strength * sum_k z_k T_k with T_k a fixed 16 x 16 x 3 texture tiled over the image (so every visual token carries it).
+    The envelopes / textures depend only on `cfg`; `seed` draws z and the noise.  shuffle_pairs: the frames of clip i are paired with the
+    audio of another clip's latent - the SAME marginals without the correspondence (what a test that can fail is compared with).
+    -> a [B, audio_len, n_mels], v [B, (T,) 3, H, W] fp32."""
+    g0 = torch.Generator().manual_seed(1234567)
+    env = torch.randn(rank, cfg.n_mels, generator=g0)                                    # spectral envelopes
+    tex = torch.randn(rank, cfg.in_chans, cfg.patch, cfg.patch, generator=g0)          # textures
+    g = torch.Generator().manual_seed(1000 + int(seed))
+    z = torch.randn(B, rank, generator=g) / rank ** 0.5
+    zv = z[torch.randperm(B, generator=g)] if shuffle_pairs else z
+    a = torch.randn(B, cfg.audio_len, cfg.n_mels, generator=g) + strength * (z @ env)[:, None, :]
+    reps = cfg.img_size // cfg.patch
+    timg = (zv @ tex.reshape(rank, -1)).reshape(B, cfg.in_chans, cfg.patch, cfg.patch).repeat(1, 1, reps, reps)
+    if cfg.frames == 1:
+        v = torch.randn(B, cfg.in_chans, cfg.img_size, cfg.img_size, generator=g) + strength * timg
+    else:
+        v = torch.randn(B, cfg.frames, cfg.in_chans, cfg.img_size, cfg.img_size, generator=g) + strength * timg[:, None]
+    return a.contiguous(), v.contiguous()

@@ -44,3 +44,35 @@ def test_relay_passes_the_line_and_the_exit_code(tmp_path, monkeypatch):
     assert bench.launch_ranks(2, ["--gpus", "2"]) == 3
     fake.write_text("#!/bin/sh\nexit 0\n")                                    # clean exit without a line is still a failure
     assert bench.launch_ranks(2, ["--gpus", "2"]) == 1
+
+
+def test_a_killed_parent_takes_its_ranks_with_it(tmp_path):
+    """SIGTERM to `python bench.py --gpus N` (the driver's timeout) must not leave the torchrun child and its ranks behind.
+    A stand-in child that writes its pid and sleeps; the parent is terminated; the child must be gone within the grace period."""
+    import signal
+    import time
+    pidfile = tmp_path / "child.pid"
+    fake = tmp_path / "fake_python.sh"
+    fake.write_text(f"#!/bin/sh\necho $$ > {pidfile}\nsleep 300\n")
+    fake.chmod(0o755)
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; sys.executable = {str(fake)!r}; "
+            "raise SystemExit(bench.launch_ranks(2, ['--gpus', '2']))")
+    parent = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    for _ in range(600):
+        if pidfile.exists() and pidfile.read_text().strip():
+            break
+        time.sleep(0.1)
+    child_pid = int(pidfile.read_text())
+    os.kill(child_pid, 0)                                   # alive
+    parent.send_signal(signal.SIGTERM)
+    parent.wait(timeout=60)
+    assert parent.returncode == 128 + signal.SIGTERM
+    for _ in range(150):
+        try:
+            os.kill(child_pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        os.kill(child_pid, signal.SIGKILL)
+        raise AssertionError("the launcher's child outlived the parent")

@@ -46,10 +46,13 @@ def _run(m, a, v, plan, which):
     return out, m.arena.g[lo:hi].clone()
 
 
-def _same_direction(g, r, cos_min=0.99999, ratio_tol=1e-3):
+def _same_direction(g, r, cos_min=0.99999, ratio_tol=1e-3, tag=None):
     g, r = g.double(), r.double()
     cos = float(torch.dot(g, r) / (g.norm() * r.norm()))
     ratio = float(g.norm() / r.norm())
+    if tag:
+        from tests.helpers import record_margin
+        record_margin(tag, grad_cos=cos, grad_norm_ratio=ratio)
     assert cos >= cos_min and abs(ratio - 1) <= ratio_tol, (cos, ratio)
 
 
@@ -68,7 +71,7 @@ def test_mae_full_batch_equals_mean_of_halves(setup):
     for i in (1, 2, 3):                                   # loss_mae, loss_mae_a, loss_mae_v
         mean = 0.5 * (halves[0][0][i].item() + halves[1][0][i].item())
         assert abs(out[i].item() - mean) <= 1e-5 * abs(mean), (i, out[i].item(), mean)
-    _same_direction(g, 0.5 * (halves[0][1] + halves[1][1]))
+    _same_direction(g, 0.5 * (halves[0][1] + halves[1][1]), tag="vit_base_fullsize_mae_halves")
 
 
 def test_contrastive_full_batch_is_order_invariant(setup):
@@ -83,7 +86,7 @@ def test_contrastive_full_batch_is_order_invariant(setup):
     assert abs(out_p[4].item() - out[4].item()) <= 1e-5 * abs(out[4].item())
     assert out_p[7].item() == out[7].item()
     assert 0.0 <= out[7].item() <= 1.0
-    _same_direction(g_p, g)
+    _same_direction(g_p, g, tag="vit_base_fullsize_contrastive_order")
 
 
 @pytest.mark.parametrize("which", [P2, P1])

@@ -90,11 +90,24 @@ def test_vit_large_full_size_contrastive_is_order_invariant():
         plan_p = ContrastivePlan(plan.a_group[perm], plan.v_group[perm], [plan.a_keep[i] for i in pl], [plan.v_keep[i] for i in pl])
         dperm = perm.cuda()
         out_p, g_p = _run(m, a[dperm].contiguous(), v[dperm].contiguous(), plan_p, P1)
+        out_r, g_r = _run(m, a, v, plan, P1)             # the SAME batch once more: the run-to-run floor (order of the fp32 atomics)
         assert math.isfinite(out[4].item()) and 0.0 <= out[7].item() <= 1.0
         assert abs(out_p[4].item() - out[4].item()) <= 1e-5 * abs(out[4].item()), (out_p[4].item(), out[4].item())
         assert out_p[7].item() == out[7].item()
-        _same_direction(g_p, g)
-        del m, g, g_p
+
+        def cos_ratio(x, y):
+            x, y = x.double(), y.double()
+            return float(torch.dot(x, y) / (x.norm() * y.norm())), float(x.norm() / y.norm())
+        (c_p, r_p), (c_r, r_r) = cos_ratio(g_p, g), cos_ratio(g_r, g)
+        record_margin("vit_large_fullsize_contrastive_order", loss_rel=abs(out_p[4].item() - out[4].item()) / abs(out[4].item()),
+                      grad_cos_permuted=c_p, grad_norm_ratio_permuted=r_p, grad_cos_rerun=c_r, grad_norm_ratio_rerun=r_r)
+        # Measured (profiles/r05/parity_margins.json): the loss is bitwise equal and the SAME batch run twice gives the same gradient
+        # (cosine 1.0), the permuted batch 0.999987 (ViT-B: 0.999992).  At a random start the contrastive gradients cancel across the
+        # samples (uniform softmax: sum_i dL/drep_i = 0), a weight gradient is ~1 % of its un-cancelled terms, and the order in which
+        # the weight-gradient GEMM sums the 95 630 token rows in fp32 - the one thing the permutation changes - shows at ~5e-3
+        # relative.  Stated tolerance: 3x the measured gap.
+        _same_direction(g_p, g, cos_min=0.99996, ratio_tol=2e-3)
+        del m, g, g_p, g_r
     finally:
         gc.collect(); torch.cuda.empty_cache()
 
@@ -106,9 +119,9 @@ def test_vit_large_full_size_contrastive_is_order_invariant():
 # (2) the MAE pass over 64 clips equals the mean of its two 32-clip halves run with the same per-clip plans.  In bf16 that holds to fp32
 #     summation order (1e-5); in fp8 every quantised tensor of the 32-clip engines carries its OWN delayed scale (amax over other rows),
 #     so the operands round on slightly different grids: the stated tolerance is the fp8 noise, at ~3x the measurement
-#     (profiles/r05/parity_margins.json, vit_huge14_fp8_fullsize): loss rel 3e-3, whole flat gradient cosine >= 0.99, norm within 5 %.
+#     (profiles/r05/parity_margins.json, vit_huge14_fp8_fullsize): loss rel 1e-3, whole flat gradient cosine >= 0.997, norm within 1 %.
 #     An indexing error at these sizes (row offsets beyond 2^31 bytes, pool aliasing) gives cosines near 0, far outside.
-FP8_FULL_LOSS_RTOL, FP8_FULL_COS_MIN, FP8_FULL_RATIO_TOL = 3e-3, 0.99, 0.05
+FP8_FULL_LOSS_RTOL, FP8_FULL_COS_MIN, FP8_FULL_RATIO_TOL = 1e-3, 0.997, 0.01     # measured: 1.2e-4, 0.99903, 0.27 %
 
 
 def test_vit_huge14_fp8_mode3_full_size_trains_and_mae_equals_mean_of_halves():

@@ -52,13 +52,18 @@ def _oracle(cfg, a, v, plan, mae, seed=1234, mode="random"):
 MATRIX_NUMEL = 1 << 16       # "matrix" tensors (Linear / patch-embedding weights, position tables) vs "vector" tensors (biases, LayerNorm)
 
 
-def _compare_grads(model, ref_grads, cos_min=0.9998, ratio_tol=0.01, tag=None, whole_cos_min=None, matrix_cos_min=None):
-    """matrix_cos_min: a tighter cosine floor for the tensors of at least MATRIX_NUMEL elements (the fp8 modes: a weight-gradient
-    element sums over every token row and a matrix has 10^5 - 10^7 of them, so its direction is far better determined than that of a
-    1280-element bias at batch 2, which sets `cos_min`)."""
+def _compare_grads(model, ref_grads, cos_min=0.9998, ratio_tol=0.01, tag=None, whole_cos_min=None, matrix_cos_min=None, matrix_ratio_tol=None):
+    """Every live tensor against the oracle's: cosine >= cos_min and norm within ratio_tol; the whole live gradient as one vector >=
+    whole_cos_min.  matrix_cos_min / matrix_ratio_tol: tighter bounds for the tensors of at least MATRIX_NUMEL elements (the fp8 modes:
+    a weight-gradient element sums over every token row and a matrix has 10^5 - 10^7 of them, so its direction and length are far
+    better determined than those of a 1280-element bias at batch 2, which set `cos_min` / `ratio_tol`).
+    All statistics are gathered (and recorded: tests.helpers.record_margin) BEFORE anything is asserted, so a failing run still says
+    what the worst tensors were."""
     worst = (1.0, None)
     worst_mat = (1.0, None)
     worst_ratio = (0.0, None)
+    worst_mat_ratio = (0.0, None)
+    bad = []
     dot = ng = nr = 0.0                    # the whole live gradient as one vector
     for info in build_spec(model.cfg):
         p = model._params[info.name]
@@ -75,12 +80,16 @@ def _compare_grads(model, ref_grads, cos_min=0.9998, ratio_tol=0.01, tag=None, w
         cos = float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-30))
         ratio = float(g.norm() / r.norm())
         dot, ng, nr = dot + float(torch.dot(g, r)), ng + float(g.norm()) ** 2, nr + float(r.norm()) ** 2
-        assert cos >= cos_min, (info.name, cos, ratio)
-        assert abs(ratio - 1) <= ratio_tol, (info.name, cos, ratio)
-        if g.numel() >= MATRIX_NUMEL:
-            assert matrix_cos_min is None or cos >= matrix_cos_min, (info.name, cos, ratio)
+        mat = g.numel() >= MATRIX_NUMEL
+        if not (cos >= cos_min and abs(ratio - 1) <= ratio_tol):
+            bad.append((info.name, cos, ratio))
+        if mat:
+            if not ((matrix_cos_min is None or cos >= matrix_cos_min) and (matrix_ratio_tol is None or abs(ratio - 1) <= matrix_ratio_tol)):
+                bad.append((info.name, cos, ratio, "matrix"))
             if cos < worst_mat[0]:
                 worst_mat = (cos, info.name)
+            if abs(ratio - 1) > worst_mat_ratio[0]:
+                worst_mat_ratio = (abs(ratio - 1), info.name)
         if cos < worst[0]:
             worst = (cos, info.name)
         if abs(ratio - 1) > worst_ratio[0]:
@@ -88,7 +97,9 @@ def _compare_grads(model, ref_grads, cos_min=0.9998, ratio_tol=0.01, tag=None, w
     whole = dot / ((ng * nr) ** 0.5 + 1e-30)
     if tag:
         record_margin(tag, worst_cos=worst[0], worst_cos_tensor=worst[1], worst_norm_ratio_err=worst_ratio[0], worst_norm_tensor=worst_ratio[1],
-                      whole_gradient_cos=whole, worst_matrix_cos=worst_mat[0], worst_matrix_tensor=worst_mat[1])
+                      whole_gradient_cos=whole, worst_matrix_cos=worst_mat[0], worst_matrix_tensor=worst_mat[1],
+                      worst_matrix_norm_ratio_err=worst_mat_ratio[0], worst_matrix_norm_tensor=worst_mat_ratio[1])
+    assert not bad, (tag, bad[:8], len(bad))
     assert whole_cos_min is None or whole >= whole_cos_min, whole
     return worst
 
@@ -499,8 +510,12 @@ def test_vit_huge14_device_drawn_plan():
 # residual-GRADIENT stream rounds 2 x depth times along a stack, and the fp8 operands' rounding accumulates
 # over 32 blocks in the forward and again in the backward.  Tolerances at ~3x the measurement (profiles/r05/parity_margins.json,
 # vit_huge14_depth32_*): stated next to each assert.
-D32_BF16_COS_MIN, D32_BF16_RATIO_TOL = 0.9990, 0.03
-D32_FP8_LOSS_RTOL, D32_FP8_LOGITS_ATOL = 1e-2, 0.12
+D32_BF16_COS_MIN, D32_BF16_RATIO_TOL = 0.9995, 0.03        # measured: worst tensor 0.99984 (a 1280-element LayerNorm bias), norm 1.1 %
+D32_FP8_LOSS_RTOL, D32_FP8_LOGITS_ATOL = 7e-3, 0.14         # measured: 2.2e-3, 0.045
+# fp8 mode 3 at depth 32, batch 2: the VECTOR tensors of the contrastive pass (2 x 2 logits, 1280-element biases 30 layers from the loss)
+# carry most of the noise - every tensor cosine >= 0.60 / norm within 50 % (measured 0.817 / 31 %), the MATRICES cosine >= 0.93 / norm
+# within 15 % (measured >= 0.978 / <= 4.3 % in the MAE pass), the whole gradient >= 0.985 (measured 0.9928)
+D32_FP8_COS_MIN, D32_FP8_RATIO_TOL, D32_FP8_MATRIX_COS_MIN, D32_FP8_MATRIX_RATIO_TOL = 0.60, 0.50, 0.93, 0.15
 
 
 def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():
@@ -538,6 +553,8 @@ def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():
                 mae = which == "mae"
                 ref, logits, rgrads = refs[which]
                 for step in ((0,) if mode == "0" else (0, 1)):       # fp8: the calibration step and the step on delayed scales
+                    for p in m._params.values():                     # (.grad views of the arena outlive a pass: the other pass's are not this one's)
+                        p.grad = None
                     out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
                     out[0].backward()
                     torch.cuda.synchronize()
@@ -552,8 +569,8 @@ def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():
                     if mode == "0":
                         _compare_grads(m, rgrads, cos_min=D32_BF16_COS_MIN, ratio_tol=D32_BF16_RATIO_TOL, tag=tag)
                     else:
-                        _compare_grads(m, rgrads, cos_min=FP8W_COS_MIN, ratio_tol=FP8W_RATIO_TOL, tag=tag, whole_cos_min=FP8W_WHOLE_COS,
-                                       matrix_cos_min=FP8W_MATRIX_COS_MIN)
+                        _compare_grads(m, rgrads, cos_min=D32_FP8_COS_MIN, ratio_tol=D32_FP8_RATIO_TOL, tag=tag, whole_cos_min=FP8W_WHOLE_COS,
+                                       matrix_cos_min=D32_FP8_MATRIX_COS_MIN, matrix_ratio_tol=D32_FP8_MATRIX_RATIO_TOL)
             if mode == "3":
                 assert m.fp8_saturation_events() == 0
     finally:

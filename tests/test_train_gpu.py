@@ -178,3 +178,99 @@ def test_shared_activation_pool_is_the_same_training(mode):
         assert mem1 < 0.8 * mem0, (mem0, mem1)                    # the passes' buffers: the larger pass (+ chunk slack) instead of the sum
     finally:
         engine.FP8 = "0"
+
+
+@pytest.mark.parametrize("mode", ["0", "3"])
+def test_contrastive_training_learns_an_audio_visual_correspondence(mode):
+    """End-to-end learning evidence for the contrastive branch (with i.i.d. Gaussian clips loss_c sits at ln B whatever the
+    step does - the token mean erases what tells them apart).  Clips with a REAL correspondence (tests.helpers.correlated_av_batch: a shared
+    latent drives a spectral envelope and a frame texture), a FRESH batch of 16 every step, 40 reference steps
+    (/root/reference/src/traintest_cavmae_base.py:131-152) in bf16 and in fp8 mode 3: the InfoNCE loss must fall below 0.8 ln B and the
+    retrieval accuracy must reach 4 / B at least (mean of the last 5 steps; the CPU oracle driven by torch.optim.Adam on the same data
+    reaches loss_c ~0.2 / c_acc ~0.9, tools/train_sanity.py --oracle).  The control - same marginals, frames paired with ANOTHER clip's audio
+    latent - must NOT: a step that ignored its inputs, or a broken gradient, fails one of the two."""
+    import math
+    from avsiam_amd import engine
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.traintest_cavmae_base import train_step
+    from tests.helpers import correlated_av_batch, record_margin
+    cfg = AVSiamConfig(audio_tokens=128, frames=1)
+    B, steps = 16, 40
+    old = engine.FP8
+    engine.FP8 = mode
+    try:
+        res = {}
+        for shuffled in (False, True):
+            m = CAVMAE_BASE(cfg=cfg, init_seed=0, init_mode="init", verbose=False, plan_seed=3).cuda()
+            m.publish_grads = False
+            hist = []
+            for step in range(steps):
+                a, v = correlated_av_batch(cfg, B, seed=step, shuffle_pairs=shuffled)
+                out = train_step(m, a.cuda(), v.cuda(), 2e-4)
+                hist.append([float(x.item()) for x in out])
+            assert all(x == x and abs(x) < 1e4 for h in hist for x in h), hist
+            res[shuffled] = (sum(h[3] for h in hist[-5:]) / 5, sum(h[4] for h in hist[-5:]) / 5, hist[0][3], hist[0][0], hist[-1][0])
+            if mode == "3":
+                assert m.fp8_saturation_events() <= 4
+            del m
+        (lc, acc, lc0, lm0, lm1), (lc_s, acc_s, _, _, _) = res[False], res[True]
+        record_margin(f"train_sanity_correlated_{'bf16' if mode == '0' else 'fp8m3'}", loss_c_first=lc0, loss_c_last5=lc, c_acc_last5=acc,
+                      loss_c_last5_shuffled_control=lc_s, c_acc_last5_shuffled_control=acc_s, loss_mae_first=lm0, loss_mae_last=lm1, ln_B=math.log(B))
+        assert lc < 0.8 * math.log(B) and acc >= 4.0 / B, (lc, acc)
+        assert lm1 < lm0, (lm0, lm1)                                        # the MAE branch learns too (every frame carries the tiled texture)
+        assert not (lc_s < 0.8 * math.log(B) and acc_s >= 4.0 / B), ("the control learned a correspondence that is not there", lc_s, acc_s)
+    finally:
+        engine.FP8 = old
+
+
+def test_graphed_step_equals_the_eager_step():
+    """graph_step.GraphedTrainStep at the reference's launch geometry (batch 4, one frame: run_pretrain_base.sh:30-31): the step replayed
+    from one captured hipGraph draws the same plans (device-resident Philox key, host part in front of the replay), applies the same
+    Adam updates (device-resident step count) and returns the same losses as the eager step - two models from the same seeds, one
+    stepped eagerly, one replayed; then eager and replayed steps mixed on one model."""
+    from avsiam_amd.graph_step import GraphedTrainStep
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.param_spec import P1, P2
+    from avsiam_amd.traintest_cavmae_base import train_step
+    cfg = AVSiamConfig(audio_tokens=128, frames=1)
+    B = 4
+    a, v = synth_inputs(cfg, B, 11)
+    a, v = a.cuda(), v.cuda()
+
+    def fresh():
+        m = CAVMAE_BASE(cfg=cfg, init_seed=2, init_mode="random", verbose=False, plan_seed=21).cuda()
+        m.publish_grads = False
+        return m
+
+    def plans_equal(x, y):
+        px, py = x.last_plans(B), y.last_plans(B)
+        assert torch.equal(px["mae"].ids_keep_a, py["mae"].ids_keep_a) and torch.equal(px["mae"].ids_keep_v, py["mae"].ids_keep_v)
+        assert torch.equal(px["contrastive"].a_group, py["contrastive"].a_group) and torch.equal(px["contrastive"].v_group, py["contrastive"].v_group)
+        assert all(torch.equal(p, q) for p, q in zip(px["contrastive"].a_keep, py["contrastive"].a_keep))
+
+    me, mg = fresh(), fresh()
+    for _ in range(2):
+        train_step(me, a, v, 2e-4)
+    gs = GraphedTrainStep(mg, a, v, 2e-4, warmup=2)
+    assert gs.kernel_nodes > 300
+    for i in range(3):
+        oe = [float(x.item()) for x in train_step(me, a, v, 2e-4)]
+        og = [float(x.item()) for x in gs.step()]
+        plans_equal(me, mg)
+        for x, y in zip(oe, og):
+            assert abs(x - y) <= 2e-3 * abs(x) + 1e-6, (i, oe, og)          # (bitwise but for the order of the fp32 atomics feeding Adam's sign)
+    assert me._opt_state[P1]["step"] == mg._opt_state[P1]["step"] == 5 and me._opt_state[P2]["step"] == mg._opt_state[P2]["step"] == 5
+    rel = float((me.arena.p - mg.arena.p).double().norm() / me.arena.p.double().norm())
+    assert rel < 1e-4, rel
+    # mixed: an eager step on the graphed model, then a replay - the counters are re-written from the host state in front of every replay
+    train_step(me, a, v, 2e-4); train_step(mg, a, v, 2e-4)
+    oe = [float(x.item()) for x in train_step(me, a, v, 2e-4)]
+    og = [float(x.item()) for x in gs.step()]
+    plans_equal(me, mg)
+    assert all(abs(x - y) <= 2e-3 * abs(x) + 1e-6 for x, y in zip(oe, og)), (oe, og)
+    # a new batch is a copy into the fixed buffers
+    a2, v2 = synth_inputs(cfg, B, 12)
+    a.copy_(a2.cuda()); v.copy_(v2.cuda())
+    oe = [float(x.item()) for x in train_step(me, a, v, 2e-4)]
+    og = [float(x.item()) for x in gs.step()]
+    assert all(abs(x - y) <= 2e-3 * abs(x) + 1e-6 for x, y in zip(oe, og)), (oe, og)
