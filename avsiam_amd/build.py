@@ -21,6 +21,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-ato
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
+# per-source flags.  attention.hip: no SLP vectorisation - packed fp32 arithmetic (v_pk_add_f32 ...) is an anti-lever beside MFMAs (see the file)
+FLAGS_FOR = {"attention.hip": ["-fno-slp-vectorize"]}
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -47,7 +51,7 @@ def build(force=False, verbose=True, out=None):
         o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + FLAGS_FOR.get(src, []) + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

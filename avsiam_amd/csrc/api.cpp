@@ -31,7 +31,7 @@ extern "C" int avs_device_cu_count(void) {
 // avs_tuning_set (the host binding calls it once per knob at load, from the AVSIAM_* environment) before kernels are queued; launchers
 // read them, nothing is initialised lazily and nothing reads the environment.
 static AvsTuning g_tuning = {/*gemm_tile*/ 0, /*gemm_persistent*/ 1, /*gemm_nt8*/ 1, /*nt_tile_h*/ 0, /*nt_grid*/ 0, /*cu_reserve*/ 0,
-                             /*ln_dma*/ 1, /*ln_rpw*/ 0, /*attn_ring*/ 1};
+                             /*ln_dma*/ 1, /*ln_rpw*/ 0, /*attn_ring*/ 0};      // (attn_ring: measured neutral to slower in round 5 - DESIGN.md 5e - so off by default)
 AvsTuning& avs_tuning() { return g_tuning; }
 
 int avs_persistent_slots() {

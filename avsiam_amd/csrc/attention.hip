@@ -197,6 +197,14 @@ __device__ __forceinline__ void store_block(bf16_t* rowp, int d, int hh, const f
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// Packed fp32 (v_pk_add_f32 / v_pk_mul_f32) must stay out of these loops: beside MFMAs a packed fp32 instruction costs the SIMD's issue port
+// about twice a plain one, and under -O3 hipcc's SLP vectoriser packs adjacent scalar adds / subs / muls (round 5: the 16 v_pk_add_f32 of a
+// 64-key tile's row sum).  This file is therefore compiled with -fno-slp-vectorize (avsiam_amd/build.py) and the arithmetic is written
+// scalar.  NOT by inline asm: an asm v_add / v_mul that reads a v_exp or MFMA result hides the producer -> consumer wait states from hipcc's
+// hazard recogniser (tried first: NaNs and wrong sums on hardware).
+__device__ __forceinline__ float add1(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub1(float a, float b) { return a - b; }
+__device__ __forceinline__ float mul1(float a, float b) { return a * b; }
 constexpr float LN2 = 0.6931471805599453f;
 
 struct AttnArgs {
@@ -325,17 +333,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         float psum;
         float p[2][16];
         auto exp_tile = [&]() {
-            // pairs are summed with v_pk_add_f32 (two scores per VALU slot)
-            f32x2 ps = {0.f, 0.f};
+            // two running sums (even / odd scores: the order the packed adds of rounds 1 - 4 summed in, bit for bit) with PLAIN adds - add1
+            float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     p[kb][r] = fast_exp2(s[kb][r]);
                     p[kb][r + 1] = fast_exp2(s[kb][r + 1]);
-                    ps += f32x2{p[kb][r], p[kb][r + 1]};
+                    ps0 = add1(ps0, p[kb][r]);
+                    ps1 = add1(ps1, p[kb][r + 1]);
                 }
-            psum = ps[0] + ps[1];
+            psum = ps0 + ps1;
         };
         exp_tile();
         if (k0 != 0 && __any(!(psum < LAZY_SUM))) {
@@ -396,6 +405,315 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
         uint8_t* orow8 = a.out8 ? a.out8 + (size_t)(seq0 + qq) * a.ldo8 + head * HG : nullptr;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) store_block<HG, false>(orow, d, hh, o[d], inv, orow8, q8s, omax);      // (columns of the image beyond the real head dim are skipped)
+        if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    }
+    if (a.out8) q_amax_update(a.q8, omax, q8seen);
+}
+
+// ===================================================================================================
+// LDS-DMA ring variants (round 5).  The kernels above stage a 64-row tile global -> VGPR -> ds_write_b128 with two barriers per tile.
+// Here the tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, no staging registers, no ds_write) into a ring of NS slots; ONE
+// barrier per tile:
+//     iteration t:  wait until this wave's DMAs of tile t have landed (counted vmcnt: the tiles behind it stay in flight)
+//                   s_barrier                      every wave's share of tile t has landed AND every wave is done reading tile t - 1
+//                   DMA of tile t + NS - 1         into the slot tile t - 1 occupied
+//                   compute on tile t
+// The LDS image of a tile is the one the register-staged kernels write (Img<HD>: 8-row x 32-column sub-tiles, chunk XOR (row>>2)&3), so
+// the fragment addressing - and therefore every product, in the same order - is unchanged: results are BITWISE those of the kernels above
+// (tests/test_kernels_gpu.py::test_attention_ring_kernels_match_the_register_staged_ones).  An LDS-DMA writes wave-uniform base + 16 x lane,
+// so the image's permutation is applied to the per-lane SOURCE address: LDS chunk i of an image holds (row, chunk) = RingOff::rc(i).
+// Every LDS read is inline asm: to hipcc an LDS-DMA in flight is an LDS store it cannot disambiguate, and a compiler-visible ds_read
+// behind it gets s_waitcnt vmcnt(0) - the ring would drain at every tile (the same reason as in gemm.hip).  Completion of the reads is
+// waited for by hand (lds_wait: s_waitcnt lgkmcnt(0) + sched_barrier, so no MFMA is hoisted above the wait).
+#define GLOBAL_AS __attribute__((address_space(1)))
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {          // counted wait on the vector-memory queue as a REAL s_waitcnt (see gemm.hip wait_vm)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void ring_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_r128(bf16x8& v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_tr64(bf16x4& v, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// per-thread source offsets (bytes from the tile's first row) of the chunks this thread's DMA instructions fetch for one [64][HD] image
+template <int HD, int NTH>
+struct RingOff {
+    static constexpr int NSUB = HD / 32;
+    static constexpr int NCHUNK = 64 * HD / 8;
+    static constexpr int PER = NCHUNK / NTH;
+    static_assert(NCHUNK % NTH == 0 && (NSUB == 1 || NSUB == 2), "ring: HD 32 / 64");
+    unsigned o[PER];
+    // LDS chunk index i of the image -> (row, 16-byte chunk of the row) it holds: the inverse of Img<HD>::off / 16
+    __device__ static __forceinline__ void rc(int i, int& row, int& ch) {
+        const int blk = i / (32 * NSUB), within = i % (32 * NSUB);
+        row = blk * 8 + ((within % 32) >> 2);
+        ch = (within / 32) * 4 + ((i & 3) ^ ((row >> 2) & 3));
+    }
+    __device__ __forceinline__ void init(long long ld, int tid) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            int row, ch;
+            rc(j * NTH + tid, row, ch);
+            o[j] = ((unsigned)row * (unsigned)ld + (unsigned)ch * 8u) * 2u;
+        }
+    }
+};
+
+// request the [64][HD] image of rows row0 .. row0 + 63 of `src` (clamped to last_row: a sequence's last, partial tile) into `img`
+template <int HD, int NTH>
+__device__ __forceinline__ void ring_issue(const RingOff<HD, NTH>& ro, const bf16_t* src, long long ld, int row0, int last_row, char* img, int tid) {
+    const char* base = reinterpret_cast<const char*>(src + (size_t)row0 * ld);        // wave-uniform
+    const int wave = tid >> 6;
+    unsigned off[RingOff<HD, NTH>::PER];
+#pragma unroll
+    for (int j = 0; j < RingOff<HD, NTH>::PER; ++j) off[j] = ro.o[j];
+    if (row0 + 63 > last_row) {                                // block-uniform
+        asm volatile("; partial tile: clamp rows" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < RingOff<HD, NTH>::PER; ++j) {
+            int row, ch;
+            RingOff<HD, NTH>::rc(j * NTH + tid, row, ch);
+            off[j] = ((unsigned)min(row, last_row - row0) * (unsigned)ld + (unsigned)ch * 8u) * 2u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RingOff<HD, NTH>::PER; ++j)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + off[j]), (LDS_AS void*)(img + (j * NTH + wave * 64) * 16), 16, 0, 0);
+}
+
+// lane-dependent parts of the fragment addresses inside an image (the row-block / sub-tile parts are immediates of the reads):
+//   row fragment (A operand by rows), k-step kk, row block rb (32 rows):  rk[kk & 1] + 2048 NSUB rb + 512 (kk >> 1)
+//   transposed fragment of rows 16 m .. 16 m + 15, 32-column block db:    lo: tv[0] + 1024 NSUB m + 512 db;  hi: tv[1] + 1024 NSUB m + 512 NSUB + 512 db
+template <int HD>
+struct FragAddr {
+    unsigned rk[2], tv[2];
+    __device__ __forceinline__ void init(int lane) {
+        const int r = lane & 31, hh = lane >> 5;
+        rk[0] = (unsigned)Img<HD>::off(r, hh);
+        rk[1] = (unsigned)Img<HD>::off(r, 2 + hh);
+        const int cb = (lane >> 4) & 1, li = lane & 15, q = li >> 2, p4 = li & 3;
+        const int ch = 2 * cb + (p4 >> 1);
+        tv[0] = (unsigned)(Img<HD>::off(4 * hh + q, ch) + 8 * (p4 & 1));
+        tv[1] = (unsigned)(Img<HD>::off(8 + 4 * hh + q, ch) + 8 * (p4 & 1)) - 512u * (HD / 32);
+    }
+};
+
+template <int HD, int RB, int KK>
+__device__ __forceinline__ void ring_row_frag(bf16x8& v, unsigned img, const FragAddr<HD>& fa) {
+    lds_r128<2048 * (HD / 32) * RB + 512 * (KK >> 1)>(v, img + fa.rk[KK & 1]);
+}
+template <int HD, int M16, int DB>
+__device__ __forceinline__ void ring_tr_frag(bf16x4& lo, bf16x4& hi, unsigned img, const FragAddr<HD>& fa) {
+    lds_tr64<1024 * (HD / 32) * M16 + 512 * DB>(lo, img + fa.tv[0]);
+    lds_tr64<1024 * (HD / 32) * M16 + 512 * (HD / 32) + 512 * DB>(hi, img + fa.tv[1]);
+}
+__device__ __forceinline__ bf16x8 join8(const bf16x4& lo, const bf16x4& hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; }
+
+template <int HD, int NW, int NS>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && HD == 32) ? 4 : (NW == 4 && HD == 64) ? 3 : 1) void attn_fwd_ring_kernel(AttnArgs a) {
+    constexpr int NTH = 64 * NW;
+    constexpr int NKK = HD / 16, NDB = HD / 32;
+    constexpr int IMG = 64 * HD * 2, SLOT = 2 * IMG;        // a slot: the K image, then the V image of one 64-key tile
+    constexpr int DPT = 2 * RingOff<HD, NTH>::PER;          // DMA instructions per thread and tile
+    static_assert(NS >= 2 && NS <= 4 && (NS - 2) * DPT <= 63, "ring depth");
+    __shared__ __attribute__((aligned(16))) char smem[NS * SLOT];
+    const unsigned smem_lds = (unsigned)(size_t)(LDS_AS const char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const float q8s = a.out8 ? a.q8[AVS_Q_SCALE] : 0.f;
+    const float q8seen = q_amax_peek(a.out8 ? a.q8 : nullptr);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = lid / a.ntiles, tix = lid - head * a.ntiles;
+    const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int qw = a.tile_q0[tix] + 32 * wave;          // first query of this wave
+    const bool active = qw < L;
+    const int q = min(qw + (lane & 31), L - 1);
+    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
+
+    RingOff<HD, NTH> ro;
+    ro.init(a.ld, tid);
+    const int ntile = (L + 63) >> 6;
+    auto issue = [&](int t, int slot) {
+        ring_issue<HD, NTH>(ro, base + a.D, a.ld, 64 * t, L - 1, smem + slot * SLOT, tid);
+        ring_issue<HD, NTH>(ro, base + 2 * a.D, a.ld, 64 * t, L - 1, smem + slot * SLOT + IMG, tid);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < ntile) issue(t, t);
+
+    bf16x8 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * a.ld + (2 * kk + hh) * 8);
+    FragAddr<HD> fa;
+    fa.init(lane);
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    constexpr float LAZY_SUM = 1099511627776.0f;         // (see attn_fwd_kernel)
+    float m_run = 0.f, l_run = 0.f;
+    f32x16 negm = splat16(0.f);
+
+    int slot = 0;
+    for (int t = 0; t < ntile; ++t) {
+        // this wave's DMAs of tile t have landed; the tiles requested behind it (at most NS - 2, fewer at the end) stay in flight
+        const int ahead = min(NS - 2, ntile - 1 - t);
+        if (NS >= 4 && ahead == 2) wait_vm<2 * DPT>();
+        else if (NS >= 3 && ahead >= 1) wait_vm<DPT>();
+        else wait_vm<0>();
+        ring_barrier();
+        if (t + NS - 1 < ntile) issue(t + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+        const unsigned sK = smem_lds + slot * SLOT, sV = sK + IMG;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        if (!active) continue;
+        const int k0 = 64 * t;
+        bf16x8 kf[2][NKK];
+        auto read_k = [&]() {
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                if (kk == 0) { ring_row_frag<HD, 0, 0>(kf[0][0], sK, fa); ring_row_frag<HD, 1, 0>(kf[1][0], sK, fa); }
+                if (kk == 1) { ring_row_frag<HD, 0, 1>(kf[0][1], sK, fa); ring_row_frag<HD, 1, 1>(kf[1][1], sK, fa); }
+                if constexpr (NKK > 2) {
+                    if (kk == 2) { ring_row_frag<HD, 0, 2>(kf[0][2], sK, fa); ring_row_frag<HD, 1, 2>(kf[1][2], sK, fa); }
+                    if (kk == 3) { ring_row_frag<HD, 0, 3>(kf[0][3], sK, fa); ring_row_frag<HD, 1, 3>(kf[1][3], sK, fa); }
+                }
+            }
+            lds_wait();
+        };
+        f32x16 s[2];
+        auto scores = [&]() {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][0], qf[0], negm, 0, 0, 0);
+#pragma unroll
+                for (int kk = 1; kk < NKK; ++kk) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][kk], qf[kk], s[kb], 0, 0, 0);
+            }
+        };
+        read_k();
+        scores();
+        // the V fragments of the first 32 keys are requested now and land under the softmax arithmetic; those of the other 32 are requested
+        // when the first have landed and land under the first half's products (one register set per half)
+        bf16x4 vlo[2][2][NDB], vhi[2][2][NDB];
+        ring_tr_frag<HD, 0, 0>(vlo[0][0][0], vhi[0][0][0], sV, fa); ring_tr_frag<HD, 1, 0>(vlo[0][1][0], vhi[0][1][0], sV, fa);
+        if constexpr (NDB > 1) { ring_tr_frag<HD, 0, 1>(vlo[0][0][1], vhi[0][0][1], sV, fa); ring_tr_frag<HD, 1, 1>(vlo[0][1][1], vhi[0][1][1], sV, fa); }
+        if (k0 + 64 > L) {
+            asm volatile("; tail key tile: mask" ::: "memory");
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[kb][r] = -INFINITY;
+        }
+        if (k0 == 0) {
+            float tm = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tm = fmaxf(tm, s[kb][r]);
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            m_run = tm;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= tm;
+            negm = splat16(-m_run);
+        }
+        float psum;
+        float p[2][16];
+        auto exp_tile = [&]() {
+            float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    p[kb][r] = fast_exp2(s[kb][r]);
+                    p[kb][r + 1] = fast_exp2(s[kb][r + 1]);
+                    ps0 = add1(ps0, p[kb][r]);
+                    ps1 = add1(ps1, p[kb][r + 1]);
+                }
+            psum = ps0 + ps1;
+        };
+        exp_tile();
+        if (k0 != 0 && __any(!(psum < LAZY_SUM))) {
+            // wave-uniform and rare: move the reference point (see attn_fwd_kernel); the key fragments are read again (K is still in its slot)
+            asm volatile("; softmax: new reference max" ::: "memory");
+            lds_wait();                                    // (the V reads in flight: the key fragments are read again into the same registers)
+            read_k();
+            scores();
+            float tm = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (k0 + 64 > L && k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[kb][r] = -INFINITY;
+                    tm = fmaxf(tm, s[kb][r]);
+                }
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            const float d = fmaxf(tm, 0.f);
+            const float alpha = fast_exp2(-d);
+            l_run *= alpha;
+#pragma unroll
+            for (int dd = 0; dd < NDB; ++dd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+            m_run += d;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= d;
+            negm = splat16(-m_run);
+            exp_tile();
+        }
+        l_run += psum;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) pf[kb][st] = acc_frag(&p[kb][8 * st]);
+        lds_wait();                                        // the V fragments of keys 0 - 31
+        ring_tr_frag<HD, 2, 0>(vlo[1][0][0], vhi[1][0][0], sV, fa); ring_tr_frag<HD, 3, 0>(vlo[1][1][0], vhi[1][1][0], sV, fa);
+        if constexpr (NDB > 1) { ring_tr_frag<HD, 2, 1>(vlo[1][0][1], vhi[1][0][1], sV, fa); ring_tr_frag<HD, 3, 1>(vlo[1][1][1], vhi[1][1][1], sV, fa); }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(vlo[0][st][d], vhi[0][st][d]), pf[0][st], o[d], 0, 0, 0);
+        lds_wait();                                        // keys 32 - 63
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(vlo[1][st][d], vhi[1][st][d]), pf[1][st], o[d], 0, 0, 0);
+    }
+    if (!active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qq = qw + (lane & 31);
+    float omax = 0.f;
+    if (qq < L) {
+        bf16_t* orow = a.out + (size_t)(seq0 + qq) * a.ldo + head * HD;
+        uint8_t* orow8 = a.out8 ? a.out8 + (size_t)(seq0 + qq) * a.ldo8 + head * HD : nullptr;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) store_block<HD, false>(orow, d, hh, o[d], inv, orow8, q8s, omax);
         if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
     if (a.out8) q_amax_update(a.q8, omax, q8seen);
@@ -494,7 +812,7 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : (HD == 64 && N
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                ds[r] = C_INIT ? fast_exp2(s[r]) * dp[r] : fast_exp2(s[r] - lse2) * (dp[r] - delta);
+                ds[r] = C_INIT ? mul1(fast_exp2(s[r]), dp[r]) : mul1(fast_exp2(sub1(s[r], lse2)), sub1(dp[r], delta));
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -518,6 +836,142 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : (HD == 64 && N
         uint8_t* drow8 = G8 ? a.dqkv8 + (size_t)(seq0 + qq) * a.ld8 + head * HG : nullptr;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) store_block<HG, true>(drow, d, hh, dq[d], a.scale, drow8, g8s, g8max);
+    }
+    if (G8) q_amax_update(a.qd8, g8max, g8seen);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dQ with the K / V tiles by LDS-DMA ring (see attn_fwd_ring_kernel): same image, same fragments, same products in the same order as
+// attn_bwd_dq_kernel.  Per 32-key block: K and V row fragments -> S and dP; the K fragments of the dQ product (transposed reads) are
+// requested behind those MFMAs and land under the exponentials.
+template <int HD, int NW, int NS, bool G8 = false>
+__global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : (HD == 64 && NW == 4) ? 3 : 1)
+void attn_bwd_dq_ring_kernel(AttnArgs a) {
+    constexpr int NTH = 64 * NW;
+    constexpr int NKK = HD / 16, NDB = HD / 32;
+    constexpr int IMG = 64 * HD * 2, SLOT = 2 * IMG;
+    constexpr int DPT = 2 * RingOff<HD, NTH>::PER;
+    static_assert(NS >= 2 && NS <= 4 && (NS - 2) * DPT <= 63, "ring depth");
+    __shared__ __attribute__((aligned(16))) char smem[NS * SLOT];
+    const unsigned smem_lds = (unsigned)(size_t)(LDS_AS const char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = lid / a.ntiles, tix = lid - head * a.ntiles;
+    const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int qw = a.tile_q0[tix] + 32 * wave;
+    const bool active = qw < L;
+    const int q = min(qw + (lane & 31), L - 1);
+    const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HD;
+
+    RingOff<HD, NTH> ro;
+    ro.init(a.ld, tid);
+    const int ntile = (L + 63) >> 6;
+    auto issue = [&](int t, int slot) {
+        ring_issue<HD, NTH>(ro, base + a.D, a.ld, 64 * t, L - 1, smem + slot * SLOT, tid);
+        ring_issue<HD, NTH>(ro, base + 2 * a.D, a.ld, 64 * t, L - 1, smem + slot * SLOT + IMG, tid);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < ntile) issue(t, t);
+
+    bf16x8 qf[NKK], dof[NKK];
+    float dpart = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * a.ld + (2 * kk + hh) * 8);
+        dof[kk] = *reinterpret_cast<const bf16x8*>(a.dout + (size_t)(seq0 + q) * a.ldo + head * HD + (2 * kk + hh) * 8);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.out + (size_t)(seq0 + q) * a.ldo + head * HD + (2 * kk + hh) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart += bf2f((bf16_t)dof[kk][j]) * bf2f((bf16_t)of[j]);
+    }
+    const float delta = dpart + __shfl_xor(dpart, 32, 64);
+    const float lse2 = a.lse[(size_t)head * a.rows_total + seq0 + q] * 1.4426950408889634f;
+    if (active && hh == 0 && qw + (lane & 31) < L) a.delta[(size_t)head * a.rows_total + seq0 + q] = delta;
+    constexpr bool C_INIT = HD == 32;            // (see attn_bwd_dq_kernel)
+    f32x16 nlse, ndel;
+    if (C_INIT) { nlse = splat16(-lse2); ndel = splat16(-delta); }
+    FragAddr<HD> fa;
+    fa.init(lane);
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+    int slot = 0;
+    for (int t = 0; t < ntile; ++t) {
+        const int ahead = min(NS - 2, ntile - 1 - t);
+        if (NS >= 4 && ahead == 2) wait_vm<2 * DPT>();
+        else if (NS >= 3 && ahead >= 1) wait_vm<DPT>();
+        else wait_vm<0>();
+        ring_barrier();
+        if (t + NS - 1 < ntile) issue(t + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+        const unsigned sK = smem_lds + slot * SLOT, sV = sK + IMG;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        if (!active) continue;
+        const int k0 = 64 * t;
+        const bool tail_tile = k0 + 64 > L;                 // block-uniform
+        auto key_block = [&](auto KB) {
+            constexpr int kb = decltype(KB)::value;
+            bf16x8 kf[NKK], vf[NKK];
+            ring_row_frag<HD, kb, 0>(kf[0], sK, fa); ring_row_frag<HD, kb, 0>(vf[0], sV, fa);
+            ring_row_frag<HD, kb, 1>(kf[1], sK, fa); ring_row_frag<HD, kb, 1>(vf[1], sV, fa);
+            if constexpr (NKK > 2) {
+                ring_row_frag<HD, kb, 2>(kf[2], sK, fa); ring_row_frag<HD, kb, 2>(vf[2], sV, fa);
+                ring_row_frag<HD, kb, 3>(kf[3], sK, fa); ring_row_frag<HD, kb, 3>(vf[3], sV, fa);
+            }
+            lds_wait();
+            f32x16 s, dp;
+            if (C_INIT) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], nlse, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], dof[0], ndel, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], dof[0], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int kk = 1; kk < NKK; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk], dof[kk], dp, 0, 0, 0);
+            }
+            // the transposed key fragments of the dQ product land under the exponentials
+            bf16x4 tlo[2][NDB], thi[2][NDB];
+            ring_tr_frag<HD, 2 * kb, 0>(tlo[0][0], thi[0][0], sK, fa); ring_tr_frag<HD, 2 * kb + 1, 0>(tlo[1][0], thi[1][0], sK, fa);
+            if constexpr (NDB > 1) { ring_tr_frag<HD, 2 * kb, 1>(tlo[0][1], thi[0][1], sK, fa); ring_tr_frag<HD, 2 * kb + 1, 1>(tlo[1][1], thi[1][1], sK, fa); }
+            if (tail_tile) {
+                asm volatile("; tail key tile: mask" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -INFINITY;     // -> p = exp2(-inf) = 0
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = C_INIT ? mul1(fast_exp2(s[r]), dp[r]) : mul1(fast_exp2(sub1(s[r], lse2)), sub1(dp[r], delta));
+            bf16x8 dsf[2];
+            dsf[0] = acc_frag(&ds[0]);
+            dsf[1] = acc_frag(&ds[8]);
+            lds_wait();
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join8(tlo[st][d], thi[st][d]), dsf[st], dq[d], 0, 0, 0);
+        };
+        key_block(std::integral_constant<int, 0>{});
+        key_block(std::integral_constant<int, 1>{});
+    }
+    if (!active) return;
+    float g8s = 0.f, g8seen = 0.f, g8max = 0.f;
+    if (G8) { g8s = a.qd8[AVS_Q_SCALE]; g8seen = a.qd8[AVS_Q_AMAX]; }
+    const int qq = qw + (lane & 31);
+    if (qq < L) {
+        bf16_t* drow = a.dqkv + (size_t)(seq0 + qq) * a.ld + head * HD;
+        uint8_t* drow8 = G8 ? a.dqkv8 + (size_t)(seq0 + qq) * a.ld8 + head * HD : nullptr;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) store_block<HD, true>(drow, d, hh, dq[d], a.scale, drow8, g8s, g8max);
     }
     if (G8) q_amax_update(a.qd8, g8max, g8seen);
 }
@@ -818,13 +1272,14 @@ extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
                out8, ldo8, q8, nullptr, 0, nullptr};
     dim3 grid(ntiles * H);
     // hd 80 (ViT-H: 1280 / 16 heads): a 96-wide LDS image whose last 16 columns are zero, five contraction steps, 128-row tiles only
+    const bool ring = avs_tuning().attn_ring != 0;          // K / V tiles by LDS-DMA ring (hd 32 / 64; bitwise the register-staged kernels' results)
     if (hd == 80) attn_fwd_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
     else if (tile_rows == 128) {
-        if (hd == 64) attn_fwd_kernel<64, 4><<<grid, 256, 0, stream>>>(a);
-        else attn_fwd_kernel<32, 4><<<grid, 256, 0, stream>>>(a);
+        if (hd == 64) { if (ring) attn_fwd_ring_kernel<64, 4, 3><<<grid, 256, 0, stream>>>(a); else attn_fwd_kernel<64, 4><<<grid, 256, 0, stream>>>(a); }
+        else { if (ring) attn_fwd_ring_kernel<32, 4, 3><<<grid, 256, 0, stream>>>(a); else attn_fwd_kernel<32, 4><<<grid, 256, 0, stream>>>(a); }
     } else {
-        if (hd == 64) attn_fwd_kernel<64, 2><<<grid, 128, 0, stream>>>(a);
-        else attn_fwd_kernel<32, 2><<<grid, 128, 0, stream>>>(a);
+        if (hd == 64) { if (ring) attn_fwd_ring_kernel<64, 2, 3><<<grid, 128, 0, stream>>>(a); else attn_fwd_kernel<64, 2><<<grid, 128, 0, stream>>>(a); }
+        else { if (ring) attn_fwd_ring_kernel<32, 2, 3><<<grid, 128, 0, stream>>>(a); else attn_fwd_kernel<32, 2><<<grid, 128, 0, stream>>>(a); }
     }
     AVS_LAUNCH_CHECK("attn_fwd");
     return 0;
@@ -864,7 +1319,20 @@ extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
             else K<32, 2, 32, G><<<grid, 128, 0, stream>>>(a);                                              \
         }                                                                                                   \
     } while (0)
-    if (dqkv8) ATTN_BWD2(attn_bwd_dq_kernel, true); else ATTN_BWD2(attn_bwd_dq_kernel, false);
+    const bool ring = avs_tuning().attn_ring != 0 && hd != 80;
+#define ATTN_BWD2R(K, G)                                                                                    \
+    do {                                                                                                    \
+        if (tile_rows == 128) {                                                                             \
+            if (hd == 64) K<64, 4, 3, G><<<grid, 256, 0, stream>>>(a);                                      \
+            else K<32, 4, 3, G><<<grid, 256, 0, stream>>>(a);                                               \
+        } else {                                                                                            \
+            if (hd == 64) K<64, 2, 3, G><<<grid, 128, 0, stream>>>(a);                                      \
+            else K<32, 2, 3, G><<<grid, 128, 0, stream>>>(a);                                               \
+        }                                                                                                   \
+    } while (0)
+    if (ring) { if (dqkv8) ATTN_BWD2R(attn_bwd_dq_ring_kernel, true); else ATTN_BWD2R(attn_bwd_dq_ring_kernel, false); }
+    else if (dqkv8) ATTN_BWD2(attn_bwd_dq_kernel, true); else ATTN_BWD2(attn_bwd_dq_kernel, false);
+#undef ATTN_BWD2R
     AVS_LAUNCH_CHECK("attn_bwd_dq");
     if (dqkv8) ATTN_BWD2(attn_bwd_dkv_kernel, true); else ATTN_BWD2(attn_bwd_dkv_kernel, false);
 #undef ATTN_BWD2

@@ -143,7 +143,8 @@ struct AvsTuning {
     int ln_dma;            // 1: LayerNorm backward by the LDS-DMA kernel where it applies | 0 never | 2 automatic per launch context
                            // (avs_layernorm_bwd's `busy_lds` hint)                                                  AVSIAM_LN_DMA
     int ln_rpw;            // rows per wave of the LayerNorm backward: 0 automatic | 4 | 8 | 16                      AVSIAM_LN_RPW
-    int attn_ring;         // 1: attention K/V (Q/dO) tiles by LDS-DMA ring where built (hd 32 / 64) | 0: register-staged kernels  AVSIAM_ATTN_RING
+    int attn_ring;         // 1: attention forward / dQ with the K/V tiles by LDS-DMA ring (hd 32 / 64) | 0 (default): register-staged kernels -
+                           // bitwise the same results, measured neutral to slower                     AVSIAM_ATTN_RING
 };
 AvsTuning& avs_tuning();
 extern "C" int avs_tuning_set(const char* name, int value);

@@ -34,7 +34,7 @@ int avs_device_cu_count(void);
  *   "cu_reserve" compute units EVERY persistent kernel (nt / fp8 nt / tn8 / tn8f grids and split factors) leaves free, a multiple of 8
  *                keeps the XCDs balanced; 0 on one GPU, 8 when a gradient all-reduce overlaps the backward (src/traintest_cavmae_base.py:58-59
  *                is DDP's overlap; RCCL's kernels need CUs WHILE a GEMM runs)
- *   "ln_dma" 0 | 1    "ln_rpw" 0 auto | 4 | 8 | 16    "attn_ring" 0 | 1 (attention K/V tiles by LDS-DMA ring)
+ *   "ln_dma" 0 | 1    "ln_rpw" 0 auto | 4 | 8 | 16    "attn_ring" 0 (default) | 1 (attention forward / dQ with K/V tiles by LDS-DMA ring: same bits, not faster)
  * avs_persistent_cu_slots(): the CUs a persistent grid fills now (device CUs - cu_reserve). */
 int avs_tuning_set(const char* name, int value);
 int avs_tuning_get(const char* name, int* value);

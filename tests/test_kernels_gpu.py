@@ -380,6 +380,57 @@ def test_attention_fwd_bwd(H, hd, lens, tile_rows):
     assert dqkv[rows:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("H,hd", [(12, 64), (16, 32)])
+@pytest.mark.parametrize("tile_rows", [128, 64])
+def test_attention_ring_kernels_match_the_register_staged_ones(H, hd, tile_rows):
+    """The LDS-DMA ring kernels (round 5: K / V - Q / dO in the dK,dV kernel - tiles by global_load_lds into a ring of slots, one barrier per
+    tile, every LDS read in inline asm) against the register-staged kernels they replace: the same LDS image, the same fragments, the same
+    products in the same order - so the outputs must be BITWISE equal (forward output and log-sum-exp, dq / dk / dv, delta), on sequences
+    that end inside a tile, fill exactly one, are shorter than one, and run over dozens (the decoder's 2472).  Twice, with the caches in
+    another state, as a race screen for the ring's waits; rows outside the sequences stay untouched."""
+    from avsiam_amd import _lib
+    o = ops()
+    D = H * hd
+    lens = [2472, 196, 49, 618, 65, 64, 1, 128, 129, 512, 63, 300]
+    rows = sum(lens)
+    rp = o.pad_rows(rows)
+    qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(rows, 3 * D, device=DEV)
+    x[:, :D] *= o.attn_q_scale(hd)
+    qkv[:rows] = bf(x)
+    # head 0 of the long sequence: every query is aligned with key 5 (first tile: it sets the reference point, score ~ 0.05 * 64 * hd in
+    # log2 units) and key 1900 is twice key 5 - its score lies 100+ above the reference, the row sum passes 2^40 and the forward's rare
+    # "new reference maximum" branch runs in tile 29
+    qkv[5, D:D + hd] *= 8.0
+    qkv[1900, D:D + hd] = qkv[5, D:D + hd] * 2.0
+    qkv[:2472, :hd] = qkv[5:6, D:D + hd] * 0.05
+    dout = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    dout[:rows] = bf(torch.randn(rows, D, device=DEV))
+    tiles = o.AttnTiles(lens, DEV, tile_rows=tile_rows)
+
+    def run(ring):
+        _lib.tuning_set("attn_ring", ring)
+        out = torch.full((rp, D), 3.0, device=DEV, dtype=torch.bfloat16)
+        lse = torch.full((H, rp), 5.0, device=DEV)
+        o.attn_fwd(qkv, tiles, H, out, lse)
+        dqkv = torch.full_like(qkv, 7.0)
+        delta = torch.full_like(lse, 9.0)
+        o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv)
+        torch.cuda.synchronize()
+        return out, lse, dqkv, delta
+
+    try:
+        want = run(0)
+        for rep in range(2):
+            got = run(1)
+            for name, g, w in zip(("out", "lse", "dqkv", "delta"), got, want):
+                assert torch.equal(g, w), (name, rep, float((g.float() - w.float()).abs().max()))
+            torch.zeros(64 << 20, device=DEV).add_(1.0)          # other traffic between the repetitions
+        assert torch.isfinite(want[0][:rows].float()).all() and float((want[0][rows:].float() - 3.0).abs().max()) == 0.0
+    finally:
+        _lib.tuning_set("attn_ring", 0)
+
+
 @pytest.mark.parametrize("H,hd", [(12, 64), (4, 32)])
 def test_attention_bwd_fused_matches_two_kernel_form(H, hd):
     """avs_attn_bwd_fused (sequences of at most 64 / 128 tokens: dq, dk, dv from one read and one S / exp evaluation per (sequence,

@@ -35,6 +35,19 @@ def run_case(name, H, hd, lens, dev, tile_rows=(128, 64)):
     msg = f"{name:34s} rows={rows:6d}:"
     for tr in tile_rows:
         tiles = ops.AttnTiles(lens, dev, tile_rows=tr)
+        if "--ring-ab" in sys.argv:              # register-staged vs LDS-DMA ring kernels, interleaved rounds in this one process (median)
+            from avsiam_amd import _lib
+            res = {0: ([], []), 1: ([], [])}
+            for _ in range(5):
+                for ring in (0, 1):
+                    _lib.tuning_set("attn_ring", ring)
+                    res[ring][0].append(timeit(lambda: ops.attn_fwd(qkv, tiles, H, out, lse), 10))
+                    res[ring][1].append(timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv), 10))
+            _lib.tuning_set("attn_ring", 0)
+            med = lambda v: sorted(v)[len(v) // 2]
+            msg += (f"  [tile {tr}] fwd staged {med(res[0][0])*1e6:7.1f} ring {med(res[1][0])*1e6:7.1f} us ({fl/med(res[1][0])/1e12:5.0f} TF/s)"
+                    f"  bwd staged {med(res[0][1])*1e6:7.1f} ring {med(res[1][1])*1e6:7.1f} us ({2.5*fl/med(res[1][1])/1e12:5.0f} TF/s)")
+            continue
         tf = timeit(lambda: ops.attn_fwd(qkv, tiles, H, out, lse), 10)
         tb = timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv), 10)
         msg += (f"  [tile {tr}] fwd {tf*1e6:7.1f} us {fl/tf/1e12:6.1f} TF/s {rows*8.0*D/tf/1e9:6.0f} GB/s"
