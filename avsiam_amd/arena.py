@@ -157,9 +157,16 @@ class ParamArena:
         if ntiles:
             ops.transpose_batched(desc, tmap, ntiles)
 
-    def zero_grad_range(self, which):
-        lo, hi = self.range[which]
+    def zero_grad_range(self, which, lo=None, hi=None):
+        """zero-fill the pass's gradient range (or [lo, hi) of the arena) and open a new gradient EPOCH: Stack.backward allows one backward
+        per block and epoch unless accumulate=True (the value third of the qkv bias gradient is derived from the accumulated proj bias
+        gradient).  Every zero-fill of gradients goes through here, so direct users of the passes (tools, external loops) that zero with
+        this method never trip the guard spuriously."""
+        a, b = self.range[which]
+        lo = a if lo is None else lo
+        hi = b if hi is None else hi
         self.g[lo:hi].zero_()
+        self.zero_epoch += 1
 
     def live_slice(self, flat, which):
         lo, hi = self.range[which]

@@ -1267,7 +1267,8 @@ extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
     AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_fwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_fwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
-    AVS_CHECK_ARG(out && lse && (ldo % 4) == 0, "attn_fwd: null output");
+    AVS_CHECK_ARG(out && lse, "attn_fwd: null output");
+    AVS_CHECK_ARG((ldo % 8) == 0 && ldo >= D, "attn_fwd: ldo=%lld must be a multiple of 8 (the epilogue stores 16 bytes per lane) and >= D", ldo);
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd),
                out8, ldo8, q8, nullptr, 0, nullptr};
     dim3 grid(ntiles * H);
@@ -1305,6 +1306,7 @@ extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
+    AVS_CHECK_ARG((ldo % 8) == 0 && ldo >= D, "attn_bwd: ldo=%lld must be a multiple of 8 (16-byte fragment loads of out / dO rows) and >= D", ldo);
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
                dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16};
     dim3 grid(ntiles * H);

@@ -584,6 +584,18 @@ class Stack:
         dxo, dxm = self.dx
         dbo, dbm = self.dxb
         ranges = [(0, M, blocks)] if blocks2 is None else [(0, split, blocks), (split, M, blocks2)]
+        # a second backward over a block since its gradients were zeroed must say accumulate=True (the value third of the qkv bias gradient is
+        # a vector-matrix product of the WHOLE accumulated proj bias gradient) - checked HERE, before any kernel is queued, so a refused call
+        # leaves the gradient arena untouched
+        for lo_, hi_, bl in ranges:
+            for i in range(self.nblocks):
+                ar = bl[i].arena
+                if not accumulate and ar.gb_epoch.get(bl[i].prefix) == ar.zero_epoch:
+                    raise RuntimeError(f"{bl[i].prefix}: second backward over this block since its gradients were zeroed - pass accumulate=True "
+                                       "(or zero the gradients with arena.zero_grad_range)")
+        for lo_, hi_, bl in ranges:
+            for i in range(self.nblocks):
+                bl[i].arena.gb_epoch[bl[i].prefix] = bl[i].arena.zero_epoch
         one = blocks2 is not None                # a row range has ONE affine set; the packed single-tower case selects by row_mod
         # recompute: the blocks share ONE set of activation buffers, refilled in front of every block's backward - weight-gradient GEMMs
         # still reading them on a second stream would race with the refill, so everything runs on one stream
@@ -733,10 +745,7 @@ class Stack:
                 ops.colsum(self.dqkv[lo:, :D], bl[i].qkv.gb[:D], hi - lo)
                 # (the vector-matrix product reads the WHOLE accumulated proj bias gradient: a second backward over the same block
                 #  between two zero-fills must say accumulate=True, or the value third would be counted twice - ADVICE r3)
-                ar = bl[i].arena
-                if not accumulate and ar.gb_epoch.get(bl[i].prefix) == ar.zero_epoch:
-                    raise RuntimeError(f"{bl[i].prefix}: second backward over this block since its gradients were zeroed - pass accumulate=True")
-                ar.gb_epoch[bl[i].prefix] = ar.zero_epoch
+                #  - checked at the top of this method)
                 ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * D:])
                 d8, q8_ = g8rec(i - 1, "dbo")          # the block below reads this gradient through its fc2 input-gradient GEMM
                 _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, None if g16 and i > 0 else dxo[lo:], self.lnws,

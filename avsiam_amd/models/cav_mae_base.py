@@ -97,13 +97,14 @@ class _HotPath(torch.autograd.Function):
             if live & w:
                 model._reduced[w] = False                              # fresh local gradients
         from .. import ops as _ops
-        arena.zero_epoch += 1                                        # (engine.Stack.backward: one backward per block and epoch unless accumulate=True)
+        # (every zero-fill opens a new gradient epoch - arena.zero_grad_range; engine.Stack.backward: one backward per block and epoch
+        #  unless accumulate=True)
         if live & P1:
             _ops.timed("torch_zero_grads", lambda: arena.zero_grad_range(P1))
         if live & P2:
             lo, hi = arena.range[P2]
             lo = max(lo, arena.range[P1][1]) if live & P1 else lo
-            _ops.timed("torch_zero_grads", lambda: arena.g[lo:hi].zero_())
+            _ops.timed("torch_zero_grads", lambda: arena.zero_grad_range(P2, lo, hi))
         # data parallel: the gradient all-reduce belongs to backward, as under DDP (traintest_cavmae_base.py:58-59) - chunks of
         # the flat arena are reduced as soon as the schedule declares them final (comm.GradReducer).  A backward with BOTH
         # passes live accumulates two passes into the shared range, so it is reduced once, at the end.

@@ -135,6 +135,27 @@ def _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train):
         sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}
         miss, unexpected = audio_model.load_state_dict(sd, strict=False)
         print('now load pretrain model from {:s}, missing keys: {:d}, unexpected keys: {:d}'.format(args.pretrain_path, len(miss), len(unexpected)))
+        # strict=False is what the reference's consumers use (run_cavmae_ft_base.py:245-248), but a checkpoint of ANOTHER model would then
+        # train silently from the random start: refuse one that shares no key with this model, and say loudly what is left out
+        total = len(audio_model.state_dict())
+        if len(miss) >= total:
+            raise SystemExit('--pretrain_path {:s}: none of the {:d} keys of CAVMAE_BASE is in this checkpoint - not a checkpoint of this model'
+                             .format(args.pretrain_path, total))
+        if miss or unexpected:
+            print('WARNING: --pretrain_path is a PARTIAL match: {:d} of {:d} keys keep their initial value (first: {}), {:d} checkpoint keys '
+                  'are ignored (first: {})'.format(len(miss), total, list(miss)[:3], len(unexpected), list(unexpected)[:3]), flush=True)
+        # The optimizer: the loop saves the FIRST optimizer's state beside the weights (best_optim_state.pth, as traintest_cavmae_base.py:230);
+        # when that file sits beside the checkpoint, Adam #1 continues from it (moments and step count).  Adam #2's state is not saved by the
+        # reference's loop either, so the MAE pass's moments restart - without the file this is a weights-only warm start, and says so.
+        from .param_spec import P1
+        opt_path = os.path.join(os.path.dirname(args.pretrain_path), 'best_optim_state.pth')
+        if os.path.exists(opt_path):
+            audio_model.to(torch.device("cuda", getattr(args, "gpu", 0)))      # (the optimizer state lives beside the weights; train() keeps this device)
+            audio_model.load_optimizer_state_dict(P1, torch.load(opt_path, map_location='cpu'))
+            print('restored the state of optimizer 1 (Adam moments, step {:d}) from {:s}; optimizer 2 restarts'
+                  .format(audio_model._opt_state[P1]['step'], opt_path))
+        else:
+            print('no best_optim_state.pth beside the checkpoint: weights-only warm start (both Adam states restart, bias correction from step 1)')
         from . import engine as _engine
         if _engine.FP8 != "0" and os.path.exists(args.pretrain_path + ".fp8"):
             audio_model.load_fp8_state(torch.load(args.pretrain_path + ".fp8", map_location='cpu'))

@@ -167,7 +167,9 @@ int avs_gemm_tn_fp8_group3(const uint8_t* A0, long long lda0, const uint8_t* B0,
 /* ---- varlen attention (F.scaled_dot_product_attention in Attention.forward, cav_mae_base.py:60-68) on the packed
  * qkv matrix [rows, 3*D] (q|k|v, head h at columns h*hd); one (tile_start, tile_len, tile_q0) triple per tile of
  * tile_rows (128: 4-wave workgroups; 64: 2-wave workgroups, twice as many resident per CU - for short sequences) rows.
- * Head dims hd = D / H: 64 (ViT-B/L encoder), 32 (decoder), 80 (ViT-H encoder; tile_rows 128 only).  lse/delta: [H][rows_total] fp32. */
+ * Head dims hd = D / H: 64 (ViT-B/L encoder), 32 (decoder), 80 (ViT-H encoder; tile_rows 128 only).  lse/delta: [H][rows_total] fp32.
+ * Rows of qkv, out, dout and dqkv must be 16-byte aligned: ld and ldo multiples of 8 elements (the kernels load fragments and store
+ * accumulator blocks 16 bytes per lane), ldo8 / ld8 of the 8-bit copies multiples of 16; other strides are refused (-2). */
 int avs_attn_fwd(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                  const int* tile_q0, int ntiles, int tile_rows, avs_bf16* out, long long ldo, float* lse, int rows_total,
                  avs_stream_t stream);

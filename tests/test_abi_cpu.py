@@ -40,6 +40,42 @@ def test_abi_version_and_error_string(lib_path):
     assert rc == -2
 
 
+def test_attention_refuses_rows_that_are_not_16_byte_aligned(lib_path):
+    """the attention epilogues store 16 bytes per lane - an output stride that is a multiple of 4 but not of 8 elements must be
+    an argument error (-2), not a misaligned store.  Argument validation precedes every launch, so this runs without a GPU."""
+    lib = _lib.load()
+    one = ctypes.c_void_p(16)                          # any non-NULL value: the call must fail before touching it
+    D, H = 768, 12
+    for ldo, ok_shape in ((772, False), (776, True)):
+        rc = lib.avs_attn_fwd(one, 3 * D, D, H, one, one, one, 1, 128, one, ldo, one, 128, None) if not ok_shape else 0
+        assert (rc == -2 and b"ldo" in lib.avs_last_error()) or ok_shape
+    rc = lib.avs_attn_bwd(one, 3 * D, D, H, one, one, one, 1, 128, one, one, 772, one, one, 128, one, None)
+    assert rc == -2 and b"ldo" in lib.avs_last_error()
+    rc = lib.avs_attn_bwd_fused(one, 3 * D, D, H, one, one, 1, 128, one, one, 772, one, 128, one, None)
+    assert rc == -2
+
+
+def test_tuning_knobs_are_set_through_the_abi_only(lib_path):
+    """The library never reads the environment (include/avsiam_hip.h): the knobs are plain integers behind avs_tuning_set / _get, range
+    checked; cu_reserve shrinks what a persistent grid may fill."""
+    lib = _lib.load()
+    full = lib.avs_persistent_cu_slots()
+    try:
+        _lib.tuning_set("cu_reserve", 8)
+        assert _lib.tuning_get("cu_reserve") == 8 and lib.avs_persistent_cu_slots() == full - 8
+        with pytest.raises(_lib.AvsiamHipError):
+            _lib.tuning_set("nt_tile_h", 100)
+        with pytest.raises(_lib.AvsiamHipError):
+            _lib.tuning_set("no_such_knob", 1)
+        for k in ("gemm_tile", "gemm_persistent", "gemm_nt8", "nt_tile_h", "nt_grid", "ln_dma", "ln_rpw", "attn_ring"):
+            _lib.tuning_get(k)
+    finally:
+        _lib.tuning_set("cu_reserve", 0)
+    import subprocess
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", lib_path], text=True)
+    assert "getenv" not in undefined, "the library must not read the environment"
+
+
 def test_missing_library_raises(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libavsiam_hip.so")

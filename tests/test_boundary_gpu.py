@@ -237,6 +237,25 @@ def test_entry_point_main_runs_two_steps(tmp_path, capsys):
     res = np.loadtxt(exp / "result.csv", delimiter=",").reshape(1, 10)
     assert np.isfinite(res).all() and res[0, 3] > 0 and res[0, 7] > 0
     assert model.cfg.audio_tokens == 128
+    # --pretrain_path: the checkpoint this run wrote resumes WITH the first optimizer's state that sits beside it (moments and
+    # step count: bias correction does not restart); a checkpoint of another model is refused instead of training from the random start
+    from avsiam_amd.param_spec import P1
+    env_keep = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    common = ["--model", "cav-mae", "--dataset", "audioset", "--target_length", "256", "--batch-size", "4", "--lr", "2e-4", "--n-epochs", "1",
+              "--steps-per-epoch", "1", "--n-print-steps", "1", "--exp-dir", str(tmp_path / "exp2"), "--save_model", "False"]
+    try:
+        resumed = entry.main(common + ["--pretrain_path", str(exp / "models" / "best_audio_model.pth")])
+        out = capsys.readouterr().out
+        assert "restored the state of optimizer 1" in out and "missing keys: 0, unexpected keys: 0" in out
+        assert resumed._opt_state[P1]["step"] == model._opt_state[P1]["step"] + 1 == 3          # 2 steps of the first run + 1
+        foreign = tmp_path / "foreign.pth"
+        torch.save({"encoder.layer.0.weight": torch.zeros(3)}, foreign)
+        with pytest.raises(SystemExit, match="not a checkpoint of this model"):
+            entry.main(common + ["--pretrain_path", str(foreign)])
+    finally:
+        for k, val in env_keep.items():
+            if val is not None:
+                os.environ[k] = val
 
 
 def test_torchrun_entry_forms_the_rccl_group_and_runs(tmp_path):

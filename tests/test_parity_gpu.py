@@ -523,10 +523,10 @@ D32_FP8_LOSS_RTOL, D32_FP8_LOGITS_ATOL = 7e-3, 0.14         # measured: 2.2e-3, 
 # fp8 mode 3 at depth 32, batch 2 (measured, profiles/r05/parity_margins.json vit_huge14_depth32_*_fp8m3_*):
 #   whole gradient            cosine 0.9870 (contrastive) / 0.9928 (MAE)                      -> >= 0.975
 #   every MATRIX              cosine >= 0.942 (contrastive: blocks.31.mlp.fc2) / 0.978 (MAE), norm within 3.7 %   -> >= 0.85, within 12 %
-#   the vector tensors, taken together as one vector                                           -> >= 0.90 (see the margins file)
+#   the vector tensors, taken together as one vector      cosine 0.976                        -> >= 0.93
 #   a single vector tensor    is mostly noise in the batch-2 contrastive pass (2 x 2 logits): the worst, a 1280-element LayerNorm bias of
 #                             the LAST block, has cosine 0.70 and 1.6 x the norm - held only to cosine >= 0.35, norm within a factor 2.2
-D32_FP8_COS_MIN, D32_FP8_RATIO_TOL, D32_FP8_MATRIX_COS_MIN, D32_FP8_MATRIX_RATIO_TOL, D32_FP8_WHOLE_COS, D32_FP8_VECTORS_COS = 0.35, 1.2, 0.85, 0.12, 0.975, 0.90
+D32_FP8_COS_MIN, D32_FP8_RATIO_TOL, D32_FP8_MATRIX_COS_MIN, D32_FP8_MATRIX_RATIO_TOL, D32_FP8_WHOLE_COS, D32_FP8_VECTORS_COS = 0.35, 1.2, 0.85, 0.12, 0.975, 0.93
 
 
 def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():

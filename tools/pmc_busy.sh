@@ -13,7 +13,7 @@ export AVSIAM_WGRAD_STREAM=0
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/p${i}_bench.json 2> $OUT/p$i.err
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o c -- python3 $REPO/bench.py --secondary-steps 0 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/p${i}_bench.json 2> $OUT/p$i.err
   echo "busy pass $i done"
 done
 cd $REPO

@@ -8,9 +8,9 @@ REPO=$PWD
 OUT=$PWD/gpurun_out/${TAG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/fetch_bench.json 2> $OUT/fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- python3 $REPO/bench.py --secondary-steps 0 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/fetch_bench.json 2> $OUT/fetch.err
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/write_bench.json 2> $OUT/write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o w -- python3 $REPO/bench.py --secondary-steps 0 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events > $OUT/write_bench.json 2> $OUT/write.err
 echo "write pass done"
 cd $REPO
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1)
