@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 artefacts for the current build (GPU box, repo root):  bash tools/round4_profile.sh [part ...]   parts: bench prof prof8 pmc dp fp8 big ln rehearsal attn shapes b4
+# Round-5 artefacts for the current build (GPU box, repo root):  bash tools/round4_profile.sh [part ...]   parts: bench prof prof8 pmc dp fp8 fp8s big ln rehearsal attn shapes b4
 # (in the build container first: git rev-parse HEAD > HEAD_COMMIT - the PMC summaries stamp it)
 # Everything goes to gpurun_out/r05/ (copy what is to be judged into profiles/r05/).
 set -e
@@ -121,4 +121,21 @@ if has b4; then
   find $OUT/prof_b4 -name "*kernel_stats.csv" -exec cp {} $OUT/b4_kernel_stats.csv \;
   rm -rf $OUT/prof_b4
   head -12 $OUT/b4_kernel_stats.csv
+fi
+if has fp8s; then
+  # the short fp8 set: ViT-B in the four precisions on one box, ViT-H/14 at batch 64 x 10 frames from one activation pool (bf16 and fp8 mode 3)
+  python bench.py --secondary-steps 0 --no-cpu-baseline --steps 10 > $OUT/b_vitb_bf16_same_box_bench.json 2> $OUT/fp8s.err
+  python bench.py --secondary-steps 0 --no-cpu-baseline --steps 10 --fp8 > $OUT/b_vitb_fp8_bench.json 2>> $OUT/fp8s.err
+  python bench.py --secondary-steps 0 --no-cpu-baseline --steps 10 --fp8 --fp8-dgrad > $OUT/b_vitb_fp8_dgrad_bench.json 2>> $OUT/fp8s.err
+  python bench.py --secondary-steps 0 --no-cpu-baseline --steps 10 --fp8 --fp8-wgrad > $OUT/b_vitb_fp8_wgrad_bench.json 2>> $OUT/fp8s.err
+  python bench.py --secondary-steps 0 --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute auto --share-pass-buffers > $OUT/h_vit_huge14_b64_pooled_bench.json 2>> $OUT/fp8s.err
+  python bench.py --secondary-steps 0 --no-cpu-baseline --steps 5 --warmup 2 --model vit_huge14 --recompute auto --share-pass-buffers --fp8 --fp8-wgrad > $OUT/h_vit_huge14_b64_pooled_fp8_wgrad_bench.json 2>> $OUT/fp8s.err
+  python - <<PY
+import json, glob
+for f in sorted(glob.glob("$OUT/[bh]_*bench.json")):
+    try:
+        d = json.load(open(f)); print(f.split("/")[-1], round(d["value"], 2), round(d["ms_per_step"], 2), "bf16 frac", round(d["roofline"]["frac"], 3), "fp8 frac", d.get("roofline_fp8", {}).get("frac"), "GiB", d["config"].get("peak_memory_gib"), d["config"].get("activation_pool_gib"))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
 fi
