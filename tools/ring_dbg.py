@@ -1,5 +1,8 @@
+"""Ring vs register-staged attention kernels, per sequence (debugging aid of round 5): max |difference| of the forward output and of dq for
+each sequence length of a mixed batch, hd 64 and 32, 128- and 64-row tiles.   python tools/ring_dbg.py   (GPU box)"""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from avsiam_amd import ops, _lib
 dev = 'cuda'
 for H, hd in ((12, 64), (16, 32)):

@@ -139,3 +139,14 @@ for f in sorted(glob.glob("$OUT/[bh]_*bench.json")):
         print(f, "ERR", e)
 PY
 fi
+if has lnstep; then
+  # LayerNorm backward variants IN THE STEP: the LDS-DMA kernel (default) against the register kernel, alternating on one box
+  for v in 1 0 1 0; do
+    AVSIAM_LN_DMA=$v python bench.py --secondary-steps 0 --no-cpu-baseline --steps 10 > $OUT/lnstep_dma$v.json 2>> $OUT/lnstep.err
+    python - <<PY
+import json
+d = json.load(open("$OUT/lnstep_dma$v.json")); f = d["roofline_more"]["ms_per_step_by_family"]
+print("AVSIAM_LN_DMA=$v", round(d["value"], 1), "samples/s", round(d["ms_per_step"], 2), "ms/step; layernorm_bwd", f["layernorm_bwd"], "ms single-stream")
+PY
+  done | tee $OUT/layernorm_dma_in_step_ab.log
+fi
