@@ -269,3 +269,92 @@ def test_deferred_mae_only_update_is_the_same_update():
         p.join(timeout=120)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_rank_5_of_8_on_one_gpu_matches_the_oracles_dp_scheme():
+    """World size 8 - the geometry of BASELINE.json configs[2] - on the REAL kernels, in ONE process: the engine runs as rank 5 of 8 with a
+    replay communicator whose all-gather returns the embeddings of the seven other ranks as the CPU oracle computes them (every rank shares
+    the weights; inputs and plans differ per rank).  Checked against the oracle's data-parallel scheme (tests/test_dp_gloo.py, pinned there
+    to the global gradient at W = 2 / 4 / 8): the [8B, 8B] logits, the global loss - identical on every rank - and rank 5's LOCAL gradient
+    (own slice of the embedding gradient x W, no backward collective: gather_layer.py:35-37) for every live tensor; then the chunked
+    reduction's bookkeeping: the whole live range declared exactly once, DDP's 1/W owed and applied.
+    What this covers that the 2-rank test cannot: N = 8 B rows of logits, a rank offset of 5 B in the slot maps, W = 8 in the backward."""
+    import random
+    from avsiam_amd.maskplan import make_contrastive_plan
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.param_spec import P1
+    from oracle import ref_cpu
+    from tests.helpers import _Waited
+    W, R, B = 8, 5, 3
+    cfg = AVSiamConfig(audio_tokens=128, depth=4)
+    m = CAVMAE_BASE(cfg=cfg, init_seed=13, init_mode="random", verbose=False).cuda()
+    live = [n for n, info in m.arena.info.items() if info.live]
+    torch.set_num_threads(16)
+    P = {k: m._params[k].detach().cpu().clone().requires_grad_(True) for k in live}
+    ins = [synth_inputs(cfg, B, 60 + r) for r in range(W)]
+    plans = [make_contrastive_plan(cfg, B, torch.Generator().manual_seed(r), random.Random(r)) for r in range(W)]
+    with torch.no_grad():
+        others = [ref_cpu.forward_encoder_mmixed(P, cfg, a, v, pl) for (a, v), pl in zip(ins, plans)]
+    msgs = [torch.cat([ca.mean(1), cv.mean(1)]).float() for ca, cv in others]               # what rank r sends: [2B, D] (audio rows, then visual)
+    # ---- the oracle's scheme on rank R
+    ca_r, cv_r = ref_cpu.forward_encoder_mmixed(P, cfg, ins[R][0], ins[R][1], plans[R])
+    own = torch.cat([ca_r.mean(1), cv_r.mean(1)])
+    allr = torch.stack([own.detach() if r == R else msgs[r] for r in range(W)])              # [W, 2B, D]
+    A = allr[:, :B].reshape(W * B, -1).clone().requires_grad_(True)
+    V = allr[:, B:].reshape(W * B, -1).clone().requires_grad_(True)
+    loss, acc, logits = ref_cpu.contrastive(A, V, cfg.temperature)
+    loss.backward()
+    own.backward(torch.cat([A.grad[R * B:(R + 1) * B], V.grad[R * B:(R + 1) * B]]) * W)
+    want = {k: p.grad for k, p in P.items() if p.grad is not None}
+
+    class Replay:
+        world, rank, active = W, R, True
+
+        def __init__(self):
+            self.messages, self.gathers = [], 0
+
+        def all_gather(self, out, inp):
+            self.gathers += 1
+            o = out.view(W, -1)
+            for r in range(W):
+                o[r].copy_(inp.reshape(-1) if r == R else msgs[r].reshape(-1).to(out.device))
+
+        def all_reduce_async(self, t):                    # the other ranks' gradients are not simulated: the SUM is this rank's own
+            self.messages.append(t.numel())
+            return _Waited()
+
+        def all_reduce(self, t):
+            self.messages.append(t.numel())
+
+    comm = Replay()
+    m.set_distributed(W, R, comm)
+    try:
+        from avsiam_amd import _lib
+        assert _lib.tuning_get("cu_reserve") == 8         # collectives on the path: the persistent kernels leave CUs to them
+        out = m(ins[R][0].cuda(), ins[R][1].cuda(), mae_loss_weight=0, contrast_loss_weight=1, mask_plan=plans[R])
+        out[0].backward()
+        torch.cuda.synchronize()
+        assert comm.gathers == 1                          # ONE packed message per rank and pass
+        eng = m._engine("contrastive", B)
+        assert tuple(eng.total.shape) == (W * B, W * B)
+        assert float((eng.total.cpu().double() - logits.detach().double()).abs().max()) <= 0.02
+        assert abs(out[4].item() - loss.item()) <= 2e-3 * abs(loss.item()), (out[4].item(), loss.item())
+        assert abs(out[7].item() - acc.item()) <= 1.0 / (W * B) + 1e-6
+        lo, hi = m.arena.range[P1]
+        assert len(comm.messages) >= 2 and sum(comm.messages) == hi - lo, comm.messages
+        worst = 1.0
+        for k, w in want.items():
+            g = m._params[k].grad                         # DDP's mean of a SUM that holds only this rank's share: local gradient / W
+            assert g is not None, k
+            g, w = g.detach().double().cpu().reshape(-1) * W, w.double().reshape(-1)
+            if float(w.norm()) == 0:
+                continue
+            cos = float(torch.dot(g, w) / (g.norm() * w.norm()))
+            assert cos >= 0.9995 and abs(float(g.norm() / w.norm()) - 1) <= 0.02, (k, cos, float(g.norm() / w.norm()))
+            worst = min(worst, cos)
+        from tests.helpers import record_margin
+        record_margin("dp_rank5_of_8_local_gradient", worst_cos=worst, loss_rel=abs(out[4].item() - loss.item()) / abs(loss.item()))
+    finally:
+        m.set_distributed(1, 0)
+        from avsiam_amd import _lib
+        assert _lib.tuning_get("cu_reserve") == 0

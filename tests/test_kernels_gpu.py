@@ -775,7 +775,7 @@ def test_mae_loss(audio):
     assert rel_err(dpred.cpu(), pr.grad.reshape(B * L, P)) < 4e-3
 
 
-@pytest.mark.parametrize("N", [4, 6, 64, 130])
+@pytest.mark.parametrize("N", [4, 6, 64, 130, 512])          # 512 = 8 ranks x batch 64: the [WB, WB] logits of BASELINE configs[2]
 def test_infonce(N):
     o = ops()
     from oracle import ref_cpu
