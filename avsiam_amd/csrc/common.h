@@ -143,6 +143,9 @@ struct AvsTuning {
     int ln_dma;            // 1: LayerNorm backward by the LDS-DMA kernel where it applies | 0 never | 2 automatic per launch context
                            // (avs_layernorm_bwd's `busy_lds` hint)                                                  AVSIAM_LN_DMA
     int ln_rpw;            // rows per wave of the LayerNorm backward: 0 automatic | 4 | 8 | 16                      AVSIAM_LN_RPW
+    int gemm_ring;         // small forward / input-gradient GEMMs (128 x 128 tiling, at most one workgroup per CU): 0 the two-buffer kernel | 1 the
+                           // 4-slot LDS-DMA ring kernel (three K-slabs in flight) | 2 (default) also: under half the CUs -> every row as 64 x 128
+                           // half-height tiles (twice the workgroups).  Bitwise the same results in every setting          AVSIAM_GEMM_RING
     int attn_ring;         // 1: attention forward / dQ with the K/V tiles by LDS-DMA ring (hd 32 / 64) | 0 (default): register-staged kernels -
                            // bitwise the same results, measured neutral to slower                     AVSIAM_ATTN_RING
 };

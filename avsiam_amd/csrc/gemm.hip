@@ -756,6 +756,114 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Small problems (round 5): when the 128 x 128 tiling gives at most one workgroup per CU, gemm_nt_kernel<., 2, 4> is a chain of load
+// latencies - one K-slab in flight, a full drain and a barrier per K-step, nothing else resident on the CU to hide them: a 2 048-row x 768
+// GEMM of the reference's batch-4 step takes 26 us for 12 K-steps of 0.25 us of MFMA work each (profiles/r05/b4_kernel_stats.csv).
+// This kernel keeps NS - 1 = 3 K-slabs in flight: a ring of NS slots of [A 128 x 64 | B 128 x 64] (32 KiB each), LDS-DMA with counted
+// vmcnt, ONE raw barrier per K-step, fragment reads in inline asm (a compiler-visible ds_read behind a pending LDS-DMA drains the ring).
+// One tile per workgroup (the grid is at most the CU count by construction), same LDS image, fragments, MFMA order and epilogue as
+// gemm_nt_kernel<., 2, 4>: bitwise the same results.
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_nt_ring_kernel(GemmNtArgs a) {
+    constexpr int NT = 256, NWN = 2, MI = 4, NS = 4;
+    constexpr int TBM = 128, TBN = 128;
+    constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, SLOT = A_BYTES + B_BYTES;
+    constexpr int CA = TBM * 8 / NT, CB = TBN * 8 / NT;      // 4 + 4 LDS-DMA instructions per thread and K-slab
+    constexpr int DPT = CA + CB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];            // NS slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int nt_n = a.N / TBN;
+    const int ntiles = ((a.M + TBM - 1) / TBM) * nt_n;
+    const int v = blockIdx.x;
+    if (v >= ntiles) return;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int off_k0 = fr * 128 + (((0 + fq) ^ (lane & 7)) << 4);
+    const int off_k1 = fr * 128 + (((4 + fq) ^ (lane & 7)) << 4);
+    const int nk = a.K / BK;
+    const int wg = xcd_remap(v, ntiles);
+    const int m0 = (wg / nt_n) * TBM, n0 = (wg % nt_n) * TBN;
+    const bf16_t* srcA[CA];
+    const bf16_t* srcB[CB];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
+        srcA[i] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int p = i * NT + tid, row = p >> 3, c = (p & 7) ^ (row & 7);
+        srcB[i] = (m0 >= a.m_split ? a.B2 : a.B) + (size_t)(n0 + row) * a.ldb + c * 8;
+    }
+    auto stage = [&](int slot, int k0) {
+        char* sa = smem + slot * SLOT;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < CA; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcA[i] + k0), (LDS_AS void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(srcB[i] + k0), (LDS_AS void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) stage(t, t * BK);
+
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned lds_base = (unsigned)(size_t)(LDS_AS const char*)smem;
+    const unsigned la = lds_base + wm * (MI * 16) * 128, lb = lds_base + A_BYTES + wn * 64 * 128;
+    int slot = 0;
+    for (int t = 0; t < nk; ++t) {
+        // K-slab t has landed (this wave's share; the barrier covers the others'); the slabs requested behind it stay in flight
+        const int ahead = min(NS - 2, nk - 1 - t);
+        if (ahead == 2) wait_vm<2 * DPT>();
+        else if (ahead == 1) wait_vm<DPT>();
+        else wait_vm<0>();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // ... and every wave is done reading slab t - 1, whose slot slab t + NS - 1 takes
+        asm volatile("" ::: "memory");
+        if (t + NS - 1 < nk) stage(slot == 0 ? NS - 1 : slot - 1, (t + NS - 1) * BK);
+        const unsigned va0 = la + slot * SLOT + off_k0, va1 = la + slot * SLOT + off_k1;
+        const unsigned vb0 = lb + slot * SLOT + off_k0, vb1 = lb + slot * SLOT + off_k1;
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        bf16x8 wf[2][4], xf[2][4];
+#define NTR_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF) : "memory")
+        NTR_RD(wf[0][0], vb0, 0); NTR_RD(wf[0][1], vb0, 2048); NTR_RD(wf[0][2], vb0, 4096); NTR_RD(wf[0][3], vb0, 6144);
+        NTR_RD(xf[0][0], va0, 0); NTR_RD(xf[0][1], va0, 2048); NTR_RD(xf[0][2], va0, 4096); NTR_RD(xf[0][3], va0, 6144);
+        NTR_RD(wf[1][0], vb1, 0); NTR_RD(wf[1][1], vb1, 2048); NTR_RD(wf[1][2], vb1, 4096); NTR_RD(wf[1][3], vb1, 6144);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");       // the kk = 0 fragments (the first eight reads)
+        __builtin_amdgcn_sched_barrier(0);
+        NTR_RD(xf[1][0], va1, 0); NTR_RD(xf[1][1], va1, 2048); NTR_RD(xf[1][2], va1, 4096); NTR_RD(xf[1][3], va1, 6144);
+#undef NTR_RD
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ni], xf[0][mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ni], xf[1][mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    const int em = m0 + wm * (MI * 16), en = n0 + wn * 64;
+    __syncthreads();                                       // every wave is done with the ring; nothing is in flight (the last wait was vmcnt(0))
+    nt_epilogue_stage_bias(a, smem, wave, lane, em, en);
+    EpiPrefetch<MI> pf;
+    nt_epilogue_prefetch<ACT, MI>(a, pf, lane, em, en);
+    nt_epilogue<ACT, MI>(a, acc, pf, smem, wave, lane, em, en);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // wgrad.  Both operands are row-major with the CONTRACTION index (token row m) as the slow dimension, so the
 // MFMA fragments (8 consecutive k per lane) are columns of the staged tiles: they are read with the gfx950
 // transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, lane i receives column i).
@@ -1094,9 +1202,11 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
                              (const void*)gemm_nt8_kernel<0, 0, 4, 3>, (const void*)gemm_nt8_kernel<1, 0, 4, 3>, (const void*)gemm_nt8_kernel<2, 0, 4, 3>};
         for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(k8[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         const void* small_k[3] = {(const void*)gemm_nt_kernel<0, 2, 4>, (const void*)gemm_nt_kernel<1, 2, 4>, (const void*)gemm_nt_kernel<2, 2, 4>};
+        const void* ring_k[3] = {(const void*)gemm_nt_ring_kernel<0>, (const void*)gemm_nt_ring_kernel<1>, (const void*)gemm_nt_ring_kernel<2>};
         for (int i = 0; i < 3 && e == hipSuccess; ++i) {
             e = hipFuncSetAttribute(big_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             if (e == hipSuccess) e = hipFuncSetAttribute(small_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            if (e == hipSuccess) e = hipFuncSetAttribute(ring_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         }
         if (e != hipSuccess) {
             avs_set_error("gemm_nt: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1106,6 +1216,25 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     }
     auto launch_small = [&](const GemmNtArgs& x) {
         const int nwg = ceil_div(x.M, BM) * (x.N / BN);
+        // fewer workgroups than half the CUs: every row as HALF-height (64 x 128) tiles of the same kernel - twice the workgroups on CUs
+        // that would idle (a CU fills its LDS at ~60 GB/s: the 32 KiB K-slab of a 128 x 128 tile takes 0.55 us against 0.25 us of MFMA
+        // work, so small GEMMs are bound by how many CUs pull, profiles/r05/small_gemm_ab.log); bitwise the full tiles' results
+        if (avs_tuning().gemm_ring == 2 && 2 * nwg <= avs_persistent_slots() && x.m_full >= x.M) {
+            GemmNtArgs h = x;
+            h.m_full = 0;
+            const int nh = ceil_div(x.M, BM / 2) * (x.N / BN);
+            if (act == 0) gemm_nt_kernel<0, 2, 4><<<nh, 256, 65536, stream>>>(h);
+            else if (act == 1) gemm_nt_kernel<1, 2, 4><<<nh, 256, 65536, stream>>>(h);
+            else gemm_nt_kernel<2, 2, 4><<<nh, 256, 65536, stream>>>(h);
+            return;
+        }
+        // at most one workgroup per CU: the ring kernel keeps three K-slabs in flight instead of one
+        if (avs_tuning().gemm_ring && nwg <= avs_persistent_slots() && x.K >= 256 && x.m_full >= x.M) {
+            if (act == 0) gemm_nt_ring_kernel<0><<<nwg, 256, 131072, stream>>>(x);
+            else if (act == 1) gemm_nt_ring_kernel<1><<<nwg, 256, 131072, stream>>>(x);
+            else gemm_nt_ring_kernel<2><<<nwg, 256, 131072, stream>>>(x);
+            return;
+        }
         if (act == 0) gemm_nt_kernel<0, 2, 4><<<nwg, 256, 65536, stream>>>(x);
         else if (act == 1) gemm_nt_kernel<1, 2, 4><<<nwg, 256, 65536, stream>>>(x);
         else gemm_nt_kernel<2, 2, 4><<<nwg, 256, 65536, stream>>>(x);

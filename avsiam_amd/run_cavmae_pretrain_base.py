@@ -147,13 +147,17 @@ def _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train):
         # The optimizer: the loop saves the FIRST optimizer's state beside the weights (best_optim_state.pth, as traintest_cavmae_base.py:230);
         # when that file sits beside the checkpoint, Adam #1 continues from it (moments and step count).  Adam #2's state is not saved by the
         # reference's loop either, so the MAE pass's moments restart - without the file this is a weights-only warm start, and says so.
-        from .param_spec import P1
+        from .param_spec import P1, P2
         opt_path = os.path.join(os.path.dirname(args.pretrain_path), 'best_optim_state.pth')
         if os.path.exists(opt_path):
             audio_model.to(torch.device("cuda", getattr(args, "gpu", 0)))      # (the optimizer state lives beside the weights; train() keeps this device)
             audio_model.load_optimizer_state_dict(P1, torch.load(opt_path, map_location='cpu'))
-            print('restored the state of optimizer 1 (Adam moments, step {:d}) from {:s}; optimizer 2 restarts'
-                  .format(audio_model._opt_state[P1]['step'], opt_path))
+            opt2 = os.path.join(os.path.dirname(args.pretrain_path), 'best_optim_state_2.pth')     # written by this loop, not by the reference's
+            if os.path.exists(opt2):
+                audio_model.load_optimizer_state_dict(P2, torch.load(opt2, map_location='cpu'))
+            print('restored the state of optimizer 1 (Adam moments, step {:d}) from {:s}; optimizer 2 {}'
+                  .format(audio_model._opt_state[P1]['step'], opt_path,
+                          'too (step {:d})'.format(audio_model._opt_state[P2]['step']) if os.path.exists(opt2) else 'restarts'))
         else:
             print('no best_optim_state.pth beside the checkpoint: weights-only warm start (both Adam states restart, bias correction from step 1)')
         from . import engine as _engine

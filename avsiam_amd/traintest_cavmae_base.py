@@ -194,6 +194,8 @@ def train(audio_model, train_sampler, test_loader, test_sampler, train_loader_li
             if best_epoch == epoch:
                 _save_checkpoint(audio_model, "%s/models/best_audio_model.pth" % exp_dir)
                 torch.save(audio_model.optimizer_state_dict(P1, lr), "%s/models/best_optim_state.pth" % exp_dir)    # the first optimizer, as :230
+                # (extension: the reference saves only optimizer 1; with the second one beside it --pretrain_path is a full resume)
+                torch.save(audio_model.optimizer_state_dict(P2, lr), "%s/models/best_optim_state_2.pth" % exp_dir)
             if getattr(args, "save_model", False):
                 _save_checkpoint(audio_model, "%s/models/audio_model.%d.pth" % (exp_dir, epoch))
         if epoch in milestones:

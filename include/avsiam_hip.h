@@ -34,6 +34,8 @@ int avs_device_cu_count(void);
  *   "cu_reserve" compute units EVERY persistent kernel (nt / fp8 nt / tn8 / tn8f grids and split factors) leaves free, a multiple of 8
  *                keeps the XCDs balanced; 0 on one GPU, 8 when a gradient all-reduce overlaps the backward (src/traintest_cavmae_base.py:58-59
  *                is DDP's overlap; RCCL's kernels need CUs WHILE a GEMM runs)
+ *   "gemm_ring" 0 | 1 | 2 (default): small forward / input-gradient GEMMs (at most one 128 x 128 workgroup per CU) on the two-buffer kernel | the
+ *               4-slot LDS-DMA ring kernel | the ring kernel, and 64 x 128 half-height tiles when even those fill less than half the CUs
  *   "ln_dma" 0 | 1    "ln_rpw" 0 auto | 4 | 8 | 16    "attn_ring" 0 (default) | 1 (attention forward / dQ with K/V tiles by LDS-DMA ring: same bits, not faster)
  * avs_persistent_cu_slots(): the CUs a persistent grid fills now (device CUs - cu_reserve). */
 int avs_tuning_set(const char* name, int value);

@@ -232,7 +232,7 @@ def test_entry_point_main_runs_two_steps(tmp_path, capsys):
     out = capsys.readouterr().out
     assert "Not using distributed mode" in out and "Epoch: [1][0/2]" in out and "Eval Total Loss" in out and "training diverged" not in out
     for f in ("args.json", "args.pkl", "result.csv", "progress.pkl", "models/audio_model.1.pth", "models/best_audio_model.pth",
-              "models/best_optim_state.pth"):
+              "models/best_optim_state.pth", "models/best_optim_state_2.pth"):
         assert (exp / f).exists(), f
     res = np.loadtxt(exp / "result.csv", delimiter=",").reshape(1, 10)
     assert np.isfinite(res).all() and res[0, 3] > 0 and res[0, 7] > 0
@@ -248,6 +248,7 @@ def test_entry_point_main_runs_two_steps(tmp_path, capsys):
         out = capsys.readouterr().out
         assert "restored the state of optimizer 1" in out and "missing keys: 0, unexpected keys: 0" in out
         assert resumed._opt_state[P1]["step"] == model._opt_state[P1]["step"] + 1 == 3          # 2 steps of the first run + 1
+        assert resumed._opt_state[P2]["step"] == 3 and "optimizer 2 too" in out                 # (this loop saves the second optimizer beside the first)
         foreign = tmp_path / "foreign.pth"
         torch.save({"encoder.layer.0.weight": torch.zeros(3)}, foreign)
         with pytest.raises(SystemExit, match="not a checkpoint of this model"):

@@ -200,6 +200,56 @@ def test_gemm_nt_epilogues(M, N, K):
     assert rel_err(csum, 1 + want.sum(0)) < 2e-3                  # fused column sum (bias gradient), accumulated
 
 
+@pytest.mark.parametrize("M,N,K", [(708, 768, 768), (1979, 2304, 768), (2832, 512, 2048), (333, 256, 256), (2048, 768, 3072), (130, 3072, 768)])
+def test_gemm_nt_ring_kernel_for_small_problems_matches_the_two_buffer_kernel(M, N, K):
+    """gemm_nt_ring_kernel (round 5: the forward / input-gradient GEMMs of small batches - at most one 128 x 128 workgroup per CU - keep three
+    K-slabs in flight in a 4-slot LDS-DMA ring instead of one) against gemm_nt_kernel<., 2, 4>: same tiles, fragments, MFMA order and
+    epilogue, so every epilogue variant must be BITWISE equal - bf16 out with column scale, fp32 out + residual, the GELU pair, the GELU'
+    input gradient with its fused column sum (to the order of the fp32 atomics), and two weight sets in one launch.  Three repetitions with
+    other traffic in between as a race screen of the ring's counted waits.  Shapes: the reference's batch-4 step (708 / 1979 / 2832 rows)."""
+    from avsiam_amd import _lib
+    o = ops()
+    A = bf(torch.randn(M, K, device=DEV))
+    W = bf(torch.randn(N, K, device=DEV) * 0.05)
+    W2 = bf(torch.randn(N, K, device=DEV) * 0.05)
+    bias, bias2 = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV)
+    split = 256 if M > 512 else 0
+
+    def run():
+        out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        o.gemm_nt(A, W, out, M, bias=bias, scale_cols=(N // 128) * 64, col_scale=0.25)
+        outf = torch.zeros(M, N, device=DEV)
+        o.gemm_nt(A, W, outf, M, bias=bias, res=res)
+        pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        act = torch.zeros_like(pre)
+        o.gemm_nt(A, W, pre, M, bias=bias, out2=act, act=1)
+        dpre = torch.zeros_like(pre)
+        cs = torch.zeros(N, device=DEV)
+        o.gemm_nt(A, W, dpre, M, aux=pre, act=2, colsum=cs)
+        outs = [out, outf, pre, act, dpre]
+        if split:
+            d = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+            o.gemm_nt(A, W, d, M, bias=bias, dual=(split, W2, bias2, None))
+            outs.append(d)
+        return outs, cs
+
+    try:
+        _lib.tuning_set("gemm_ring", 0)
+        want, wcs = run()
+        for rep in range(4):
+            _lib.tuning_set("gemm_ring", 1 if rep < 2 else 2)          # 2: half-height tiles for the shapes under half the CUs, else the ring
+            got, gcs = run()
+            for i, (g, w) in enumerate(zip(got, want)):
+                assert torch.equal(g, w), (i, rep, float((g.float() - w.float()).abs().max()))
+            assert rel_err(gcs, wcs) < 1e-5
+            torch.zeros(32 << 20, device=DEV).add_(1.0)
+    finally:
+        _lib.tuning_set("gemm_ring", 2)
+    ref = A.double() @ W.double().t() + bias.double()
+    assert rel_err(want[1], ref + res.double()) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(33000, 768, 256), (70001, 512, 2048), (95630, 768, 768), (66000, 256, 128), (40001, 512, 192),
                                    (158208, 2048, 512)])
 def test_gemm_nt_8phase_matches_two_buffer_kernel(M, N, K):
