@@ -763,10 +763,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(GemmNtArgs a) {
 // vmcnt, ONE raw barrier per K-step, fragment reads in inline asm (a compiler-visible ds_read behind a pending LDS-DMA drains the ring).
 // One tile per workgroup (the grid is at most the CU count by construction), same LDS image, fragments, MFMA order and epilogue as
 // gemm_nt_kernel<., 2, 4>: bitwise the same results.
-template <int ACT>
+// MI = 4: 128 x 128 tiles; MI = 2: 64 x 128 tiles (24 KiB slots) for problems that would otherwise fill less than half the CUs.
+template <int ACT, int MI = 4>
 __global__ __launch_bounds__(256) void gemm_nt_ring_kernel(GemmNtArgs a) {
-    constexpr int NT = 256, NWN = 2, MI = 4, NS = 4;
-    constexpr int TBM = 128, TBN = 128;
+    constexpr int NT = 256, NWN = 2, NS = 4;
+    constexpr int TBM = 2 * MI * 16, TBN = 128;
     constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, SLOT = A_BYTES + B_BYTES;
     constexpr int CA = TBM * 8 / NT, CB = TBN * 8 / NT;      // 4 + 4 LDS-DMA instructions per thread and K-slab
     constexpr int DPT = CA + CB;
@@ -831,14 +832,16 @@ __global__ __launch_bounds__(256) void gemm_nt_ring_kernel(GemmNtArgs a) {
         const unsigned va0 = la + slot * SLOT + off_k0, va1 = la + slot * SLOT + off_k1;
         const unsigned vb0 = lb + slot * SLOT + off_k0, vb1 = lb + slot * SLOT + off_k1;
         slot = slot + 1 == NS ? 0 : slot + 1;
-        bf16x8 wf[2][4], xf[2][4];
+        bf16x8 wf[2][4], xf[2][MI];
 #define NTR_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "i"(OFF) : "memory")
         NTR_RD(wf[0][0], vb0, 0); NTR_RD(wf[0][1], vb0, 2048); NTR_RD(wf[0][2], vb0, 4096); NTR_RD(wf[0][3], vb0, 6144);
-        NTR_RD(xf[0][0], va0, 0); NTR_RD(xf[0][1], va0, 2048); NTR_RD(xf[0][2], va0, 4096); NTR_RD(xf[0][3], va0, 6144);
+        NTR_RD(xf[0][0], va0, 0); NTR_RD(xf[0][1], va0, 2048);
+        if constexpr (MI == 4) { NTR_RD(xf[0][2], va0, 4096); NTR_RD(xf[0][3], va0, 6144); }
         NTR_RD(wf[1][0], vb1, 0); NTR_RD(wf[1][1], vb1, 2048); NTR_RD(wf[1][2], vb1, 4096); NTR_RD(wf[1][3], vb1, 6144);
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");       // the kk = 0 fragments (the first eight reads)
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");       // the kk = 0 fragments (everything but the last four reads)
         __builtin_amdgcn_sched_barrier(0);
-        NTR_RD(xf[1][0], va1, 0); NTR_RD(xf[1][1], va1, 2048); NTR_RD(xf[1][2], va1, 4096); NTR_RD(xf[1][3], va1, 6144);
+        NTR_RD(xf[1][0], va1, 0); NTR_RD(xf[1][1], va1, 2048);
+        if constexpr (MI == 4) { NTR_RD(xf[1][2], va1, 4096); NTR_RD(xf[1][3], va1, 6144); }
 #undef NTR_RD
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1203,6 +1206,8 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
         for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(k8[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         const void* small_k[3] = {(const void*)gemm_nt_kernel<0, 2, 4>, (const void*)gemm_nt_kernel<1, 2, 4>, (const void*)gemm_nt_kernel<2, 2, 4>};
         const void* ring_k[3] = {(const void*)gemm_nt_ring_kernel<0>, (const void*)gemm_nt_ring_kernel<1>, (const void*)gemm_nt_ring_kernel<2>};
+        const void* ring_h[3] = {(const void*)gemm_nt_ring_kernel<0, 2>, (const void*)gemm_nt_ring_kernel<1, 2>, (const void*)gemm_nt_ring_kernel<2, 2>};
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipFuncSetAttribute(ring_h[i], hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
         for (int i = 0; i < 3 && e == hipSuccess; ++i) {
             e = hipFuncSetAttribute(big_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
             if (e == hipSuccess) e = hipFuncSetAttribute(small_k[i], hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -1220,9 +1225,15 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
         // that would idle (a CU fills its LDS at ~60 GB/s: the 32 KiB K-slab of a 128 x 128 tile takes 0.55 us against 0.25 us of MFMA
         // work, so small GEMMs are bound by how many CUs pull, profiles/r05/small_gemm_ab.log); bitwise the full tiles' results
         if (avs_tuning().gemm_ring == 2 && 2 * nwg <= avs_persistent_slots() && x.m_full >= x.M) {
+            const int nh = ceil_div(x.M, BM / 2) * (x.N / BN);
+            if (x.K >= 256) {                  // ... of the ring kernel (three K-slabs in flight)
+                if (act == 0) gemm_nt_ring_kernel<0, 2><<<nh, 256, 98304, stream>>>(x);
+                else if (act == 1) gemm_nt_ring_kernel<1, 2><<<nh, 256, 98304, stream>>>(x);
+                else gemm_nt_ring_kernel<2, 2><<<nh, 256, 98304, stream>>>(x);
+                return;
+            }
             GemmNtArgs h = x;
             h.m_full = 0;
-            const int nh = ceil_div(x.M, BM / 2) * (x.N / BN);
             if (act == 0) gemm_nt_kernel<0, 2, 4><<<nh, 256, 65536, stream>>>(h);
             else if (act == 1) gemm_nt_kernel<1, 2, 4><<<nh, 256, 65536, stream>>>(h);
             else gemm_nt_kernel<2, 2, 4><<<nh, 256, 65536, stream>>>(h);
