@@ -326,6 +326,8 @@ def test_recompute_matches_saved_activations(which):
                 assert all(st.act[0] is st.act[st.nrecomp - 1] and st.act[st.nrecomp] is not st.act[0] for st in stacks)
     finally:
         engine.RECOMPUTE = "0"
+        from avsiam_amd import _lib
+        _lib.tuning_set("cu_reserve", 0)          # (the counting communicator is "active": set_distributed reserved CUs for collectives, process-wide)
     for r in res[1:]:
         assert res[0][0] == r[0]
         assert res[0][1].keys() == r[1].keys() and len(r[1]) > 100
