@@ -148,6 +148,8 @@ struct AvsTuning {
                            // half-height tiles (twice the workgroups).  Bitwise the same results in every setting          AVSIAM_GEMM_RING
     int attn_ring;         // 1: attention forward / dQ with the K/V tiles by LDS-DMA ring (hd 32 / 64) | 0 (default): register-staged kernels -
                            // bitwise the same results, measured neutral to slower                     AVSIAM_ATTN_RING
+    int nt_big_min;        // forward / input-gradient GEMMs with at least this many 256^2 output tiles run the persistent 256^2 kernels, smaller
+                           // ones the 128 x 128 kernels; 0 (default): half the persistent slots                      AVSIAM_NT_BIG_MIN
 };
 AvsTuning& avs_tuning();
 extern "C" int avs_tuning_set(const char* name, int value);

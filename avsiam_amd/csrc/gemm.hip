@@ -1193,10 +1193,14 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M,
                  m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
-    // 256^2 tiles once they alone give every CU at least one workgroup; otherwise 128^2 (4x the workgroups)
+    // 256^2 tiles once they give half the CUs a workgroup; otherwise 128^2 (4x the workgroups, two per CU).  Rounds 1 - 4 asked for 224 tiles; between
+    // 128 and 224 the 128^2 tiling needs 512 ... 896 workgroups = a second round on 512 slots, and the persistent kernel on a part of the chip
+    // runs at a higher clock: 135 tiles, K = 3072: 78.1 -> 63.8 us, K = 768: 25.8 -> 23.5; 192 tiles: 80.9 -> 68.9, 28.4 -> 25.7; under
+    // 128 tiles the 128^2 tiling fits one round and wins (96 tiles: 48.2 against 62.1 us) - tools/bench_nt_midsize.py, profiles/r05/nt_midsize.log
     const int force = g_force_tile;
     const int big_tiles = ceil_div(M, 256) * (N / 256);
-    const bool big = force == 256 ? (N % 256) == 0 : force == 128 ? false : ((N % 256) == 0 && big_tiles >= 224);
+    const int big_min = avs_tuning().nt_big_min > 0 ? avs_tuning().nt_big_min : avs_persistent_slots() / 2;
+    const bool big = force == 256 ? (N % 256) == 0 : force == 128 ? false : ((N % 256) == 0 && big_tiles >= big_min);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipSuccess;

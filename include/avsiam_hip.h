@@ -36,6 +36,8 @@ int avs_device_cu_count(void);
  *                is DDP's overlap; RCCL's kernels need CUs WHILE a GEMM runs)
  *   "gemm_ring" 0 | 1 | 2 (default): small forward / input-gradient GEMMs (at most one 128 x 128 workgroup per CU) on the two-buffer kernel | the
  *               4-slot LDS-DMA ring kernel | the ring kernel, and 64 x 128 half-height tiles when even those fill less than half the CUs
+ *   "nt_big_min" forward / input-gradient GEMMs with at least this many 256 x 256 output tiles run the persistent 256^2 kernels, smaller ones the
+ *               128 x 128 kernels; 0 (default) = half the persistent CU slots
  *   "ln_dma" 0 | 1    "ln_rpw" 0 auto | 4 | 8 | 16    "attn_ring" 0 (default) | 1 (attention forward / dQ with K/V tiles by LDS-DMA ring: same bits, not faster)
  * avs_persistent_cu_slots(): the CUs a persistent grid fills now (device CUs - cu_reserve). */
 int avs_tuning_set(const char* name, int value);

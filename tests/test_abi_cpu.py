@@ -67,7 +67,7 @@ def test_tuning_knobs_are_set_through_the_abi_only(lib_path):
             _lib.tuning_set("nt_tile_h", 100)
         with pytest.raises(_lib.AvsiamHipError):
             _lib.tuning_set("no_such_knob", 1)
-        for k in ("gemm_tile", "gemm_persistent", "gemm_nt8", "nt_tile_h", "nt_grid", "ln_dma", "ln_rpw", "attn_ring"):
+        for k in ("gemm_tile", "gemm_persistent", "gemm_nt8", "nt_tile_h", "nt_grid", "ln_dma", "ln_rpw", "attn_ring", "nt_big_min"):
             _lib.tuning_get(k)
     finally:
         _lib.tuning_set("cu_reserve", 0)

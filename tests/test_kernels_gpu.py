@@ -250,6 +250,50 @@ def test_gemm_nt_ring_kernel_for_small_problems_matches_the_two_buffer_kernel(M,
     assert rel_err(want[1], ref + res.double()) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(11328, 768, 3072), (16384, 768, 768), (11328, 768, 2304), (9000, 1024, 512)])
+def test_gemm_nt_midsize_problems_agree_across_kernel_families(M, N, K):
+    """128 ... 224 output tiles of 256^2 (the reference's one-frame shapes at batch 64: 11 328 rows): since round 5 these run the persistent 256^2
+    kernel on a part of the chip instead of 128 x 128 tiles in two rounds (knob nt_big_min, default half the CU slots).  Both families accumulate
+    K in the same order with the same per-element epilogue arithmetic, so every epilogue variant is BITWISE the same whichever side of the
+    threshold a problem falls on (column sums: to the order of the fp32 atomics)."""
+    from avsiam_amd import _lib
+    o = ops()
+    A = bf(torch.randn(M, K, device=DEV))
+    W = bf(torch.randn(N, K, device=DEV) * 0.05)
+    W2 = bf(torch.randn(N, K, device=DEV) * 0.05)
+    bias, bias2 = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+    res = torch.randn(M, N, device=DEV)
+
+    def run():
+        out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        o.gemm_nt(A, W, out, M, bias=bias, scale_cols=(N // 128) * 64, col_scale=0.25)
+        outf = torch.zeros(M, N, device=DEV)
+        o.gemm_nt(A, W, outf, M, bias=bias, res=res)
+        pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        act = torch.zeros_like(pre)
+        o.gemm_nt(A, W, pre, M, bias=bias, out2=act, act=1)
+        dpre = torch.zeros_like(pre)
+        cs = torch.zeros(N, device=DEV)
+        o.gemm_nt(A, W, dpre, M, aux=pre, act=2, colsum=cs)
+        d = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        o.gemm_nt(A, W, d, M, bias=bias, dual=(4096, W2, bias2, None))
+        return [out, outf, pre, act, dpre, d], cs
+
+    try:
+        _lib.tuning_set("nt_big_min", 1 << 20)         # 128 x 128 kernels
+        want, wcs = run()
+        for big_min in (0, 1):                          # the default threshold; the persistent kernel whatever the tile count
+            _lib.tuning_set("nt_big_min", big_min)
+            got, gcs = run()
+            for i, (g, w) in enumerate(zip(got, want)):
+                assert torch.equal(g, w), (i, big_min, float((g.float() - w.float()).abs().max()))
+            assert rel_err(gcs, wcs) < 1e-5
+    finally:
+        _lib.tuning_set("nt_big_min", 0)
+    ref = A.double() @ W.double().t() + bias.double()
+    assert rel_err(want[1], ref + res.double()) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(33000, 768, 256), (70001, 512, 2048), (95630, 768, 768), (66000, 256, 128), (40001, 512, 192),
                                    (158208, 2048, 512)])
 def test_gemm_nt_8phase_matches_two_buffer_kernel(M, N, K):
