@@ -27,10 +27,18 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tag", default="")
     ap.add_argument("--stream", choices=("fp32", "bf16"), default="bf16", help="residual-gradient stream of the backward (engine.GRAD_STREAM)")
+    ap.add_argument("--shapes", default="", help="name:rows:D:calls,... instead of the ViT-B step (ViT-H/14: p1:51456:1280:64,tow:51456:1280:62,dec:205888:512:16)")
+    ap.add_argument("--dma", type=int, default=-1, help="knob ln_dma for this run: 0 register kernel | 1 LDS-DMA, one row ahead | 2 two rows ahead")
     args = ap.parse_args()
+    if args.dma >= 0:
+        from avsiam_amd import _lib
+        _lib.tuning_set("ln_dma", args.dma)
     dev = "cuda"
     tot = 0.0
-    for name, rows, D, calls in (("p1", 95630, 768, 24), ("video", 31360, 768, 22), ("audio", 8192, 768, 22), ("mm", 39552, 768, 4), ("dec", 158208, 512, 16)):
+    shapes = (("p1", 95630, 768, 24), ("video", 31360, 768, 22), ("audio", 8192, 768, 22), ("mm", 39552, 768, 4), ("dec", 158208, 512, 16))
+    if args.shapes:
+        shapes = tuple((n, int(r), int(d), int(c)) for n, r, d, c in (t.split(":") for t in args.shapes.split(",")))
+    for name, rows, D, calls in shapes:
         rp = ops.pad_rows(rows, 128)
         x, dres, dx = (torch.randn(rp, D, device=dev) for _ in range(3))
         dy = torch.randn(rp, D, device=dev).to(BF16)
