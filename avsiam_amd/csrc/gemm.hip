@@ -117,7 +117,10 @@ struct EpiPrefetch {
     static constexpr int RG = 1;                 // residual: 16 rows per group      (4 float4 per 16 rows -> 16 VGPRs / group)
     static constexpr int AG = MI < 4 ? MI : 4;                 // GELU' aux: 4 x 16 rows per group, single-buffered (32 VGPRs; a second
                                                  // buffer spills next to the 128 accumulator registers and costs more than it hides)
-    f32x4 rs[2][RG][4];                          // [buffer][16-row block][row quad]   (ext vectors: HIP's float4/uint4
+    static constexpr int NB = 3;                 // residual buffers: NB - 1 groups in flight while one is transposed and stored (two buffers until round
+                                                 // 5; the third is worth 2 - 4 % on the K = 512 / 768 residual GEMMs, a fourth spills; the epilogue is bound
+                                                 // by what a CU can read from HBM, ~15 - 25 GB/s, not by round trips: DESIGN.md 5e item 13)
+    f32x4 rs[NB][RG][4];                         // [buffer][16-row block][row quad]   (ext vectors: HIP's float4/uint4
     u32x4 ax[AG][2];                             //  structs in arrays end up in scratch)
 };
 
@@ -163,7 +166,10 @@ __device__ __forceinline__ void epi_load_aux(const GemmNtArgs& a, u32x4 (&ax)[Ep
 // group 0 of whatever this epilogue will read; called before the barrier that ends the main loop
 template <int ACT, int MI>
 __device__ __forceinline__ void nt_epilogue_prefetch(const GemmNtArgs& a, EpiPrefetch<MI>& pf, int lane, int mw0, int nw0) {
-    if (ACT == 0 && a.out_f32 && a.res) epi_load_res<MI>(a, pf.rs[0], 0, lane, mw0, nw0);
+    if (ACT == 0 && a.out_f32 && a.res) {
+#pragma unroll
+        for (int g = 0; g < EpiPrefetch<MI>::NB - 1 && g < MI / EpiPrefetch<MI>::RG; ++g) epi_load_res<MI>(a, pf.rs[g], g, lane, mw0, nw0);
+    }
 }
 
 // called by the kernels BEFORE they put the next tile's LDS-DMAs in flight: the one global load of the bias path is then
@@ -196,11 +202,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
         const int n = nw0 + cc;
         float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 68);
         const float* sbias = reinterpret_cast<const float*>(smem) + (blockDim.x >> 6) * (16 * 68) + wave * 64;
-        constexpr int RG = EpiPrefetch<MI>::RG, NG = MI / RG;
+        constexpr int RG = EpiPrefetch<MI>::RG, NG = MI / RG, NB = EpiPrefetch<MI>::NB;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g * RG * 16 >= nrow) continue;
-            if (a.res && g + 1 < NG) epi_load_res<MI>(a, pf.rs[(g + 1) & 1], g + 1, lane, mw0, nw0);
+            if (a.res && g + NB - 1 < NG) epi_load_res<MI>(a, pf.rs[(g + NB - 1) % NB], g + NB - 1, lane, mw0, nw0);
 #pragma unroll
             for (int mj = 0; mj < RG; ++mj) {
                 const int mi = g * RG + mj;
@@ -216,7 +222,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     if (m >= a.M) continue;
                     float v[4] = {t.x, t.y, t.z, t.w};
                     const float4 bias4 = *reinterpret_cast<const float4*>(sbias + cc);
-                    epi_apply4(alpha, 0, v, bias4, make_uint2(0, 0), a.res != nullptr, pf.rs[g & 1][mj][i]);
+                    epi_apply4(alpha, 0, v, bias4, make_uint2(0, 0), a.res != nullptr, pf.rs[g % NB][mj][i]);
                     NT_STORE(reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + (size_t)m * a.ldo + n), (f32x4{v[0], v[1], v[2], v[3]}));
                 }
             }
