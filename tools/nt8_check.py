@@ -31,12 +31,15 @@ def main():
             e1 = (outf - ref - res).abs().max().item()
             pre = torch.zeros(M, N, device=dev, dtype=torch.bfloat16); act = torch.zeros_like(pre)
             ops.gemm_nt(A, W, pre, M, bias=bias, out2=act, act=1)
-            e2 = (pre.float() - ref).abs().max().item()
+            x = ref.double().requires_grad_(True)                      # act 1 stores gelu'(x) in `out` (since round 3) and gelu(x) in out2
+            g = torch.nn.functional.gelu(x)
+            g.sum().backward()
+            e2 = max((pre.double() - x.grad).abs().max().item(), ((act.double() - g.detach()).abs() / (1 + g.detach().abs())).max().item() * 4)
             dp = torch.zeros_like(pre)
             ops.gemm_nt(A, W, dp, M, aux=pre, act=2)
-            ok = e0 < 0.13 and e1 < 2e-2 and e2 < 0.13 and bool(torch.isfinite(dp.float()).all())
+            ok = e0 < 0.13 and e1 < 2e-2 and e2 < 0.05 and bool(torch.isfinite(dp.float()).all())
             bad += not ok
-            print(f"M={M} N={N} K={K} rep {r}: bf16 {e0:.4f} f32+res {e1:.5f} gelu-pre {e2:.4f} {'ok' if ok else 'BAD'}", flush=True)
+            print(f"M={M} N={N} K={K} rep {r}: bf16 {e0:.4f} f32+res {e1:.5f} gelu pair {e2:.4f} {'ok' if ok else 'BAD'}", flush=True)
     print("FAILED" if bad else "all ok")
     sys.exit(1 if bad else 0)
 
