@@ -1428,6 +1428,42 @@ static int tn_splits(int tiles, int nstages, int slots, double t_stage, double t
     return s < cap ? s : cap;
 }
 
+// Host-side plan of one weight-gradient launch - tile size, split count of the token rows, stages per split - as avs_gemm_tn_bf16 takes it
+// (the knobs gemm_tile / gemm_nt8 / cu_reserve included).  No device work: exported as avs_gemm_tn_plan so that the heuristic is pinned by the
+// CPU test suite against the measured optima of tools/bench_tn_splits.py.
+struct TnPlan { int tile, tiles, splits, stages_per_split; };
+static TnPlan tn_plan(int M, int N1, int N2, int splits) {
+    const int nstages = ceil_div(M, BK);
+    const bool can_big = (N1 % 256) == 0 && (N2 % 256) == 0;
+    // 256^2 tiles need a long contraction to amortise their 256 KiB atomic epilogue per split
+    // ... and enough output tiles that the splits (each adds a full-tile atomic epilogue) stay few
+    // (8-phase kernel: from 12 tiles - the decoder's 1536x512 / 2048x512 gradients gain 14-18 % on it; 9 tiles and fewer lose)
+    const int min_tiles = g_nt8 >= 1 ? 12 : 24;
+    const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256 && (N1 / 256) * (N2 / 256) >= min_tiles);
+    const int T = big ? 256 : 128;
+    const int tiles = (N1 / T) * (N2 / T);
+    if (splits <= 0) {
+        // at most one resident round: 256^2 tiles hold 128 KiB of LDS (1 workgroup per CU), 128^2 tiles 64 KiB (2 per CU).  A grid
+        // slightly LARGER than the resident slots would add a second, almost empty round that doubles the critical path,
+        // so the cap is rounded DOWN (e.g. 27 tiles -> at most 9 splits = 243 workgroups on 256 CUs).
+        const int ncu = avs_persistent_slots();      // CUs a persistent grid may fill (device CUs - the cu_reserve knob)
+        const int slots = big ? ncu : 2 * ncu;
+        splits = tn_splits(tiles, nstages, slots, big ? 1.3 : 0.35, big ? 0.2 : 0.065);
+    }
+    if (splits > nstages) splits = nstages;
+    const int per = ceil_div(nstages, splits);
+    splits = ceil_div(nstages, per);
+    return TnPlan{T, tiles, splits, per};
+}
+
+extern "C" int avs_gemm_tn_plan(int M, int N1, int N2, int* tile, int* splits) {
+    AVS_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0 && (N1 % 128) == 0 && (N2 % 128) == 0 && tile && splits, "gemm_tn_plan: bad arguments M=%d N1=%d N2=%d", M, N1, N2);
+    const TnPlan pl = tn_plan(M, N1, N2, 0);
+    *tile = pl.tile;
+    *splits = pl.splits;
+    return 0;
+}
+
 extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, float* C, long long ldc,
                                 int M, int N1, int N2, int splits, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && (N1 % 128) == 0 && (N2 % 128) == 0, "gemm_tn: need N1%%128==0 and N2%%128==0 (N1=%d N2=%d)", N1, N2);
@@ -1443,26 +1479,10 @@ extern "C" int avs_gemm_tn_bf16(const bf16_t* A, long long lda, const bf16_t* B,
         }
         attr_done = true;
     }
-    const int nstages = ceil_div(M, BK);
-    const bool can_big = (N1 % 256) == 0 && (N2 % 256) == 0;
-    // 256^2 tiles need a long contraction to amortise their 256 KiB atomic epilogue per split
-    // ... and enough output tiles that the splits (each adds a full-tile atomic epilogue) stay few
-    // (8-phase kernel: from 12 tiles - the decoder's 1536x512 / 2048x512 gradients gain 14-18 % on it; 9 tiles and fewer lose)
-    const int min_tiles = g_nt8 >= 1 ? 12 : 24;
-    const bool big = g_force_tile == 256 ? can_big : g_force_tile == 128 ? false : (can_big && nstages >= 256 && (N1 / 256) * (N2 / 256) >= min_tiles);
-    const int T = big ? 256 : 128;
-    const int tiles = (N1 / T) * (N2 / T);
-    if (splits <= 0) {
-        // one resident round: 256^2 tiles hold 128 KiB of LDS (1 workgroup per CU), 128^2 tiles 64 KiB (2 per CU).  A grid
-        // slightly LARGER than the resident slots would add a second, almost empty round that doubles the critical path,
-        // so round the split count DOWN (e.g. 27 tiles -> 9 splits = 243 workgroups on 256 CUs).
-        const int ncu = avs_persistent_slots();      // CUs a persistent grid may fill (device CUs - the cu_reserve knob)
-        const int slots = big ? ncu : 2 * ncu;
-        splits = tn_splits(tiles, nstages, slots, big ? 1.3 : 0.35, big ? 0.2 : 0.065);
-    }
-    if (splits > nstages) splits = nstages;
-    const int per = ceil_div(nstages, splits);
-    splits = ceil_div(nstages, per);
+    TnPlan pl = tn_plan(M, N1, N2, splits);
+    const bool big = pl.tile == 256;
+    const int tiles = pl.tiles, per = pl.stages_per_split;
+    splits = pl.splits;
     GemmTnArgs a{A, lda, B, ldb, C, ldc, M, N1, N2, per};
     if (big && g_nt8 >= 1) {
         GemmTnGroupArgs g{};

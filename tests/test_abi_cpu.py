@@ -81,3 +81,48 @@ def test_missing_library_raises(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libavsiam_hip.so")
     with pytest.raises(_lib.AvsiamHipError):
         _lib.load()
+
+
+# Weight-gradient GEMM time (us, MI355X) against the split count of the token rows: profiles/r05/tn_splits.log (tools/bench_tn_splits.py)
+TN_SPLIT_TIMES = {
+    (2832, 3072, 768): {1: 37.7, 2: 35.6, 3: 35.2, 4: 45.1, 5: 47.6, 7: 57.0},
+    (2832, 768, 768): {1: 31.4, 2: 18.4, 3: 16.1, 4: 15.0, 5: 16.5, 7: 17.3, 9: 21.7, 14: 25.2, 28: 44.5},
+    (11328, 3072, 768): {1: 110.1, 2: 90.9, 3: 69.5, 4: 92.3, 5: 83.1, 7: 86.1},
+    (11328, 768, 768): {1: 110.9, 2: 55.6, 3: 41.3, 4: 34.7, 5: 31.6, 7: 29.5, 9: 32.1, 14: 37.2, 28: 55.9},
+    (27419, 3072, 768): {1: 560.0, 2: 295.7, 3: 210.4, 4: 172.3, 5: 152.8, 7: 143.9},
+    (27419, 2304, 768): {1: 558.0, 2: 290.5, 3: 203.2, 4: 161.6, 5: 140.9, 7: 123.5, 9: 122.3},
+    (27419, 768, 768): {1: 262.8, 2: 126.7, 3: 89.4, 4: 70.4, 5: 61.7, 7: 50.7, 9: 55.0, 14: 53.7, 28: 72.2},
+    (95630, 3072, 768): {1: 1934.7, 2: 986.1, 3: 664.5, 4: 528.7, 5: 460.6, 7: 404.6},
+    (95630, 2304, 768): {1: 1931.7, 2: 980.2, 3: 657.9, 4: 502.5, 5: 419.3, 7: 344.9, 9: 321.4},
+    (95630, 768, 768): {1: 1158.9, 2: 564.3, 3: 378.5, 4: 284.8, 5: 235.6, 7: 175.8, 9: 159.0, 14: 130.6, 28: 151.2},
+}
+
+
+def test_weight_gradient_split_plan_stays_near_the_measured_optimum():
+    """avs_gemm_tn_plan (host arithmetic, no GPU): the split count the library picks for a weight-gradient launch - a stage / atomics cost model
+    fitted in round 5, rounds 1 - 4 always filled one resident round - against the measured time-vs-splits table of the same shapes: within 20 %
+    of the best measured split everywhere (the old rule was 45 - 200 % off below ~30 000 rows), never more than one resident round, and fewer
+    splits for fewer rows."""
+    lib = _lib.load()
+
+    def plan(M, N1, N2):
+        tile, splits = ctypes.c_int(0), ctypes.c_int(0)
+        assert lib.avs_gemm_tn_plan(M, N1, N2, ctypes.byref(tile), ctypes.byref(splits)) == 0
+        return tile.value, splits.value
+
+    slots = lib.avs_persistent_cu_slots()
+    for (M, N1, N2), times in TN_SPLIT_TIMES.items():
+        tile, s = plan(M, N1, N2)
+        assert tile in (128, 256) and s >= 1
+        assert (N1 // tile) * (N2 // tile) * s <= slots * (1 if tile == 256 else 2), (M, N1, N2, tile, s)
+        # the measured table is indexed by the split count of a few sampled values: take the nearest sampled neighbours of the plan
+        lo = max(k for k in times if k <= s)
+        hi = min((k for k in times if k >= s), default=lo)
+        t = max(times[lo], times[hi])
+        assert t <= 1.2 * min(times.values()), ((M, N1, N2), s, t, min(times.values()))
+    for N1, N2 in ((3072, 768), (768, 768), (2048, 512)):
+        seq = [plan(M, N1, N2) for M in (708, 2832, 11328, 27419, 95630)]
+        wgs = [(N1 // t) * (N2 // t) * s * (4 if t == 256 else 1) for t, s in seq]            # output area x splits, in 128^2 units
+        assert all(a <= b for a, b in zip(wgs, wgs[1:])), seq                                  # more rows never mean fewer partial tiles
+    assert plan(708, 768, 768)[1] <= 2 and plan(64, 128, 128) == (128, 1)
+    assert lib.avs_gemm_tn_plan(100, 100, 128, None, None) == -2
