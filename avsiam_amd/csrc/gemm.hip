@@ -1183,6 +1183,37 @@ extern "C" int avs_gemm_set_nt8(int on) { return avs_tuning_set("gemm_nt8", on ?
 extern "C" int avs_gemm_set_tile_height(int h) { return avs_tuning_set("nt_tile_h", h); }
 extern "C" int avs_gemm_set_tile(int tile) { return avs_tuning_set("gemm_tile", tile); }
 
+// Host-side choice of the kernel family of a forward / input-gradient GEMM (knobs gemm_tile, nt_big_min, gemm_ring, cu_reserve included; no device
+// work).  gemm_nt_launch takes exactly these decisions; avs_gemm_nt_plan exports them so that the dispatch thresholds are pinned by the CPU tests.
+enum { NT_TWOBUF = 0, NT_RING = 1, NT_RING_HALF = 2, NT_TWOBUF_HALF = 3, NT_PERSISTENT = 4 };
+static bool nt_use_big(int M, int N) {
+    const int force = g_force_tile;
+    const int big_tiles = ceil_div(M, 256) * (N / 256);
+    const int big_min = avs_tuning().nt_big_min > 0 ? avs_tuning().nt_big_min : avs_persistent_slots() / 2;
+    return force == 256 ? (N % 256) == 0 : force == 128 ? false : ((N % 256) == 0 && big_tiles >= big_min);
+}
+// the 128 x 128 side: `whole` = every row in full-height tiles (not the remainder rows of a persistent launch)
+static int nt_small_family(int M, int N, int K, bool whole) {
+    const int nwg = ceil_div(M, BM) * (N / BN);
+    if (avs_tuning().gemm_ring == 2 && 2 * nwg <= avs_persistent_slots() && whole) return K >= 256 ? NT_RING_HALF : NT_TWOBUF_HALF;
+    if (avs_tuning().gemm_ring && nwg <= avs_persistent_slots() && K >= 256 && whole) return NT_RING;
+    return NT_TWOBUF;
+}
+
+extern "C" int avs_gemm_nt_plan(int M, int N, int K, int* family, int* workgroups) {
+    AVS_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % BN) == 0 && (K % BK) == 0 && family && workgroups, "gemm_nt_plan: bad arguments M=%d N=%d K=%d", M, N, K);
+    if (nt_use_big(M, N)) {
+        const int tiles = ceil_div(M, 256) * (N / 256), slots = avs_persistent_slots();
+        *family = NT_PERSISTENT;
+        *workgroups = tiles < slots ? tiles : slots;          // (with two tile heights the 8-phase kernel may walk a few more, cheaper tiles)
+        return 0;
+    }
+    const int fam = nt_small_family(M, N, K, true);
+    *family = fam;
+    *workgroups = ceil_div(M, (fam == NT_RING_HALF || fam == NT_TWOBUF_HALF) ? BM / 2 : BM) * (N / BN);
+    return 0;
+}
+
 static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long long ldb, int M, int N, int K,
                           const float* bias, const float* res, long long ldr, const int* res_idx, const bf16_t* aux,
                           long long ldaux, void* out, long long ldo, int out_f32, bf16_t* out2, long long ldo2,
@@ -1203,10 +1234,8 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     // 128 and 224 the 128^2 tiling needs 512 ... 896 workgroups = a second round on 512 slots, and the persistent kernel on a part of the chip
     // runs at a higher clock: 135 tiles, K = 3072: 78.1 -> 63.8 us, K = 768: 25.8 -> 23.5; 192 tiles: 80.9 -> 68.9, 28.4 -> 25.7; under
     // 128 tiles the 128^2 tiling fits one round and wins (96 tiles: 48.2 against 62.1 us) - tools/bench_nt_midsize.py, profiles/r05/nt_midsize.log
-    const int force = g_force_tile;
     const int big_tiles = ceil_div(M, 256) * (N / 256);
-    const int big_min = avs_tuning().nt_big_min > 0 ? avs_tuning().nt_big_min : avs_persistent_slots() / 2;
-    const bool big = force == 256 ? (N % 256) == 0 : force == 128 ? false : ((N % 256) == 0 && big_tiles >= big_min);
+    const bool big = nt_use_big(M, N);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipSuccess;
@@ -1231,12 +1260,13 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     }
     auto launch_small = [&](const GemmNtArgs& x) {
         const int nwg = ceil_div(x.M, BM) * (x.N / BN);
+        const int fam = nt_small_family(x.M, x.N, x.K, x.m_full >= x.M);
         // fewer workgroups than half the CUs: every row as HALF-height (64 x 128) tiles of the same kernel - twice the workgroups on CUs
         // that would idle (a CU fills its LDS at ~60 GB/s: the 32 KiB K-slab of a 128 x 128 tile takes 0.55 us against 0.25 us of MFMA
         // work, so small GEMMs are bound by how many CUs pull, profiles/r05/small_gemm_ab.log); bitwise the full tiles' results
-        if (avs_tuning().gemm_ring == 2 && 2 * nwg <= avs_persistent_slots() && x.m_full >= x.M) {
+        if (fam == NT_RING_HALF || fam == NT_TWOBUF_HALF) {
             const int nh = ceil_div(x.M, BM / 2) * (x.N / BN);
-            if (x.K >= 256) {                  // ... of the ring kernel (three K-slabs in flight)
+            if (fam == NT_RING_HALF) {         // ... of the ring kernel (three K-slabs in flight)
                 if (act == 0) gemm_nt_ring_kernel<0, 2><<<nh, 256, 98304, stream>>>(x);
                 else if (act == 1) gemm_nt_ring_kernel<1, 2><<<nh, 256, 98304, stream>>>(x);
                 else gemm_nt_ring_kernel<2, 2><<<nh, 256, 98304, stream>>>(x);
@@ -1250,7 +1280,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
             return;
         }
         // at most one workgroup per CU: the ring kernel keeps three K-slabs in flight instead of one
-        if (avs_tuning().gemm_ring && nwg <= avs_persistent_slots() && x.K >= 256 && x.m_full >= x.M) {
+        if (fam == NT_RING) {
             if (act == 0) gemm_nt_ring_kernel<0><<<nwg, 256, 131072, stream>>>(x);
             else if (act == 1) gemm_nt_ring_kernel<1><<<nwg, 256, 131072, stream>>>(x);
             else gemm_nt_ring_kernel<2><<<nwg, 256, 131072, stream>>>(x);

@@ -153,6 +153,10 @@ int avs_gemm_tn_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
 /* The plan avs_gemm_tn_bf16 takes for (M, N1, N2) with splits <= 0 under the current knobs: output tile size (128 | 256) and the number of
  * splits of the token rows.  Host arithmetic only (no device work, callable without a GPU): pins the split heuristic in the CPU test suite. */
 int avs_gemm_tn_plan(int M, int N1, int N2, int* tile, int* splits);
+/* The kernel family avs_gemm_nt_bf16 dispatches (M, N, K) to under the current knobs, and the workgroups it launches: family 0 two-buffer
+ * 128 x 128 tiles | 1 LDS-DMA ring, 128 x 128 | 2 ring, 64 x 128 half-height tiles | 3 two-buffer, 64 x 128 | 4 persistent 256 x 256 (8-phase).
+ * Host arithmetic only (callable without a GPU). */
+int avs_gemm_nt_plan(int M, int N, int K, int* family, int* workgroups);
 /* up to three weight gradients over the SAME M token rows in one launch: Ci[N1_i, N2_i] (contiguous) += Ai^T . Bi; problem i is absent
  * when Ai is NULL (problem 0 must exist).  A block's fc2 / fc1 / proj gradients (timm Mlp + Attention.proj, cav_mae_base.py:77,138-143)
  * exist at the same time; together they fill the chip with 3 splits of the token rows instead of 7 + 7 + 14, i.e. with 40 % of the fp32

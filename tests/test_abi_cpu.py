@@ -126,3 +126,49 @@ def test_weight_gradient_split_plan_stays_near_the_measured_optimum():
         assert all(a <= b for a, b in zip(wgs, wgs[1:])), seq                                  # more rows never mean fewer partial tiles
     assert plan(708, 768, 768)[1] <= 2 and plan(64, 128, 128) == (128, 1)
     assert lib.avs_gemm_tn_plan(100, 100, 128, None, None) == -2
+
+
+def test_forward_gemm_dispatch_plan():
+    """avs_gemm_nt_plan (host arithmetic, no GPU): which kernel family a forward / input-gradient GEMM goes to.  The thresholds follow the
+    measurements of round 5 (profiles/r05/nt_midsize.log, small_gemm_ab.log): the persistent 256 x 256 kernel from half the CU slots' worth
+    of tiles (135 tiles: 76.7 -> 62.6 us; 96 tiles stay on 128 x 128: 44.6 against 57.2 us), the LDS-DMA ring kernel when the 128 x 128 tiling
+    gives at most one workgroup per CU, half-height tiles when even that fills less than half the CUs; cu_reserve shifts every threshold;
+    the knobs gemm_tile / nt_big_min / gemm_ring override."""
+    lib = _lib.load()
+    TWOBUF, RING, RING_HALF, TWOBUF_HALF, PERSISTENT = range(5)
+
+    def plan(M, N, K):
+        fam, wgs = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib.avs_gemm_nt_plan(M, N, K, ctypes.byref(fam), ctypes.byref(wgs)) == 0
+        return fam.value, wgs.value
+
+    slots = lib.avs_persistent_cu_slots()
+    assert slots == 256 or slots > 8                                   # 256 without a device (the default) and on MI355X
+    if slots == 256:
+        assert plan(95630, 768, 768) == (PERSISTENT, 256)              # the headline shapes: 1122 tiles walked by one workgroup per CU
+        assert plan(11328, 768, 3072) == (PERSISTENT, 135)             # one frame at batch 64: 135 tiles >= 128 (round 5; 224 before)
+        assert plan(8192, 768, 3072) == (TWOBUF, 384)                  # 96 tiles: 128 x 128 tiles, one round of two per CU
+        assert plan(2832, 768, 768) == (RING, 138)                     # batch 4, decoder rows: at most one 128 x 128 workgroup per CU
+        assert plan(708, 768, 768) == (RING_HALF, 72)                  # batch 4, encoder rows: 36 full tiles -> 72 half-height ones
+        assert plan(708, 768, 128) == (TWOBUF_HALF, 72)                # two K-steps only: nothing for a ring to keep in flight
+        assert plan(1979, 2304, 768) == (TWOBUF, 288)                  # more than one workgroup per CU: the ring kernel does not apply
+    try:
+        _lib.tuning_set("cu_reserve", 64)                              # 192 slots: the persistent threshold moves to 96 tiles
+        assert plan(8192, 768, 3072) == (PERSISTENT, 96)
+        _lib.tuning_set("cu_reserve", 0)
+        _lib.tuning_set("nt_big_min", 224)                             # the threshold of rounds 1 - 4
+        assert plan(11328, 768, 3072)[0] != PERSISTENT
+        _lib.tuning_set("nt_big_min", 0)
+        _lib.tuning_set("gemm_ring", 0)
+        assert plan(708, 768, 768) == (TWOBUF, 36) and plan(2832, 768, 768) == (TWOBUF, 138)
+        _lib.tuning_set("gemm_ring", 1)
+        assert plan(708, 768, 768) == (RING, 36)
+        _lib.tuning_set("gemm_ring", 2)
+        _lib.tuning_set("gemm_tile", 128)
+        assert plan(95630, 768, 768)[0] == TWOBUF
+        _lib.tuning_set("gemm_tile", 256)
+        assert plan(708, 768, 768)[0] == PERSISTENT and plan(708, 384, 768)[0] != PERSISTENT      # N must be a multiple of 256 for that tile
+    finally:
+        for k, v in (("cu_reserve", 0), ("nt_big_min", 0), ("gemm_ring", 2), ("gemm_tile", 0)):
+            _lib.tuning_set(k, v)
+    assert lib.avs_gemm_nt_plan(100, 100, 64, None, None) == -2
