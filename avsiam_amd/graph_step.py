@@ -39,8 +39,8 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=a.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):                     # eager warm-up: engines, optimizer state, kernel attributes, shadows
-            for _ in range(max(1, warmup)):
-                train_step(model, a, v, self.lr)
+            for _ in range(max(1, warmup)):               # (REAL training steps on the contents of a / v - a loop that captures on its first
+                self.warm_out = train_step(model, a, v, self.lr)      #  batch asks for warmup=1 and takes this step's losses as that batch's)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         dev = a.device

@@ -69,6 +69,9 @@ def build_parser():
     parser.add_argument('--frames', default=1, type=int, help="frames per sample (extension; reference pre-training uses 1)")
     parser.add_argument('--steps-per-epoch', dest="steps_per_epoch", default=20, type=int, help="synthetic-data epoch length")
     parser.add_argument('--val-steps', dest="val_steps", default=2, type=int, help="synthetic validation batches per epoch")
+    parser.add_argument('--graph-step', dest="graph_step", action="store_true",
+                        help="(extension) replay the training step from one captured hipGraph - single GPU; for small per-GPU batches such as the "
+                             "reference's 4, where the eager step is bound by the host's launch rate")
     parser.add_argument('--raw-input', dest="raw_input", action="store_true",
                         help="feed un-normalised fbank + uint8 frames and normalise on the device (dataloader.py:505-513,461-462)")
     return parser

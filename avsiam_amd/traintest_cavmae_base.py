@@ -140,6 +140,13 @@ def train(audio_model, train_sampler, test_loader, test_sampler, train_loader_li
         return n
 
     B_ref = [args.batch_size]
+    # --graph-step (extension, single GPU): the step replayed from one captured hipGraph (avsiam_amd.graph_step) - for the reference's own
+    # per-GPU batch of 4, where the eager step is bound by the host's launch rate.  Captured on the first batch (whose one warm-up step IS that
+    # batch's training step) and again when the batch size or the learning rate changes; every other batch is copied into the captured buffers.
+    use_graph = bool(getattr(args, "graph_step", False)) and getattr(args, "world_size", 1) == 1 and raw is None and not audio_model.share_pass_buffers
+    if getattr(args, "graph_step", False) and not use_graph:
+        print("--graph-step ignored: it needs one GPU, pre-normalised inputs and private pass buffers")
+    gstep, gkey, gbuf = None, None, None
     while epoch < args.n_epochs + 1:
         begin_time = end_time = time.time()
         print('---------------'); print(datetime.datetime.now())
@@ -150,8 +157,18 @@ def train(audio_model, train_sampler, test_loader, test_sampler, train_loader_li
             a_input = a_input.to(device, non_blocking=True)
             v_input = v_input.to(device, non_blocking=True)
             dnn_start_time = time.time()
-            loss, la, lv, lc, c_acc = train_step(audio_model, a_input, v_input, lr,
-                                                 input_xf=raw(B, train=True) if raw is not None else None)
+            if use_graph:
+                if gstep is None or gkey != (tuple(a_input.shape), tuple(v_input.shape), lr):
+                    from .graph_step import GraphedTrainStep
+                    gbuf = (a_input.clone(), v_input.clone())
+                    gstep, gkey = GraphedTrainStep(audio_model, gbuf[0], gbuf[1], lr, warmup=1), (tuple(a_input.shape), tuple(v_input.shape), lr)
+                    loss, la, lv, lc, c_acc = gstep.warm_out
+                else:
+                    gbuf[0].copy_(a_input); gbuf[1].copy_(v_input)
+                    loss, la, lv, lc, c_acc = gstep.step()
+            else:
+                loss, la, lv, lc, c_acc = train_step(audio_model, a_input, v_input, lr,
+                                                     input_xf=raw(B, train=True) if raw is not None else None)
             step_vals = torch.stack([loss.detach(), la.detach(), lv.detach(), lc.detach()]).float()
             dsum += step_vals
             dcount += 1

@@ -157,6 +157,35 @@ def test_train_loop_bookkeeping(tmp_path):
     assert np.loadtxt(d2 / "result.csv", delimiter=",").reshape(1, 10)[0, 3] > 0
 
 
+def test_train_loop_with_graph_step_equals_the_eager_loop(tmp_path):
+    """train() with args.graph_step (`--graph-step`, round 5): the loop captures the step on its first batch - whose one warm-up step IS that
+    batch's training step - and again when the learning rate changes (epoch 2 here), copies every other batch into the captured buffers and
+    replays.  Same number of optimizer steps, same plans, the same result.csv (losses to the order of the fp32 atomics) and the same weights as
+    the eager loop from the same seeds; validation between the epochs runs eagerly on the same model."""
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.param_spec import P1, P2
+    from avsiam_amd.traintest_cavmae_base import SyntheticAVLoader, train
+    cfg = AVSiamConfig(audio_tokens=128)
+    runs = {}
+    for name, flag in (("eager", False), ("graph", True)):
+        m = CAVMAE_BASE(cfg=cfg, init_seed=3, init_mode="random", verbose=False, plan_seed=7)
+        d = tmp_path / name
+        args = _args(d, n_epochs=2, steps_per_epoch=3, lrscheduler_start=1, lrscheduler_step=1, graph_step=flag)      # lr halves after epoch 1
+        val = SyntheticAVLoader(cfg, 4, 1, "cuda", seed=5)
+        train(m, None, [val, None], [None, None], None, args, None)
+        runs[name] = (m, np.loadtxt(d / "result.csv", delimiter=","))
+    (me, re_), (mg, rg) = runs["eager"], runs["graph"]
+    assert me._opt_state[P1]["step"] == mg._opt_state[P1]["step"] == 6 and me._opt_state[P2]["step"] == mg._opt_state[P2]["step"] == 6
+    assert re_[0, 9] == rg[0, 9] == 1e-3 and re_[1, 9] == rg[1, 9] == 5e-4
+    # reconstruction losses (train and eval) to 2e-3; the InfoNCE terms of a batch of 4 move by a few percent with the atomics' order (test_train_gpu)
+    for col in (0, 1, 3, 4, 5):
+        assert np.allclose(re_[:, col], rg[:, col], rtol=3e-3, atol=1e-6), (col, re_[:, col], rg[:, col])
+    for col in (2, 6, 7):
+        assert np.allclose(re_[:, col], rg[:, col], rtol=0.08, atol=5e-3), (col, re_[:, col], rg[:, col])
+    rel = float((me.arena.p - mg.arena.p).double().norm() / me.arena.p.double().norm())
+    assert rel < 3e-3, rel
+
+
 def test_pretrained_vit_checkpoint_forward_matches_oracle():
     """SURVEY 8(f) row 1 on the device: a timm-shaped checkpoint loaded the reference constructor's way
     (tests/test_oracle_golden.py pins that derivation bit-exactly to the reference) runs through the HIP path and agrees with
