@@ -177,13 +177,14 @@ def test_train_loop_with_graph_step_equals_the_eager_loop(tmp_path):
     (me, re_), (mg, rg) = runs["eager"], runs["graph"]
     assert me._opt_state[P1]["step"] == mg._opt_state[P1]["step"] == 6 and me._opt_state[P2]["step"] == mg._opt_state[P2]["step"] == 6
     assert re_[0, 9] == rg[0, 9] == 1e-3 and re_[1, 9] == rg[1, 9] == 5e-4
-    # reconstruction losses (train and eval) to 2e-3; the InfoNCE terms of a batch of 4 move by a few percent with the atomics' order (test_train_gpu)
+    # Two EAGER runs of this loop differ by up to 3.6e-3 in the reconstruction losses, 1.9e-2 in the InfoNCE terms of a batch of 4 and 1.7e-3 in the
+    # weights after six Adam updates (order of the fp32 atomics x Adam's sign sensitivity: DESIGN.md 5d item 1); graph vs eager measured the same
     for col in (0, 1, 3, 4, 5):
-        assert np.allclose(re_[:, col], rg[:, col], rtol=3e-3, atol=1e-6), (col, re_[:, col], rg[:, col])
+        assert np.allclose(re_[:, col], rg[:, col], rtol=1e-2, atol=1e-6), (col, re_[:, col], rg[:, col])
     for col in (2, 6, 7):
         assert np.allclose(re_[:, col], rg[:, col], rtol=0.08, atol=5e-3), (col, re_[:, col], rg[:, col])
     rel = float((me.arena.p - mg.arena.p).double().norm() / me.arena.p.double().norm())
-    assert rel < 3e-3, rel
+    assert rel < 5e-3, rel
 
 
 def test_pretrained_vit_checkpoint_forward_matches_oracle():
