@@ -98,7 +98,7 @@ TN_SPLIT_TIMES = {
 }
 
 
-def test_weight_gradient_split_plan_stays_near_the_measured_optimum():
+def test_weight_gradient_split_plan_stays_near_the_measured_optimum(lib_path):
     """avs_gemm_tn_plan (host arithmetic, no GPU): the split count the library picks for a weight-gradient launch - a stage / atomics cost model
     fitted in round 5, rounds 1 - 4 always filled one resident round - against the measured time-vs-splits table of the same shapes: within 20 %
     of the best measured split everywhere (the old rule was 45 - 200 % off below ~30 000 rows), never more than one resident round, and fewer
@@ -128,7 +128,7 @@ def test_weight_gradient_split_plan_stays_near_the_measured_optimum():
     assert lib.avs_gemm_tn_plan(100, 100, 128, None, None) == -2
 
 
-def test_forward_gemm_dispatch_plan():
+def test_forward_gemm_dispatch_plan(lib_path):
     """avs_gemm_nt_plan (host arithmetic, no GPU): which kernel family a forward / input-gradient GEMM goes to.  The thresholds follow the
     measurements of round 5 (profiles/r05/nt_midsize.log, small_gemm_ab.log): the persistent 256 x 256 kernel from half the CU slots' worth
     of tiles (135 tiles: 76.7 -> 62.6 us; 96 tiles stay on 128 x 128: 44.6 against 57.2 us), the LDS-DMA ring kernel when the 128 x 128 tiling
