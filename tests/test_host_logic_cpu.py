@@ -1,0 +1,127 @@
+"""CPU checks of the host-side logic around the kernels: the mask-plan bookkeeping (group sizes, keep counts, the structured audio masks, the
+.npz form of a plan) against the reference's expressions and against the plans the UNMODIFIED reference drew for the golden fixtures, and the
+algorithmic FLOP count the roofline is priced with."""
+import math
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from avsiam_amd import flops, maskplan
+from avsiam_amd.config import AVSiamConfig, vit_huge14, vit_large
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("batch", list(range(1, 24)) + [64, 65, 69, 70, 512])
+def test_group_sizes_are_torch_chunk_sizes(batch):
+    """/root/reference/src/models/cav_mae_base.py:534 - `torch.chunk(torch.randperm(B), 5)`: ceil(B / 5)-sized chunks, possibly fewer than 5"""
+    want = [c.numel() for c in torch.chunk(torch.arange(batch), 5)]
+    assert maskplan.group_sizes(batch, 5) == want and sum(want) == batch
+
+
+def test_keep_counts_follow_the_reference_expressions():
+    """:372 / :399 `int(L * (1 - mask_ratio))` with the ratio `0 + 0.2 * i` of :546 / :549 - in floating point, as the reference evaluates it"""
+    for L in (196, 256, 512, 657, 128, 49):
+        for g in range(5):
+            r = 0 + 0.2 * g
+            assert maskplan.group_ratio(g) == r and maskplan.len_keep(L, r) == int(L * (1 - r))
+    assert maskplan.len_keep(196, maskplan.group_ratio(3)) == 78 and maskplan.len_keep(512, maskplan.group_ratio(3)) == 204      # (0.6000000000000001)
+    cfg = AVSiamConfig()
+    assert (cfg.keep_a, cfg.keep_v) == (128, 49) and (cfg.audio_t, cfg.audio_f, cfg.video_tokens) == (64, 8, 196)
+    h = vit_huge14()
+    assert h.audio_tokens == 657 and h.audio_f == 9 and h.video_tokens == 256 and vit_large().embed_dim == 1024
+
+
+@pytest.mark.parametrize("name,batch", [("c_w1_b4", 4), ("c_w1_b5", 5), ("c_w1_b10", 10)])
+def test_reference_drawn_contrastive_plans_have_the_structure_the_host_code_assumes(name, batch):
+    """The golden plans were drawn by the unmodified reference (oracle/gen_golden.py).  Group populations = the chunk sizes of two independent
+    batch permutations; every sample keeps exactly len_keep(L, 0.2 g) distinct tokens per modality (and per frame); the .npz form round-trips."""
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    plan = maskplan.plan_from_arrays({k[5:]: d[k] for k in d.files if k.startswith("plan_")})
+    assert plan.batch == batch
+    sizes = maskplan.group_sizes(batch)
+    for grp in (plan.a_group, plan.v_group):
+        assert sorted(torch.bincount(grp, minlength=len(sizes)).tolist(), reverse=True) == sorted(sizes, reverse=True)
+        assert torch.bincount(grp, minlength=len(sizes)).tolist() == sizes
+    La, Lv = int(d["plan_a_keep"].shape[1]), int(d["plan_v_keep"].shape[2])
+    for b in range(batch):
+        ka = plan.a_keep[b]
+        assert ka.numel() == maskplan.len_keep(La, maskplan.group_ratio(int(plan.a_group[b]))) and ka.unique().numel() == ka.numel()
+        assert int(ka.min()) >= 0 and int(ka.max()) < La
+        for kv in plan.v_keep[b]:
+            assert kv.numel() == maskplan.len_keep(Lv, maskplan.group_ratio(int(plan.v_group[b]))) and kv.unique().numel() == kv.numel()
+    back = maskplan.plan_to_arrays(plan)
+    for k in ("a_group", "v_group", "a_keep", "v_keep"):
+        assert np.array_equal(np.asarray(back[k]), d["plan_" + k]), k
+
+
+def test_reference_drawn_mae_plan_is_a_permutation_split():
+    d = np.load(os.path.join(GOLD, "m_w1_b4.npz"))
+    plan = maskplan.plan_from_arrays({k[5:]: d[k] for k in d.files if k.startswith("plan_")})
+    B, La = plan.ids_restore_a.shape
+    assert plan.batch == B == 4 and plan.ids_keep_a.shape[1] == int(La * 0.25) and plan.ids_keep_v.shape[-1] == 49
+    for b in range(B):
+        assert sorted(plan.ids_restore_a[b].tolist()) == list(range(La))                       # a permutation
+        # the kept tokens are the ones whose rank in the shuffle is below keep (:379-388): mask 0 there, 1 elsewhere
+        assert torch.equal(torch.nonzero(plan.mask_a()[b] == 0).flatten(), plan.ids_keep_a[b].sort().values)
+    assert float(plan.mask_a().mean()) == 0.75 and float(plan.mask_v().mean()) == 0.75
+    back = maskplan.plan_to_arrays(plan)
+    assert all(np.array_equal(np.asarray(back[k]), d["plan_" + k]) for k in back)
+
+
+def test_host_plan_generator_has_the_reference_distribution_properties():
+    """make_contrastive_plan / make_mae_plan (the host generator used where no device draw exists: oracle-side tests, fixtures): structured audio masks
+    remove WHOLE time columns and frequency rows first (:415-422: int(t r 0.7) columns, int(f r 0.7) rows get noise 1.1 = sorted last), group 0 keeps
+    everything, the MAE plan keeps a quarter."""
+    cfg = AVSiamConfig(audio_tokens=512, frames=2)
+    gen = torch.Generator().manual_seed(5)
+    plan = maskplan.make_contrastive_plan(cfg, 10, gen, random.Random(7))
+    t, f = cfg.audio_t, cfg.audio_f
+    assert torch.bincount(plan.a_group).tolist() == [2, 2, 2, 2, 2]
+    for b in range(10):
+        g = int(plan.a_group[b]); r = maskplan.group_ratio(g)
+        kept = torch.zeros(cfg.audio_tokens, dtype=torch.bool); kept[plan.a_keep[b]] = True
+        grid = kept.reshape(f, t)
+        assert int(kept.sum()) == maskplan.len_keep(cfg.audio_tokens, r)
+        if g == 0:
+            assert bool(kept.all())
+        else:
+            # the structured picks - c = int(t r 0.7) whole time columns, w = int(f r 0.7) whole frequency rows - are sorted last, i.e. removed first;
+            # when they are MORE than the tokens to remove, the surplus (lowest token ids first: stable ties) stays, one token per picked column
+            c, w = int(t * r * 0.7), int(f * r * 0.7)
+            slack = max(0, c * f + w * (t - c) - (cfg.audio_tokens - int(kept.sum())))
+            assert int((~grid.any(0)).sum()) >= c - slack and int((~grid.any(1)).sum()) >= w - slack
+            if g == 4:                                                # no surplus at ratio 0.8: exactly the picked columns and rows are empty
+                assert (int((~grid.any(0)).sum()), int((~grid.any(1)).sum())) == (c, w) == (35, 4)
+        assert len(plan.v_keep[b]) == 2 and all(k.numel() == maskplan.len_keep(196, maskplan.group_ratio(int(plan.v_group[b]))) for k in plan.v_keep[b])
+    mae = maskplan.make_mae_plan(cfg, 3, gen)
+    assert mae.ids_keep_a.shape == (3, 128) and mae.ids_keep_v.shape == (3, 2, 49)
+    assert all(sorted(mae.ids_restore_v[b, tt].tolist()) == list(range(196)) for b in range(3) for tt in range(2))
+    # same generator state, same plan (the fixtures depend on it)
+    p1 = maskplan.make_mae_plan(cfg, 2, torch.Generator().manual_seed(9)); p2 = maskplan.make_mae_plan(cfg, 2, torch.Generator().manual_seed(9))
+    assert torch.equal(p1.ids_keep_a, p2.ids_keep_a) and torch.equal(p1.ids_restore_v, p2.ids_restore_v)
+
+
+def test_algorithmic_flops_of_the_step():
+    """flops.step_flops: 24 N D^2 + 4 N^2 D per block on KEPT tokens, training = 3 x forward except the patch embedding (2 x).
+    The values bench.py prints for the headline shape and for the reference's one-frame shapes are pinned; the contrastive pass's count follows the
+    group sizes of the batch."""
+    assert flops.blk(10, 8) == 24 * 10 * 64 + 4 * 100 * 8
+    head = AVSiamConfig(frames=10, audio_tokens=512)
+    assert abs(flops.gflop_per_sample(head, 64) - 1856.56426368) < 1e-6                      # profiles/r05/a_bench.json config.gflop_per_sample
+    one = AVSiamConfig(frames=1, audio_tokens=512)
+    assert abs(flops.gflop_per_sample(one, 4) - 511.573945344) < 1e-6                        # secondary[1].gflop_per_sample
+    s = flops.step_flops(head, 64)
+    assert s["train_total"] == 3 * (s["fwd_pass1"] + s["fwd_pass2"]) + 2 * s["fwd_embed"]
+    # pass 2 by hand: the modality blocks on the kept tokens of each modality (per frame), the joint layers on their union, decoder embedding, the decoder on ALL tokens, the two prediction heads
+    D, Dd, T, ka, kv, La, Lv = 768, 512, 10, 128, 49, 512, 196
+    n_enc = ka + T * kv
+    per = head.depth * (flops.blk(ka, D) + T * flops.blk(kv, D)) + 2 * flops.blk(n_enc, D) + n_enc * 2 * D * Dd + head.dec_depth * flops.blk(La + T * Lv, Dd) \
+        + La * 2 * Dd * 256 + T * Lv * 2 * Dd * 768
+    assert s["fwd_pass2"] == 64 * per
+    # the contrastive pass depends on the batch through its group sizes only: per-sample cost is not constant in B
+    assert flops.step_flops(head, 5)["fwd_pass1"] * 2 == flops.step_flops(head, 10)["fwd_pass1"]
+    assert math.isclose(flops.gflop_per_sample(head, 64), flops.gflop_per_sample(head, 65), rel_tol=0.02)
