@@ -125,3 +125,44 @@ def test_algorithmic_flops_of_the_step():
     # the contrastive pass depends on the batch through its group sizes only: per-sample cost is not constant in B
     assert flops.step_flops(head, 5)["fwd_pass1"] * 2 == flops.step_flops(head, 10)["fwd_pass1"]
     assert math.isclose(flops.gflop_per_sample(head, 64), flops.gflop_per_sample(head, 65), rel_tol=0.02)
+
+
+def test_parameter_arena_layout():
+    """arena.ParamArena: one flat fp32 buffer ordered [pass-1 only | both passes | pass-2 only | dead], so that each pass's gradients, its
+    all-reduce and its fused Adam launch cover ONE contiguous range and the parameters the reference never updates (grad None under
+    DDP(find_unused_parameters=True): torch.optim.Adam skips them) lie outside both.  Offsets are 64-element aligned; views alias the buffer;
+    the bf16 transposed copies exist for the matrices the input-gradient GEMMs read."""
+    from avsiam_amd.arena import ALIGN, ParamArena
+    from avsiam_amd.param_spec import P1, P2, build_spec, live_names, state_dict_keys
+    cfg = AVSiamConfig()
+    spec = build_spec(cfg)
+    a = ParamArena(cfg)
+    (b1, e1), (b2, e2) = a.range[P1], a.range[P2]
+    assert b1 == 0 and b1 < b2 < e1 < e2 == a.live_end < a.total                   # the two ranges overlap exactly in the shared parameters
+    info = {s.name: s for s in spec}
+    for name, off in a.offset.items():
+        n = math.prod(info[name].shape)
+        assert off % ALIGN == 0
+        live = info[name].live
+        inside1, inside2 = b1 <= off and off + n <= e1, b2 <= off and off + n <= e2
+        assert inside1 == bool(live & P1) and inside2 == bool(live & P2), name
+        if live == 0:
+            assert off >= a.live_end
+    # no two parameters overlap
+    spans = sorted((off, off + math.prod(info[n].shape)) for n, off in a.offset.items())
+    assert all(x[1] <= y[0] for x, y in zip(spans, spans[1:]))
+    assert set(live_names(cfg, P1)) == {s.name for s in spec if s.live & P1} and len(live_names(cfg, P2)) == sum(1 for s in spec if s.live & P2)
+    assert len(state_dict_keys(cfg)) == 963                                        # the reference's state_dict (aliases of shared tensors included)
+    # views alias the flat buffer; matrices come as [N, K]
+    w = a.w("blocks_u.0.mlp.fc1.weight") if "blocks_u.0.mlp.fc1.weight" in a.offset else a.w(next(n for n in a.names if n.endswith("mlp.fc1.weight")))
+    assert w.dim() == 2 and w.shape == (3072, 768) and w.data_ptr() >= a.p.data_ptr()
+    w.fill_(2.0)
+    assert float(a.p.sum()) == 2.0 * w.numel()
+    # a CPU arena gets its gradient buffer lazily (the gloo tests use it); the epoch counter opens with every zero-fill
+    g = a.ensure_grads()
+    assert g.numel() == a.live_end and a.zero_epoch == 0
+    a.zero_grad_range(P2)
+    assert a.zero_epoch == 1
+    # inference arenas skip the transposed copies and the gradients
+    inf = ParamArena(cfg, transposed=False, grads=False)
+    assert inf.t_total == 0 and a.t_total > 0 and inf.total == a.total
