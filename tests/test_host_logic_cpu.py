@@ -166,3 +166,32 @@ def test_parameter_arena_layout():
     # inference arenas skip the transposed copies and the gradients
     inf = ParamArena(cfg, transposed=False, grads=False)
     assert inf.t_total == 0 and a.t_total > 0 and inf.total == a.total
+
+
+@pytest.mark.parametrize("tile_rows", [64, 128])
+def test_attention_tile_tables_partition_the_packed_rows(tile_rows):
+    """ops.AttnTiles / ops.AttnSeqs (host tables the varlen attention kernels walk): every sequence longer than min_len is covered by ceil(L /
+    tile_rows) tiles that name its first row, its length and their own first query; the shorter ones go to the fused backward's table exactly
+    once; both tables count the same rows and sum of L^2 the roofline FLOPs are computed from."""
+    from avsiam_amd import ops
+    lens = [196] * 3 + [39, 128, 1, 129, 512, 64, 65, 2472]
+    tiles = ops.AttnTiles(lens, "cpu", tile_rows=tile_rows)
+    assert tiles.ntiles == sum(-(-L // tile_rows) for L in lens) and tiles.max_row == sum(lens)
+    row, k = 0, 0
+    for L in lens:
+        for q0 in range(0, L, tile_rows):
+            assert (int(tiles.start[k]), int(tiles.len[k]), int(tiles.q0[k])) == (row, L, q0)
+            k += 1
+        row += L
+    assert tiles.rows == float(sum(lens)) and tiles.sum_sq == float(sum(L * L for L in lens))
+    # the engine's split of a backward: sequences of at most 64 / 128 tokens to the fused kernel, the rest to the two-kernel path
+    short, mid = ops.AttnSeqs(lens, "cpu", 0, 64), ops.AttnSeqs(lens, "cpu", 64, 128)
+    long_ = ops.AttnTiles(lens, "cpu", tile_rows=tile_rows, min_len=128)
+    assert short.len.tolist() == [39, 1, 64] and mid.len.tolist() == [128, 65] and short.max_len == 64 and mid.max_len == 128
+    starts = [sum(lens[:i]) for i in range(len(lens))]
+    assert short.start.tolist() == [starts[3], starts[5], starts[8]] and mid.start.tolist() == [starts[4], starts[9]]
+    assert long_.ntiles == sum(-(-L // tile_rows) for L in lens if L > 128) and long_.max_row == sum(lens)
+    assert short.rows + mid.rows + long_.rows == float(sum(lens))
+    assert short.sum_sq + mid.sum_sq + long_.sum_sq == tiles.sum_sq
+    assert ops.pad_rows(95630) == 95744 and ops.pad_rows(128) == 128 and ops.pad_rows(1, 64) == 64
+    assert abs(ops.attn_q_scale(64) - 64 ** -0.5 * math.log2(math.e)) < 1e-12
