@@ -195,3 +195,46 @@ def test_attention_tile_tables_partition_the_packed_rows(tile_rows):
     assert short.sum_sq + mid.sum_sq + long_.sum_sq == tiles.sum_sq
     assert ops.pad_rows(95630) == 95744 and ops.pad_rows(128) == 128 and ops.pad_rows(1, 64) == 64
     assert abs(ops.attn_q_scale(64) - 64 ** -0.5 * math.log2(math.e)) < 1e-12
+
+
+def test_entry_point_arguments_and_process_group_plumbing(monkeypatch, capsys):
+    """run_cavmae_pretrain_base.build_parser keeps the reference's flags and defaults (/root/reference/src/run_cavmae_pretrain_base.py:44-100:
+    what egs/audioset/run_pretrain_base.sh passes must parse) and adds the documented extensions; utils.init_distributed_mode reads the torchrun
+    environment like utils.py:250-299 and stays single-process without it; the print gate of :216-229; AverageMeter of util.py:238-253."""
+    import argparse
+    from avsiam_amd import utils
+    from avsiam_amd.run_cavmae_pretrain_base import build_parser
+    p = build_parser()
+    a = p.parse_args([])
+    assert (a.masking_ratio, a.mask_mode, a.contrast_loss_weight, a.mae_loss_weight, a.lr, a.target_length) == (0.75, "unstructured", 0.01, 3.0, 0.001, 1024)
+    assert (a.dataset_mean, a.dataset_std, a.n_epochs if hasattr(a, "n_epochs") else 1) [:2] == (-5.081, 4.4849)
+    assert a.frames == 1 and a.graph_step is False and a.raw_input is False and a.pretrain_path == 'None'
+    # every option of the reference's launch line (egs/audioset/run_pretrain_base.sh:75-87)
+    b = p.parse_args("--model cav-mae --dataset audioset --data-train tr.json --data-val te.json --exp-dir ./exp --label-csv l.csv --n_class 527 "
+                     "--lr 5e-5 --n-epochs 25 --batch-size 4 --save_model True --mixup 0.0 --bal None --lrscheduler_start 10 --lrscheduler_decay 0.5 "
+                     "--lrscheduler_step 5 --dataset_mean -5.081 --dataset_std 4.4849 --target_length 1024 --noise True --warmup True --lr_adapt False "
+                     "--norm_pix_loss True --pretrain_path None --mae_loss_weight 1.0 --contrast_loss_weight 0.01 --num_workers 6 --tr_pos False --masking_ratio 0.75 "
+                     "--masking_ratio_a 0.75 --mask_mode unstructured --wandb 0 --model_name run1".split())
+    assert b.masking_ratio_a == 0.75 and b.num_workers == 6 and b.batch_size == 4 and b.lr == 5e-5 and b.n_epochs == 25 and b.save_model is True and b.noise is True and b.norm_pix_loss is True and b.tr_pos is False
+    c = p.parse_args(["--frames", "10", "--graph-step", "--raw-input", "--steps-per-epoch", "7"])
+    assert c.frames == 10 and c.graph_step and c.raw_input and c.steps_per_epoch == 7
+    # no launcher: single process, rank 0, no process group
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    ns = argparse.Namespace()
+    utils.init_distributed_mode(ns)
+    assert (ns.rank, ns.world_size, ns.gpu, ns.distributed) == (0, 1, 0, False) and "Not using distributed mode" in capsys.readouterr().out
+    # the print gate: silent on non-master ranks unless forced, restored afterwards
+    utils.setup_for_distributed(False)
+    try:
+        print("hidden"); print("shown", force=True)
+    finally:
+        utils.restore_print()
+    out = capsys.readouterr().out
+    assert "hidden" not in out and "shown" in out
+    m = utils.AverageMeter()
+    m.update(2.0, 3); m.update(4.0, 1)
+    assert (m.val, m.sum, m.count, m.avg) == (4.0, 10.0, 4, 2.5)
+    utils.init_seeds(87)
+    x = torch.rand(1).item(); utils.init_seeds(87)
+    assert torch.rand(1).item() == x
