@@ -76,3 +76,38 @@ def test_a_killed_parent_takes_its_ranks_with_it(tmp_path):
     else:
         os.kill(child_pid, signal.SIGKILL)
         raise AssertionError("the launcher's child outlived the parent")
+
+
+def test_counter_summaries_are_attached_only_for_the_source_and_workload_they_were_measured_on(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` / `pmc` / `pmc_source` are not measured in the run (counters need rocprofv3 passes of their own): they are read
+    from profiles/rNN/*.json and attached ONLY while the kernel source is byte-identical (SHA-1) to the one the passes ran on and the workload is
+    BASELINE's (batch 64, 10 frames, 512 audio tokens, ViT-B, bf16) - otherwise null, never a stale number."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    head = argparse.Namespace(batch=64, frames=10, audio_tokens=512, model="vit_base", fp8=False, recompute=None)
+    sha = bench._sha1(os.path.join(ROOT, "avsiam_amd", "csrc", "gemm.hip"))
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r05", "traffic.json")))
+    if committed["source_sha1"]["gemm.hip"] == sha:
+        # the committed summaries belong to the kernel source as it is: the line carries them, with their provenance
+        t = bench.pmc_traffic(head)
+        assert t is not None and 6e8 < t < 1.2e9                                   # ~0.87 GB per forward/dgrad GEMM launch (613 MB algorithmic)
+        src = bench.pmc_source(head)
+        assert set(src) == {"traffic.json", "pmc_busy.json"}
+        assert all(v["kernel_source_sha1"] == sha and v["file"].startswith("profiles/r05/") for v in src.values())
+    else:
+        # gemm.hip was edited after the passes ran: the line must carry null until tools/round5_profile.sh pmc is re-run
+        assert bench.pmc_traffic(head) is None and not bench.pmc_source(head)
+    # another workload: nothing attached
+    for kw in ({"batch": 4}, {"frames": 1}, {"model": "vit_large"}, {"fp8": True}, {"recompute": "auto"}):
+        other = argparse.Namespace(**{**vars(head), **kw})
+        assert bench.pmc_traffic(other) is None and not bench.pmc_source(other)
+    # another kernel source: nothing attached (a copy of the tree's profiles with a foreign SHA-1)
+    fake_root = tmp_path / "repo"
+    (fake_root / "profiles" / "r05").mkdir(parents=True)
+    (fake_root / "avsiam_amd" / "csrc").mkdir(parents=True)
+    (fake_root / "avsiam_amd" / "csrc" / "gemm.hip").write_text("// edited kernel\n")
+    for name in ("traffic.json", "pmc_busy.json"):
+        (fake_root / "profiles" / "r05" / name).write_text(open(os.path.join(ROOT, "profiles", "r05", name)).read())
+    monkeypatch.setattr(bench, "ROOT", str(fake_root))
+    assert bench.pmc_traffic(head) is None and not bench.pmc_source(head)
