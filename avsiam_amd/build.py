@@ -45,16 +45,21 @@ def build(force=False, verbose=True, out=None):
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    objs = []
+    objs, todo = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + FLAGS_FOR.get(src, []) + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            todo.append([hipcc] + FLAGS + FLAGS_FOR.get(src, []) + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o])
+    if todo:
+        # the translation units are independent: compile them side by side (a fresh build is bounded by gemm.hip alone instead of the sum)
+        from concurrent.futures import ThreadPoolExecutor
+        for cmd in todo:
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=max(1, min(len(todo), (os.cpu_count() or 2), 8))) as pool:
+            list(pool.map(subprocess.check_call, todo))
     if force or _stale(lib, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         if verbose:
