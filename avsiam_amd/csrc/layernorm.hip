@@ -237,18 +237,20 @@ __device__ __forceinline__ void lds_r64(unsigned long long& v, unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
 }
 
-template <int NV, int RPW>
+// G8 (fp8 backward, round 5): also the e5m2 copy of dx with its device record, as ln_bwd_kernel writes it (dx8 / q8) - held back one row like the bf16 row.
+template <int NV, int RPW, bool G8 = false>
 __global__ __launch_bounds__(256) void ln_bwd_dma_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ g0, const float* __restrict__ g1,
                                                          const uint8_t* __restrict__ row_mod, const int* __restrict__ out_map,
                                                          const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx_bf16,
-                                                         float* __restrict__ ws, int rows) {
+                                                         float* __restrict__ ws, int rows, uint8_t* __restrict__ dx8 = nullptr, float* q8 = nullptr) {
     constexpr int D = NV * 256;
     constexpr int SLOT = 8 * D;                        // bytes: x | dy | dres
     constexpr int NH = (NV * 32 + 63) / 64;            // DMA instructions of a bf16 row (16 B per lane; the last one may use half the lanes)
     constexpr int NDMA = NV + 2 * NH;                  // LDS-DMA instructions per row
-    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * SLOT];       // 48 KiB at D = 768: three blocks per CU; reused by the slab reduction
+    extern __shared__ __attribute__((aligned(16))) char smem[];            // 4 x 2 x SLOT bytes (the launcher passes it): 48 KiB at D = 768 = three blocks per
+                                                                            // CU, 80 KiB at D = 1280 = two; reused by the slab reduction
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* const myslots = smem + wave * 2 * SLOT;
@@ -265,6 +267,11 @@ __global__ __launch_bounds__(256) void ln_bwd_dma_kernel(const bf16_t* __restric
     const int l_mod = row_mod ? row_mod[lrow] : 0;
     const float l_mean = mean_in[lrow], l_rs = rstd_in[lrow];
     const int l_drow = out_map ? out_map[lrow] : lrow;
+    float q8s = 0.f, amax_seen = 0.f, dmax = 0.f;
+    if (G8) {                                           // (ordinary loads, waited for with the per-row scalars in front of the loop)
+        q8s = q8[AVS_Q_SCALE];
+        amax_seen = q_amax_peek(q8);
+    }
 
     auto issue = [&](int row, int drow, int slot) {     // the three operand rows of `row` -> slot, by LDS-DMA
         char* base = myslots + slot * SLOT;
@@ -286,12 +293,13 @@ __global__ __launch_bounds__(256) void ln_bwd_dma_kernel(const bf16_t* __restric
     f32x4 gcur[NV];
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
     u32x2 held[NV];                                    // bf16 output of the previous row (stored one iteration late, see the wait)
+    uint32_t held8[NV];                                // ... and its e5m2 copy (G8)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { gcur[i] = f32x4{0.f, 0.f, 0.f, 0.f}; held[i] = u32x2{0u, 0u}; }
+    for (int i = 0; i < NV; ++i) { gcur[i] = f32x4{0.f, 0.f, 0.f, 0.f}; held[i] = u32x2{0u, 0u}; held8[i] = 0u; }
     int cur_mod = -1, last = -1;
     // the per-row scalars are consumed here, in the compiler's view: it waits for their loads ONCE, before the loop (left to the first
     // v_readlane it would wait at the loop header - vmcnt(0) in every iteration, in front of the next row's DMA issue)
-    asm volatile("" ::"v"(l_mod), "v"(l_mean), "v"(l_rs), "v"(l_drow) : "memory");
+    asm volatile("" ::"v"(l_mod), "v"(l_mean), "v"(l_rs), "v"(l_drow), "v"(q8s), "v"(amax_seen) : "memory");
     if (row0 < rows) issue(row0, __builtin_amdgcn_readlane(l_drow, 0), 0);
     const int nmine = max(0, min(RPW, rows - row0));          // rows of this wave (one loop exit: with a `break` hipcc keeps a second copy of
                                                               // every accumulator for the merge of the two exits)
@@ -332,12 +340,17 @@ __global__ __launch_bounds__(256) void ln_bwd_dma_kernel(const bf16_t* __restric
             if (NV > 1) { lds_r128<1024>(xv[1], ax); lds_r64<512>(dv[1], ad); lds_r64<512>(rv[1], ar); }
             if (NV > 2) { lds_r128<2048>(xv[2], ax); lds_r64<1024>(dv[2], ad); lds_r64<1024>(rv[2], ar); }
             if (NV > 3) { lds_r128<3072>(xv[3], ax); lds_r64<1536>(dv[3], ad); lds_r64<1536>(rv[3], ar); }
+            if (NV > 4) { lds_r128<4096>(xv[4], ax); lds_r64<2048>(dv[4], ad); lds_r64<2048>(rv[4], ar); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
         if (rr > 0) {                                     // the previous row's output, held back across the wait above
 #pragma unroll
             for (int i = 0; i < NV; ++i) reinterpret_cast<u32x2*>(dx_bf16 + (size_t)(row - 1) * D)[i * 64 + lane] = held[i];
+            if (G8) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) reinterpret_cast<uint32_t*>(dx8 + (size_t)(row - 1) * D)[i * 64 + lane] = held8[i];
+            }
         }
         f32x4 xh[NV], gy[NV];
         float s1 = 0.f, s2 = 0.f;
@@ -367,14 +380,25 @@ __global__ __launch_bounds__(256) void ln_bwd_dma_kernel(const bf16_t* __restric
             const f32x4 o = rs * (gy[i] - m1 - xh[i] * m2) + rsd;
             dc[i] += o;
             held[i] = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            if (G8) {
+                dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                int w = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(o[0] * q8s, -57344.f, 57344.f), __builtin_amdgcn_fmed3f(o[1] * q8s, -57344.f, 57344.f), 0, false);
+                w = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(o[2] * q8s, -57344.f, 57344.f), __builtin_amdgcn_fmed3f(o[3] * q8s, -57344.f, 57344.f), w, true);
+                held8[i] = (uint32_t)w;
+            }
         }
         last = row;
     }
     if (last >= 0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) reinterpret_cast<u32x2*>(dx_bf16 + (size_t)last * D)[i * 64 + lane] = held[i];
+        if (G8) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) reinterpret_cast<uint32_t*>(dx8 + (size_t)last * D)[i * 64 + lane] = held8[i];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (dummy) prefetch has landed: the slots can be reused
+    if (G8) q_amax_update(q8, dmax, amax_seen);
     float (*red)[D] = reinterpret_cast<float (*)[D]>(smem);
     float* slab = ws + (size_t)blockIdx.x * LN_SETS * D;
 #pragma unroll
@@ -461,17 +485,31 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
     if (rpw != 4 && rpw != 8 && rpw != 16) rpw = rows >= 16384 ? 16 : 8;        // measured (tools/bench_ln.py): 8 wins only on the 8192-row audio tower
     const int nblocks = ceil_div(rows, 4 * rpw);
     dim3 grid(nblocks), block(256);
-    // the step's common case - bf16 dy, bf16 residual-gradient stream in, bf16 dx out only - takes the LDS-DMA kernel (D <= 1024:
-    // two slots per wave must leave room for at least two blocks per CU); AVSIAM_LN_DMA=0: the register-load kernel for everything (A/B)
-    if (avs_tuning().ln_dma && !dy_f32 && dres && dres_bf16 && !dx && dx_bf16 && !dx8 && D <= 1024) {
-#define LN_DMA(NV)                                                                                                                              \
+    // the step's common case - bf16 dy, bf16 residual-gradient stream in, bf16 dx out only - takes the LDS-DMA kernel (D = 1280, round 5: 80 KiB of
+    // dynamic LDS, two blocks per CU); AVSIAM_LN_DMA=0: the register-load kernel for everything (A/B)
+    if (avs_tuning().ln_dma && !dy_f32 && dres && dres_bf16 && !dx && dx_bf16) {
+        const int lds = 4 * 2 * 8 * D;                     // four waves x two slots of [x fp32 | dy bf16 | dres bf16] rows
+        static bool attr_done = false;
+        if (!attr_done) {                                  // D = 1280: 80 KiB, above the 64 KiB a kernel gets without asking
+            const void* ks[6] = {(const void*)ln_bwd_dma_kernel<5, 16>, (const void*)ln_bwd_dma_kernel<5, 8>, (const void*)ln_bwd_dma_kernel<5, 4>,
+                                 (const void*)ln_bwd_dma_kernel<5, 16, true>, (const void*)ln_bwd_dma_kernel<5, 8, true>, (const void*)ln_bwd_dma_kernel<5, 4, true>};
+            for (const void* k : ks)
+                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) {
+                    avs_set_error("layernorm_bwd: hipFuncSetAttribute failed");
+                    return -1;
+                }
+            attr_done = true;
+        }
+#define LN_DMA_(NV, G)                                                                                                                          \
     do {                                                                                                                                        \
-        if (rpw == 16) ln_bwd_dma_kernel<NV, 16><<<grid, block, 0, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows); \
-        else if (rpw == 8) ln_bwd_dma_kernel<NV, 8><<<grid, block, 0, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows); \
-        else ln_bwd_dma_kernel<NV, 4><<<grid, block, 0, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows); \
+        if (rpw == 16) ln_bwd_dma_kernel<NV, 16, G><<<grid, block, lds, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows, dx8, q8); \
+        else if (rpw == 8) ln_bwd_dma_kernel<NV, 8, G><<<grid, block, lds, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows, dx8, q8); \
+        else ln_bwd_dma_kernel<NV, 4, G><<<grid, block, lds, stream>>>((const bf16_t*)dy, x, mean, rstd, g0, g1, row_mod, out_map, (const bf16_t*)dres, dx_bf16, ws, rows, dx8, q8); \
     } while (0)
-        if (D == 512) LN_DMA(2); else if (D == 768) LN_DMA(3); else LN_DMA(4);
+#define LN_DMA(NV) do { if (dx8) LN_DMA_(NV, true); else LN_DMA_(NV, false); } while (0)
+        if (D == 512) LN_DMA(2); else if (D == 768) LN_DMA(3); else if (D == 1024) LN_DMA(4); else LN_DMA(5);
 #undef LN_DMA
+#undef LN_DMA_
         AVS_LAUNCH_CHECK("layernorm_bwd_dma");
         const int chunks_ = nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;
         ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), LN_SETS, chunks_), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1, dcol);

@@ -98,7 +98,7 @@ def test_layernorm(D, rows):
         o.layernorm_bwd(dyf, x, mean, rstd, g[0], None, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres_b, dres_b)
 
 
-@pytest.mark.parametrize("D,rows", [(768, 1000), (768, 20001), (512, 16500), (1024, 777)])
+@pytest.mark.parametrize("D,rows", [(768, 1000), (768, 20001), (512, 16500), (1024, 777), (1280, 3001), (1280, 17000)])
 def test_layernorm_bwd_dma_kernel(D, rows):
     """The step's common LayerNorm backward - bf16 dy, bf16 residual-gradient stream in, bf16 dx out only - runs the LDS-DMA kernel
     (ln_bwd_dma_kernel: next row prefetched into LDS under the current row's reductions, counted waits, DPP row sums).  Against an fp64
@@ -142,6 +142,26 @@ def test_layernorm_bwd_dma_kernel(D, rows):
     assert rel_err(dxb.float(), dxb_r.float()) < 1e-4
     for a, b_ in zip(dg + db + [dcol], dg_r + db_r + [dcol_r]):
         assert rel_err(a, b_) < 2e-5
+    # fp8 backward (round 5): the DMA kernel also writes the e5m2 copy of dx with its device record - same bytes and the same running amax as
+    # the register-load kernel's (which the fp32-dx request selects), wherever the two bf16 outputs agree
+    def run8(dx):
+        rec = o.Fp8Records(1, DEV)
+        rec.q[0, 0], rec.q[0, 1] = 64.0, 1.0 / 64.0
+        dg = [torch.zeros(D, device=DEV) for _ in range(2)]
+        db = [torch.zeros(D, device=DEV) for _ in range(2)]
+        dxb8 = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+        d8 = torch.zeros(rows, D, device=DEV, dtype=torch.uint8)
+        o.layernorm_bwd(dy, x, mean, rstd, g[0], dx, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres, dxb8, None, dx8=d8, q8=rec.rec(0))
+        return dxb8, d8, rec.amax(0)
+
+    b_dma, d8_dma, q_dma = run8(None)
+    b_reg, d8_reg, q_reg = run8(torch.empty(rows, D, device=DEV))
+    assert torch.equal(b_dma, dxb)                                                 # the bf16 output does not depend on the extra copy
+    same = (b_dma.float() == b_reg.float())
+    assert float((d8_dma != d8_reg)[same].float().mean()) < 1e-3                   # (fp32 o differs in its last bits between the kernels: rare e5m2 flips)
+    want8 = (b_reg.float() * 64.0).clamp(-57344, 57344).to(torch.float8_e5m2).view(torch.uint8)
+    assert float((d8_dma != want8).float().mean()) < 0.02                          # against the quantised bf16 output: e5m2 of the fp32 value, not of its bf16 rounding
+    assert abs(q_dma - q_reg) <= 1e-5 * abs(q_reg) and q_dma > 0, (q_dma, q_reg)      # the running amax of the record
     # fp64 reference of the formula
     xh = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
     gam = torch.where(mod.bool()[:, None], g[1].double(), g[0].double())
