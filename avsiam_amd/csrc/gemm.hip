@@ -52,7 +52,13 @@ struct GemmNtArgs {
     const float* qa; const float* qw; const float* qw2; float* q8;
     float q8_seen;                           // set by the kernel: the amax q8 held at kernel start (filter of the epilogue's atomic)
     int tb;                                  // gemm_nt8_kernel: tiles [0, tb) are of the FIRST height class (a multiple of 8 and of N / 256); 0: one class
+    // fp8 backward (modes 2 / 3): gelu'(x) travels from the fc1 forward epilogue (ACT 1: `out`) to the fc2 input-gradient epilogue (ACT 2: `aux`) as an
+    // 8-bit fixed-point code instead of bf16 - (g' + GP8_BIAS) * GP8_STEPS in [0, 255], g' in [-0.129, 1.129]: a step of 0.005, finer than bf16 near 1 and
+    // far below the e5m2 rounding (2 mantissa bits) of the gradient it multiplies.  ldo / ldaux then count bytes.
+    int aux8;
 };
+#define GP8_BIAS 0.1296875f
+#define GP8_STEPS 202.0f
 
 
 // Epilogue, staged through LDS (free once the main loop is done).  The accumulators hold 16-row x 4-column patches
@@ -159,6 +165,10 @@ __device__ __forceinline__ void epi_load_aux(const GemmNtArgs& a, u32x4 (&ax)[Ep
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = min(mw0 + (grp * EpiPrefetch<MI>::AG + mj) * 16 + i * 8 + rq, a.M - 1);
+            if (a.aux8) {                                  // 8 codes = 8 bytes per lane (block-uniform branch)
+                const uint2 c = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(a.aux) + (size_t)m * a.ldaux + n);
+                ax[mj][i] = u32x4{c.x, c.y, 0u, 0u};
+            } else
             ax[mj][i] = *reinterpret_cast<const u32x4*>(a.aux + (size_t)m * a.ldaux + n);
         }
 }
@@ -263,8 +273,20 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     if (ACT == 2) ax = pf.ax[mj][i];
                     const f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
                     const float4 bias_lo = make_float4(bq[0][0], bq[0][1], bq[0][2], bq[0][3]), bias_hi = make_float4(bq[1][0], bq[1][1], bq[1][2], bq[1][3]);
+                    if (ACT == 2 && Q8 == 2 && a.aux8) {          // the 8-bit gelu': one code per value, four per dword (hipcc turns the byte picks into v_cvt_f32_ubyteN)
+                        auto dec = [](float b) { return fmaf(b, 1.0f / GP8_STEPS, -GP8_BIAS); };
+                        const float g0[4] = {dec((float)((ax[0] >> 0) & 0xffu)), dec((float)((ax[0] >> 8) & 0xffu)),
+                                             dec((float)((ax[0] >> 16) & 0xffu)), dec((float)((ax[0] >> 24) & 0xffu))};
+                        const float g1[4] = {dec((float)((ax[1] >> 0) & 0xffu)), dec((float)((ax[1] >> 8) & 0xffu)),
+                                             dec((float)((ax[1] >> 16) & 0xffu)), dec((float)((ax[1] >> 24) & 0xffu))};
+                        epi_apply4(alpha, 0, v0, bias_lo, make_uint2(0, 0), false, r0);
+                        epi_apply4(alpha, 0, v1, bias_hi, make_uint2(0, 0), false, r1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v0[j] *= g0[j]; v1[j] *= g1[j]; }
+                    } else {
                     epi_apply4(alpha, ACT, v0, bias_lo, make_uint2(ax[0], ax[1]), false, r0);
                     epi_apply4(alpha, ACT, v1, bias_hi, make_uint2(ax[2], ax[3]), false, r1);
+                    }
                     if (colsum) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { cs[j] += v0[j]; cs[4 + j] += v1[j]; }
@@ -281,6 +303,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                         o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
                     }
                     // (fp8 input-gradient form: `out` may be NULL - every reader of this gradient takes the e5m2 copy below; the bf16 kernels never test it)
+                    if (ACT == 1 && Q8 == 1 && a.aux8) {          // gelu'(x) as 8-bit codes (fp8 backward): 8 bytes per lane instead of 16
+                        auto enc = [](float g, unsigned sel, unsigned old) { return __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g, GP8_STEPS, GP8_BIAS * GP8_STEPS), sel, old); };
+                        unsigned c0 = enc(gelu_erf_grad(v0[0]), 0, 0); c0 = enc(gelu_erf_grad(v0[1]), 1, c0); c0 = enc(gelu_erf_grad(v0[2]), 2, c0); c0 = enc(gelu_erf_grad(v0[3]), 3, c0);
+                        unsigned c1 = enc(gelu_erf_grad(v1[0]), 0, 0); c1 = enc(gelu_erf_grad(v1[1]), 1, c1); c1 = enc(gelu_erf_grad(v1[2]), 2, c1); c1 = enc(gelu_erf_grad(v1[3]), 3, c1);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(a.out) + (size_t)m * a.ldo + n) = make_uint2(c0, c1);
+                    } else
                     if (Q8 != 2 || a.out) NT_STORE(reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n), (u32x4{o.x, o.y, o.z, o.w}));
                     if (Q8 == 2 && ACT != 1 && a.out8) {
                         // fp8 backward: the e5m2 copy of this output gradient, the operand of the next input-gradient GEMM
@@ -1382,6 +1410,12 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
                                int act, int scale_cols, float col_scale, uint8_t* out8, long long ldo8, float out8_scale,
                                const float* qa, const float* qw, float* q8, int m_split, const uint8_t* B2, const float* bias2, const float* qw2,
                                int a_e5m2, const bf16_t* aux, long long ldaux, float* colsum, float* colsum2, hipStream_t stream) {
+    // 8-bit gelu' (fp8 backward): out_f32 == 2 with act 1 - `out` receives the codes (ldo in bytes); a_e5m2 == 2 with act 2 - `aux` holds them (ldaux in bytes)
+    const bool gp8 = (out_f32 == 2) || (a_e5m2 == 2);
+    AVS_CHECK_ARG(out_f32 != 2 || (act == 1 && !a_e5m2 && out && (ldo % 8) == 0 && ldo >= N), "gemm_nt_fp8: out_f32 == 2 (8-bit gelu') goes with act 1 of the forward form");
+    AVS_CHECK_ARG(a_e5m2 != 2 || (act == 2 && aux && ldaux >= N), "gemm_nt_fp8: a_e5m2 == 2 (8-bit gelu' operand) goes with act 2");
+    if (out_f32 == 2) out_f32 = 0;
+    if (a_e5m2 == 2) a_e5m2 = 1;
     // a_e5m2 != 0: the INPUT-GRADIENT form - A holds e5m2 gradients (B stays e4m3: the transposed weight copy); act 0, or act 2 with aux =
     // the saved gelu'(x) (bf16) and colsum (fc1 bias gradient) as in avs_gemm_nt_bf16; out8 then receives e5m2(out) for the next such GEMM
     AVS_CHECK_ARG(!out8 || ((ldo8 % 8) == 0 && ldo8 >= N && (a_e5m2 ? act != 1 : act == 1)),
@@ -1417,6 +1451,7 @@ extern "C" int avs_gemm_nt_fp8(const uint8_t* A, long long lda, const uint8_t* B
                  out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M, dual ? m_split : 0x7fffffff,
                  dual ? reinterpret_cast<const bf16_t*>(B2) : nullptr, dual ? bias2 : nullptr, dual ? colsum2 : nullptr,
                  out8, ldo8, out8_scale, qa, qw, dual ? qw2 : qw, q8, 0.f};
+    a.aux8 = gp8 ? 1 : 0;
     const int ncu = avs_persistent_slots();      // CUs a persistent grid may fill (device CUs - the cu_reserve knob)
     const int tiles = ceil_div(M, 256) * (N / 256);
     const int grid = tiles < ncu ? tiles : ncu;

@@ -251,6 +251,7 @@ class _SideStream:
 
 WGRAD_STREAM_MODE = os.environ.get("AVSIAM_WGRAD_STREAM", "2")     # read once (A/B runs set it before the import)
 WGRAD_GROUP = os.environ.get("AVSIAM_WGRAD_GROUP", "1") != "0"      # a block's fc2 / fc1 / proj weight gradients in one launch (0: A/B)
+FP8_GELU8 = os.environ.get("AVSIAM_FP8_GELU8", "1") != "0"          # fp8 backward: gelu'(x) saved as 8-bit fixed-point codes instead of bf16 (0: A/B)
 _side_streams = {}
 
 
@@ -384,7 +385,9 @@ class Stack:
         self.ln2 = self.ln1 if (inference or lean) else per_block((rp, D), BF16)
         self.qkv = per_block((rp, 3 * D), BF16)
         self.att = per_block((rp, D), BF16)
-        self.fc1 = per_block((rp, hidden), BF16)          # gelu'(fc1 output): all the backward needs of the pre-activation (gemm act 1 / 2)
+        # gelu'(fc1 output): all the backward needs of the pre-activation (gemm act 1 / 2).  With the fp8 backward (modes 2 / 3) it travels as 8-bit
+        # fixed-point codes (ops.gemm_nt_fp8: a uint8 `out` / `aux`): half the bytes of the two epilogues that write and read it (AVSIAM_FP8_GELU8=0: A/B)
+        self.fc1 = per_block((rp, hidden), U8 if (getattr(self, "fp8_bwd", False) and FP8_GELU8) else BF16)
         self.act = (one_for_all if lean else per_block)((rp, hidden), BF16)
         self.lse = per_block((H, rp), F32)
         nshared = nblocks if inference else self.nrecomp

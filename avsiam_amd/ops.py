@@ -360,11 +360,17 @@ def gemm_nt_fp8(A8, B8, out, M, alpha=1.0, bias=None, res=None, out2=None, act=0
     grad=True: the input-gradient form - A8 holds e5m2 gradients; act 0 or 2 (aux = saved gelu'(x), colsum = fc1 bias gradient); out8
     then receives e5m2(out) for the next input-gradient GEMM."""
     _chk(A8, U8, "gemm8.A", 2); _chk(B8, U8, "gemm8.B", 2); _chk(bias, F32, "gemm8.bias"); _chk(res, F32, "gemm8.res", 2); _chk(out2, BF16, "gemm8.out2", 2)
-    _chk(out8, U8, "gemm8.out8", 2); _chk(aux, BF16, "gemm8.aux", 2); _chk(colsum, F32, "gemm8.colsum")
+    _chk(out8, U8, "gemm8.out8", 2); _chk(colsum, F32, "gemm8.colsum")
+    # gelu'(x) as 8-bit fixed-point codes (fp8 backward, round 5): a uint8 `out` with act 1 / a uint8 `aux` with act 2 - the two epilogues that write and read it
+    gp8_out = out is not None and out.dtype == U8
+    gp8_aux = aux is not None and aux.dtype == U8
+    _chk(aux, U8 if gp8_aux else BF16, "gemm8.aux", 2)
+    assert not gp8_out or (act == 1 and not grad), "a uint8 `out` is the 8-bit gelu'(x) of act 1"
+    assert not gp8_aux or (act == 2 and grad), "a uint8 `aux` is the 8-bit gelu'(x) read by act 2"
     N, K = B8.shape
     # 8-bit-only outputs (fp8 mode 3): out=None in the input-gradient form beside out8; out2=None with act 1 beside out8
     assert out is not None or (grad and out8 is not None)
-    assert out is None or (out.dtype in (BF16, F32) and out.dim() == 2 and out.is_contiguous() and out.shape[0] >= M and out.shape[1] == N)
+    assert out is None or (out.dtype in (BF16, F32, U8) and out.dim() == 2 and out.is_contiguous() and out.shape[0] >= M and out.shape[1] == N)
     assert A8.shape[1] == K and A8.shape[0] >= M
     assert (qa is None) == (qw is None)
     assert act in (0, 1, 2) and (act != 2 or (grad and aux is not None and aux.shape[0] >= M and aux.shape[1] == N)) and (act != 1 or not grad)
@@ -377,9 +383,9 @@ def gemm_nt_fp8(A8, B8, out, M, alpha=1.0, bias=None, res=None, out2=None, act=0
         assert B2.shape == B8.shape and B2.stride(0) == B8.stride(0) and 0 < m_split < M and m_split % 256 == 0 and qa is not None and qw2 is not None
         assert (bias2 is None) == (bias is None) and (colsum2 is None) == (colsum is None)
     _launch("gemm_nt_fp8", 2.0 * M * N * K, "avs_gemm_nt_fp8", A8, A8.stride(0), B8, B8.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
-            out, out.stride(0) if out is not None else 0, 1 if (out is not None and out.dtype == F32) else 0, out2, out2.stride(0) if out2 is not None else 0, float(alpha), int(act), int(scale_cols),
+            out, out.stride(0) if out is not None else 0, 2 if gp8_out else 1 if (out is not None and out.dtype == F32) else 0, out2, out2.stride(0) if out2 is not None else 0, float(alpha), int(act), int(scale_cols),
             float(col_scale), out8, out8.stride(0) if out8 is not None else 0, float(out8_scale), _qrec(qa), _qrec(qw), _qrec(q8),
-            int(m_split), B2, bias2, _qrec(qw2), 1 if grad else 0, aux, aux.stride(0) if aux is not None else 0, colsum, colsum2, _stream())
+            int(m_split), B2, bias2, _qrec(qw2), 2 if gp8_aux else 1 if grad else 0, aux, aux.stride(0) if aux is not None else 0, colsum, colsum2, _stream())
 
 
 def gemm_tn(A, B, C, M, splits=0):

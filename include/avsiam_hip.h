@@ -99,6 +99,8 @@ int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long l
  * fmax = 448 (e4m3 tensors) or 57344 (e5m2: the gradient operands of the input-gradient form).
  * Input-gradient form (a_e5m2 != 0; BASELINE configs[4]'s fp8 path in the backward): A holds e5m2 gradients, B the e4m3 transposed weight;
  * act 0, or act 2 with aux / colsum as in avs_gemm_nt_bf16 (fc2 input gradient); out8 (may be NULL) = e5m2(out * q8[0]) for the next one.
+ * gelu'(x) as 8-bit codes (fp8 backward: half the bytes between the two epilogues that write and read it): out_f32 == 2 with act 1 - `out` receives
+ * round((gelu'(x) + 0.1296875) * 202) in [0, 255], one byte per element, ldo in bytes; a_e5m2 == 2 with act 2 - `aux` holds such codes, ldaux in bytes.
  * m_split / B2 / bias2 / qw2: a second weight set for rows from m_split (m_split % 256 == 0; needs the records), else m_split = 0.
  * avs_absmax: out = max(out, max |x|) (caller zeroes out; x fp32 or bf16);
  * avs_quantize_fp8: y = e4m3(clamp(x * scale, +-448)) (e5m2 != 0: e5m2, +-57344), n%4==0; with q: scale = q[0], max |x| into q[2]. */

@@ -1049,6 +1049,45 @@ def test_gemm_nt_fp8(M, N, K, f32out):
     assert 5e-3 < e < 8e-2, e
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (4099, 3072, 768)])
+def test_gemm_nt_fp8_gelu_grad_as_8_bit_codes(M, N, K):
+    """fp8 backward (round 5): gelu'(x) travels from the fc1 forward epilogue (act 1) to the fc2 input-gradient epilogue (act 2) as 8-bit
+    fixed-point codes - (g' + 0.1296875) * 202 in [0, 255] - instead of bf16: a uint8 `out` / `aux` of ops.gemm_nt_fp8.  The codes decode to the
+    bf16 epilogue's gelu'(x) within half a step (0.0025) plus the bf16 rounding; gelu(x) and its e4m3 copy do not change; the input gradient
+    computed with the coded operand equals the one computed with the bf16 operand to 2e-3 - far inside the e5m2 rounding of that gradient."""
+    o = ops()
+    g = torch.Generator(device=DEV).manual_seed(M)
+    Mp = o.pad_rows(M, 256)
+    A8 = torch.zeros(Mp, K, device=DEV, dtype=torch.uint8)
+    o.quantize_fp8(torch.randn(M, K, device=DEV, generator=g), 64.0, out=A8[:M])
+    W8 = o.quantize_fp8((torch.randn(N, K, device=DEV, generator=g) * 0.08).to(torch.bfloat16), 512.0)
+    b = torch.randn(N, device=DEV, generator=g)
+    alpha = 1.0 / (64.0 * 512.0)
+    gp16, act16 = (torch.zeros(Mp, N, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    a8_16, a8_8 = (torch.zeros(Mp, N, device=DEV, dtype=torch.uint8) for _ in range(2))
+    o.gemm_nt_fp8(A8, W8, gp16, M, alpha, bias=b, out2=act16, act=1, out8=a8_16, out8_scale=32.0)
+    gp8 = torch.full((Mp, N), 255, device=DEV, dtype=torch.uint8)
+    act8 = torch.zeros_like(act16)
+    o.gemm_nt_fp8(A8, W8, gp8, M, alpha, bias=b, out2=act8, act=1, out8=a8_8, out8_scale=32.0)
+    assert torch.equal(act8, act16) and torch.equal(a8_8, a8_16)                 # gelu(x) and its e4m3 copy are untouched
+    dec = gp8[:M].float() / 202.0 - 0.1296875
+    err = (dec - gp16[:M].float()).abs().max().item()
+    assert err < 0.0025 + 0.0045, err                                            # half a code step + the bf16 rounding of the reference near 1
+    assert float(dec.min()) > -0.135 and float(dec.max()) < 1.135 and int(gp8[:M].min()) >= 0
+    assert Mp == M or bool((gp8[M:] == 255).all())                               # rows beyond M are not written
+    # the consumer: fc2 input gradient, e5m2 gradient x e4m3 transposed weight, times gelu'(x), with the fused column sum
+    G8 = torch.zeros(Mp, K, device=DEV, dtype=torch.uint8)
+    o.quantize_fp8(torch.randn(M, K, device=DEV, generator=g) * 0.01, 4096.0, out=G8[:M], e5m2=True)
+    alpha_g = 1.0 / (4096.0 * 512.0)
+    d16, d8 = (torch.zeros(Mp, N, device=DEV, dtype=torch.bfloat16) for _ in range(2))
+    c16, c8 = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    o.gemm_nt_fp8(G8, W8, d16, M, alpha_g, act=2, aux=gp16, colsum=c16, grad=True)
+    o.gemm_nt_fp8(G8, W8, d8, M, alpha_g, act=2, aux=gp8, colsum=c8, grad=True)
+    assert rel_err(d8[:M].float(), d16[:M].float()) < 6e-3 and rel_err(c8, c16) < 6e-3
+    want = (G8[:M].view(torch.float8_e5m2).double() / 4096.0) @ (W8.view(torch.float8_e4m3fn).double() / 512.0).t() * dec.double()
+    assert rel_err(d8[:M].float(), want) < 4e-3                                  # bf16 output rounding: the coded operand is applied exactly
+
+
 def test_fp8_delayed_scaling_records():
     """The fp8 mode's device-side quantisation state (ops.Fp8Records, csrc/common.h AVS_Q_*): calibration (absmax -> scale on the device),
     the producers that write e4m3 operands themselves (quantising pass, LayerNorm, GELU epilogue, attention epilogue) read the scale from the
