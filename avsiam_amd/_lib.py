@@ -64,13 +64,26 @@ def load():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_char_p if ret == "str" else ctypes.c_longlong if ret == "ll" else ctypes.c_int
         fn.argtypes = [_CT[k] for k in kinds]
-    _lib = lib
-    # the library never reads the environment (include/avsiam_hip.h): the AVSIAM_* tuning variables are applied HERE, once
+    # the library never reads the environment (include/avsiam_hip.h): the AVSIAM_* tuning variables are applied HERE, once - and BEFORE the
+    # library is published, so that a rejected value fails every load() the same way instead of leaving a half-configured library behind
     for env, knob in _ENV_KNOBS.items():
-        v = os.environ.get(env)
-        if v is not None and v != "":
-            tuning_set(knob, int(v))
+        v = env_value(env)
+        if v is not None:
+            try:
+                value = int(v)
+            except ValueError:
+                raise AvsiamHipError(f"{env}={v!r} is not an integer") from None
+            rc = lib.avs_tuning_set(knob.encode(), value)
+            if rc != 0:
+                raise AvsiamHipError(f"{env}={v}: avs_tuning_set({knob}, {value}) failed ({rc}): {lib.avs_last_error().decode()}")
+    _lib = lib
     return lib
+
+
+def env_value(name):
+    """an AVSIAM_* variable, or None when it is unset OR empty (one emptiness rule for the loader and for set_distributed)"""
+    v = os.environ.get(name)
+    return v if v not in (None, "") else None
 
 
 _ENV_KNOBS = {"AVSIAM_GEMM_TILE": "gemm_tile", "AVSIAM_GEMM_NT8": "gemm_nt8", "AVSIAM_NT_TILE_H": "nt_tile_h", "AVSIAM_NT_GRID": "nt_grid",

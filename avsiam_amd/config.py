@@ -81,7 +81,8 @@ def vit_base(**kw):
 def vit_large(**kw):
     """ViT-L/16 re-parameterisation (BASELINE.json configs[3]); no reference source exists
     for it so parity for this shape is pinned by the oracle only."""
-    return AVSiamConfig(embed_dim=1024, depth=24, num_heads=16, **kw)
+    kw.setdefault("depth", 24)
+    return AVSiamConfig(embed_dim=1024, num_heads=16, **kw)
 
 
 def vit_huge(**kw):
@@ -100,3 +101,87 @@ def vit_huge14(**kw):
     kw.setdefault("audio_tokens", 657)
     kw.setdefault("audio_f", 9)
     return AVSiamConfig(embed_dim=1280, num_heads=16, stride=14, **kw)
+
+
+# =====================================================================================================================
+@dataclass
+class EngineOptions:
+    """How ONE model runs the hot path - precision, activation memory, backward schedule.  A property of the model (round 6): two models with
+    different precisions live side by side in one process, and the entry point chooses per run (`--fp8`, `--recompute`).  The `AVSIAM_*`
+    environment variables only SEED the defaults (`from_env`, read when a model is constructed without the keyword); nothing in the engine
+    reads the environment or a module global any more.
+
+    STRUCTURAL fields are read when a pass engine is built (buffers, fp8 records and kernels selected then): change them through
+    `CAVMAE_BASE.set_options`, which drops the engines.  RUNTIME fields are read on every call.
+
+    fp8           "0" bf16 operands (the headline metric) | "1" e4m3 forward GEMMs | "2" + e5m2 x e4m3 input gradients | "3" + fp8 weight
+                  gradients (BASELINE.json configs[4]'s "fp8 MFMA path"; engine.Stack)                                           [structural]
+    fp8_lean      mode 3: producers whose bf16 output has no reader left write the 8-bit copy only                                [structural]
+    fp8_gelu8     modes 2 / 3: gelu'(x) travels between the fc1 forward and fc2 input-gradient epilogues as 8-bit codes           [structural]
+    gelu8         the same 8-bit gelu'(x) codes in the BF16 path (A/B of VERDICT r5 item 6a; default off)                         [structural]
+    recompute     "0" | "1" | fraction: leading blocks of every stack that keep no activations and re-run their forward           [structural]
+    grad_stream   "bf16" | "fp32": the residual-GRADIENT stream between the blocks of a stack                                     [structural]
+    attn_tile     0 automatic | 64 | 128: rows per attention workgroup (A/B)                                                      [structural]
+    attn_fused    sequences of at most 128 tokens take the single-workgroup attention backward                                    [structural]
+    group_towers  the MAE pass's audio and visual towers as one packed stack with two weight sets per launch                      [structural]
+    prune_dead    pass 2 skips the rows whose loss and gradient are identically zero: prediction heads and their backward on MASKED
+                  rows only; in the last decoder block query / proj / LN2 / MLP / decoder_norm on masked rows only (K, V for all)     [structural]
+    wgrad_stream  "2" weight gradients on a second stream beside attention / LayerNorm backward | "1" beside everything | "0" one
+                  stream                                                                                                          [runtime]
+    wgrad_group   a block's fc2 / fc1 / proj weight gradients in one launch                                                       [runtime]
+    deterministic weight gradients with ONE writer per output tile and an ordered contraction (no split over the token rows, no
+                  cross-workgroup atomics), everything on one stream: two runs of a step are bit-identical.  For debugging (the
+                  first multi-GPU session); slower                                                                                [runtime]
+    """
+    fp8: str = "0"
+    fp8_lean: bool = True
+    fp8_gelu8: bool = True
+    gelu8: bool = False
+    recompute: str = "0"
+    grad_stream: str = "bf16"
+    attn_tile: int = 0
+    attn_fused: bool = True
+    group_towers: bool = True
+    prune_dead: bool = True
+    wgrad_stream: str = "2"
+    wgrad_group: bool = True
+    deterministic: bool = False
+
+    STRUCTURAL = ("fp8", "fp8_lean", "fp8_gelu8", "gelu8", "recompute", "grad_stream", "attn_tile", "attn_fused", "group_towers", "prune_dead")
+
+    _ENV = {"fp8": ("AVSIAM_FP8", str), "fp8_lean": ("AVSIAM_FP8_LEAN", "flag"), "fp8_gelu8": ("AVSIAM_FP8_GELU8", "flag"), "gelu8": ("AVSIAM_GELU8", "flag"),
+            "recompute": ("AVSIAM_RECOMPUTE", str), "grad_stream": ("AVSIAM_GRAD_STREAM", str), "attn_tile": ("AVSIAM_ATTN_TILE", int),
+            "attn_fused": ("AVSIAM_ATTN_FUSED", "flag"), "group_towers": ("AVSIAM_GROUP_TOWERS", "flag"), "prune_dead": ("AVSIAM_PRUNE_DEAD", "flag"),
+            "wgrad_stream": ("AVSIAM_WGRAD_STREAM", str), "wgrad_group": ("AVSIAM_WGRAD_GROUP", "flag"), "deterministic": ("AVSIAM_DETERMINISTIC", "flag")}
+
+    @classmethod
+    def from_env(cls, **over):
+        """defaults <- AVSIAM_* environment (unset or empty: the default) <- keyword overrides that are not None"""
+        import os
+        kw = {}
+        for field, (env, kind) in cls._ENV.items():
+            v = os.environ.get(env)
+            if v in (None, ""):
+                continue
+            kw[field] = (v != "0") if kind == "flag" else kind(v)
+        kw.update({k: v for k, v in over.items() if v is not None})
+        return cls(**kw).validated()
+
+    def validated(self):
+        self.fp8, self.recompute, self.wgrad_stream = str(self.fp8), str(self.recompute), str(self.wgrad_stream)
+        if self.fp8 not in ("0", "1", "2", "3"):
+            raise ValueError(f"fp8 mode must be 0, 1, 2 or 3, not {self.fp8!r}")
+        f = float(self.recompute)
+        if not 0.0 <= f <= 1.0:
+            raise ValueError(f"recompute must be 0, 1 or a fraction between them, not {self.recompute!r}")
+        if self.grad_stream not in ("bf16", "fp32"):
+            raise ValueError(f"grad_stream must be bf16 or fp32, not {self.grad_stream!r}")
+        if self.wgrad_stream not in ("0", "1", "2"):
+            raise ValueError(f"wgrad_stream must be 0, 1 or 2, not {self.wgrad_stream!r}")
+        if self.attn_tile not in (0, 64, 128):
+            raise ValueError(f"attn_tile must be 0, 64 or 128, not {self.attn_tile!r}")
+        return self
+
+    def describe(self):
+        import dataclasses
+        return {k: v for k, v in dataclasses.asdict(self).items()}

@@ -17,7 +17,9 @@ extern "C" void avs_set_error(const char* fmt, ...) {
 
 extern "C" const char* avs_last_error(void) { return g_err; }
 
-extern "C" int avs_abi_version(void) { return 1; }
+// 2 (round 6): avs_attn_fwd / avs_attn_bwd need 16-byte-aligned rows (ldo % 8 == 0; was % 4), avs_gemm_nt_fp8 gives out_f32 == 2 / a_e5m2 == 2
+// a meaning (gelu'(x) as 8-bit codes), "ln_dma" is 0 | 1, the deterministic weight-gradient knob "tn_det" exists
+extern "C" int avs_abi_version(void) { return 2; }
 
 // number of compute units of the current device (used by hosts to size split factors); <0 on error
 extern "C" int avs_device_cu_count(void) {
@@ -48,7 +50,7 @@ struct Knob { const char* name; int AvsTuning::*field; int lo, hi; };
 static const Knob g_knobs[] = {
     {"gemm_tile", &AvsTuning::gemm_tile, 0, 256},   {"gemm_persistent", &AvsTuning::gemm_persistent, 0, 1}, {"gemm_nt8", &AvsTuning::gemm_nt8, 0, 1},
     {"nt_tile_h", &AvsTuning::nt_tile_h, 0, 256},   {"nt_grid", &AvsTuning::nt_grid, 0, 1 << 20},           {"cu_reserve", &AvsTuning::cu_reserve, 0, 128},
-    {"ln_dma", &AvsTuning::ln_dma, 0, 2},           {"ln_rpw", &AvsTuning::ln_rpw, 0, 16},                  {"attn_ring", &AvsTuning::attn_ring, 0, 1},
+    {"ln_dma", &AvsTuning::ln_dma, 0, 1},           {"ln_rpw", &AvsTuning::ln_rpw, 0, 16},                  {"attn_ring", &AvsTuning::attn_ring, 0, 1},
     {"gemm_ring", &AvsTuning::gemm_ring, 0, 2},     {"nt_big_min", &AvsTuning::nt_big_min, 0, 1 << 20},
 };
 

@@ -140,8 +140,7 @@ struct AvsTuning {
                            // and split factors are sized for (CUs - cu_reserve), so that a collective's kernels (RCCL) find CUs WHILE a
                            // GEMM runs instead of only at kernel boundaries.  0 on one GPU; the host sets 8 when world > 1 and the
                            // gradient all-reduce overlaps the backward (comm.py)                                    AVSIAM_CU_RESERVE
-    int ln_dma;            // 1: LayerNorm backward by the LDS-DMA kernel where it applies | 0 never | 2 automatic per launch context
-                           // (avs_layernorm_bwd's `busy_lds` hint)                                                  AVSIAM_LN_DMA
+    int ln_dma;            // 1: LayerNorm backward by the LDS-DMA kernel where it applies | 0 never                 AVSIAM_LN_DMA
     int ln_rpw;            // rows per wave of the LayerNorm backward: 0 automatic | 4 | 8 | 16                      AVSIAM_LN_RPW
     int gemm_ring;         // small forward / input-gradient GEMMs (128 x 128 tiling, at most one workgroup per CU): 0 the two-buffer kernel | 1 the
                            // 4-slot LDS-DMA ring kernel (three K-slabs in flight) | 2 (default) also: under half the CUs -> every row as 64 x 128

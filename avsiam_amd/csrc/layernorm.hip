@@ -440,8 +440,10 @@ extern "C" int avs_layernorm_fwd_q8(const float* x, const float* g0, const float
                                     const uint8_t* row_mod, const int* out_map, void* y, int y_f32, float* mean, float* rstd,
                                     int rows, int D, float eps, uint8_t* y8, float q8, float* q8_dev, hipStream_t stream) {
     AVS_CHECK_ARG(!(y8 && y_f32), "layernorm_fwd: the fp8 copy goes with the bf16 output");
-    // D = 1536: the concatenated audio|video feature of the fusion classification head (forward only)
-    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280 || D == 1536), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
+    // D = 1536 / 2048 / 2560: the concatenated audio|video feature of the fusion classification head at ViT-B / ViT-L / ViT-H width (forward
+    // only, no e4m3 copy)
+    AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280 || D == 1536 || D == 2048 || D == 2560), "layernorm_fwd: unsupported rows=%d D=%d", rows, D);
+    AVS_CHECK_ARG(!(y8 && D > 1536), "layernorm_fwd: no e4m3 copy at D=%d", D);
     AVS_CHECK_ARG(x && g0 && b0 && (y || (y8 && !y_f32)) && mean && rstd, "layernorm_fwd: null pointer (y may be NULL only beside y8)");
     AVS_CHECK_ARG(!row_mod || (g1 && b1), "layernorm_fwd: row_mod given without second affine set");
     dim3 grid(ceil_div(rows, 4)), block(256);
@@ -450,9 +452,11 @@ extern "C" int avs_layernorm_fwd_q8(const float* x, const float* g0, const float
     if (y8 && q8_dev) {                                   // e4m3 copy with a record: 8 rows per wave, one amax atomic per wave
         if (D == 512) LN_FWD8(2); else if (D == 768) LN_FWD8(3); else if (D == 1024) LN_FWD8(4); else if (D == 1280) LN_FWD8(5); else LN_FWD8(6);
     } else if (y_f32) {
-        if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else if (D == 1024) LN_FWD(4, true); else if (D == 1280) LN_FWD(5, true); else LN_FWD(6, true);
+        if (D == 512) LN_FWD(2, true); else if (D == 768) LN_FWD(3, true); else if (D == 1024) LN_FWD(4, true); else if (D == 1280) LN_FWD(5, true);
+        else if (D == 1536) LN_FWD(6, true); else if (D == 2048) LN_FWD(8, true); else LN_FWD(10, true);
     } else {
-        if (D == 512) LN_FWD(2, false); else if (D == 768) LN_FWD(3, false); else if (D == 1024) LN_FWD(4, false); else if (D == 1280) LN_FWD(5, false); else LN_FWD(6, false);
+        if (D == 512) LN_FWD(2, false); else if (D == 768) LN_FWD(3, false); else if (D == 1024) LN_FWD(4, false); else if (D == 1280) LN_FWD(5, false);
+        else if (D == 1536) LN_FWD(6, false); else if (D == 2048) LN_FWD(8, false); else LN_FWD(10, false);
     }
 #undef LN_FWD
 #undef LN_FWD8

@@ -24,7 +24,7 @@ import torch
 
 from . import ops
 from .arena import ParamArena
-from .config import AVSiamConfig
+from .config import AVSiamConfig, EngineOptions
 from .maskplan import ContrastivePlan, MaePlan, group_sizes, group_ratio, len_keep
 
 BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
@@ -37,14 +37,14 @@ LN_EPS_BLOCK, LN_EPS_FINAL = 1e-5, 1e-6       # nn.LayerNorm default in Block; t
 # A FRACTION (AVSIAM_RECOMPUTE=0.5 / bench.py --recompute 0.5) recomputes only the first ceil(f x nblocks) blocks of every Stack and
 # saves the others' activations as usual: the memory between "everything recomputed" (75 GiB at ViT-H/14, batch 64) and the card's
 # 288 GB buys back the same share of the recompute time.
-RECOMPUTE = os.environ.get("AVSIAM_RECOMPUTE", "0")
+# -> EngineOptions.recompute (config.py): a property of the model, seeded by AVSIAM_RECOMPUTE.
 
 
-def recompute_blocks(nblocks, setting=None):
-    """number of leading blocks of a Stack of `nblocks` that are recomputed under engine.RECOMPUTE ("0" | "1" | a fraction in (0, 1))"""
-    f = float(RECOMPUTE if setting is None else setting)
+def recompute_blocks(nblocks, setting):
+    """number of leading blocks of a Stack of `nblocks` that are recomputed under EngineOptions.recompute ("0" | "1" | a fraction in (0, 1))"""
+    f = float(setting)
     if not 0.0 <= f <= 1.0:
-        raise ValueError(f"AVSIAM_RECOMPUTE must be 0, 1 or a fraction between them, not {f}")
+        raise ValueError(f"recompute must be 0, 1 or a fraction between them, not {f}")
     return min(nblocks, int(math.ceil(f * nblocks - 1e-9)))
 # fp8 forward (AVSIAM_FP8=1 / bench.py --fp8; BASELINE configs[4]'s "fp8 MFMA path", never the default): the four forward GEMMs of a
 # block (qkv, proj, fc1, fc2) take OCP e4m3 operands with per-tensor DELAYED scaling and accumulate in fp32.  Every quantised tensor has a
@@ -60,21 +60,21 @@ def recompute_blocks(nblocks, setting=None):
 # backward (residual gradient), the fc2 input-gradient epilogue and the three attention backward kernels (dqkv; avs_attn_bwd_q8 /
 # avs_attn_bwd_fused_q8); own records, fmax 57344 - against the e4m3 copy of the transposed weight (the forward's weight scale).
 # The weight gradients stay bf16.
-FP8 = os.environ.get("AVSIAM_FP8", "0")
+# -> EngineOptions.fp8 ("0" | "1" | "2" | "3"): a property of the model (CAVMAE_BASE(fp8_mode=...), --fp8 at the entry point), seeded by AVSIAM_FP8.
 # AVSIAM_FP8=3 only.  With the weight gradients on fp8 operands four bf16 tensors of a block have no reader left once their consumers'
 # records are calibrated: the two LayerNorm outputs and gelu(x) (read by qkv / fc1 / fc2 and their weight gradients - all in e4m3) and
 # the fc2 input gradient (read by fc1's input- and weight-gradient GEMMs in e5m2; fc1's bias gradient is the fused column sum).  "1"
 # (default): their producers write the 8-bit copy ONLY (NULL bf16 output) and the three activations live in one shared buffer per stack
 # instead of one per block - 2 x D + hidden fewer bf16 values written and kept per token and block, and the GEMM epilogues that wrote
 # them (bound by the write burst of all CUs at once) shrink to 3/5 (fc1) and 1/3 (fc2 input gradient) of their bytes.  "0": A/B.
-FP8_LEAN = os.environ.get("AVSIAM_FP8_LEAN", "1") != "0"
+# -> EngineOptions.fp8_lean.
 # The residual-GRADIENT stream between the blocks of a stack (AVSIAM_GRAD_STREAM=bf16 | fp32).  bf16 (default): a LayerNorm backward
 # reads the upstream residual gradient from the bf16 copy the previous LayerNorm backward wrote for the GEMMs anyway and writes
 # only its own bf16 copy - 10 instead of 16 bytes per element and call (the kernel is HBM-bound); the sum itself is formed in fp32
 # registers and rounded once per LayerNorm (2 x depth roundings of 2^-9 along a stack: ~0.5 % rms at the bottom of 12 blocks,
 # inside the bf16 operand noise the gradients already carry).  A stack's OUTPUT gradient (block 0) is still written in fp32.
 # fp32: the round-2 behaviour (fp32 stream beside the bf16 copies).
-GRAD_STREAM = os.environ.get("AVSIAM_GRAD_STREAM", "bf16")
+# -> EngineOptions.grad_stream.
 
 
 def _z(shape, dtype, dev):
@@ -210,7 +210,7 @@ def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, 
 
 def _dx_in(stack):
     """fp32 buffer for the gradient a stack's backward STARTS from: only the fp32 gradient stream reads it"""
-    return None if GRAD_STREAM == "bf16" else stack.dx[0]
+    return None if stack.opts.grad_stream == "bf16" else stack.dx[0]
 
 
 class _SideStream:
@@ -249,9 +249,7 @@ class _SideStream:
         self.done.clear()
 
 
-WGRAD_STREAM_MODE = os.environ.get("AVSIAM_WGRAD_STREAM", "2")     # read once (A/B runs set it before the import)
-WGRAD_GROUP = os.environ.get("AVSIAM_WGRAD_GROUP", "1") != "0"      # a block's fc2 / fc1 / proj weight gradients in one launch (0: A/B)
-FP8_GELU8 = os.environ.get("AVSIAM_FP8_GELU8", "1") != "0"          # fp8 backward: gelu'(x) saved as 8-bit fixed-point codes instead of bf16 (0: A/B)
+# (EngineOptions.wgrad_stream / wgrad_group / fp8_gelu8: runtime and structural options of the model, config.py)
 _side_streams = {}
 
 
@@ -279,13 +277,17 @@ class _Inline:
 class Stack:
     """`nblocks` transformer blocks over a packed [rows, D] fp32 residual stream with saved activations."""
 
-    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None, inference=False, pool=None):
+    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None, inference=False, pool=None, opts=None):
         """inference=True: forward only - no activation is kept, every block reuses one set of buffers (the residual stream
         ping-pongs between two) and the backward scratch is not allocated.
-        pool (BufferPool): the stack's per-token buffers come from the model's shared activation pool instead of torch.zeros."""
+        pool (BufferPool): the stack's per-token buffers come from the model's shared activation pool instead of torch.zeros.
+        opts (config.EngineOptions): the MODEL's options object, shared by reference - structural fields are read here, runtime fields
+        (wgrad_stream, wgrad_group, deterministic) on every backward."""
         assert sum(seq_lens) == rows
         assert pool is None or not inference
         self.pool = pool
+        self.opts = opts = opts if opts is not None else EngineOptions.from_env()
+        FP8, FP8_LEAN, FP8_GELU8 = opts.fp8, opts.fp8_lean, opts.fp8_gelu8
         self._pads = ops.ZeroTable() if pool is not None else None
 
         def _z(shape, dtype, dev_):          # (shadows the module's _z for every allocation below)
@@ -298,7 +300,7 @@ class Stack:
         self.rows, self.D, self.H, self.hidden, self.nblocks = rows, D, H, hidden, nblocks
         self.row_mod = row_mod
         self.inference = inference
-        self.nrecomp = 0 if inference else recompute_blocks(nblocks)     # blocks [0, nrecomp) keep no activations (one shared set)
+        self.nrecomp = 0 if inference else recompute_blocks(nblocks, opts.recompute)     # blocks [0, nrecomp) keep no activations (one shared set)
         self.recompute = self.nrecomp > 0
         self.fp8 = FP8 in ("1", "2", "3") and D % 256 == 0 and hidden % 256 == 0 and D >= 256     # the fp8 GEMM's tile constraints (N % 256, K % 128)
         self.fp8_bwd = self.fp8 and FP8 in ("2", "3") and not inference
@@ -346,7 +348,7 @@ class Stack:
         # step's mixes (tools/bench_attn.py --step): the backward of the contrastive pass (39-196 video, 102-512 audio tokens) is 12 %
         # faster with 64-row workgroups, its forward 11 % slower; 49/128-token towers: forward 10 % faster; 618 and 2472 tokens: 128
         mean_len = rows / max(1, len(seq_lens))
-        force = int(os.environ.get("AVSIAM_ATTN_TILE", "0"))                 # A/B switch: 64 | 128 for every stack and direction
+        force = int(opts.attn_tile)                                           # A/B switch: 64 | 128 for every stack and direction
         if D // H == 80:
             force = 128                                                       # the hd-80 instantiation (ViT-H) exists for 128-row workgroups only
         self.tiles = ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_len < 64 else 128))
@@ -357,7 +359,7 @@ class Stack:
         if inference:
             self.tiles_bwd = self.tiles
         else:
-            cut = 128 if (os.environ.get("AVSIAM_ATTN_FUSED", "1") != "0" and D // H in (32, 64)) else 0
+            cut = 128 if (opts.attn_fused and D // H in (32, 64)) else 0
             if cut:
                 self.fused_bwd = [sq for sq in (ops.AttnSeqs(seq_lens, dev, 0, 64), ops.AttnSeqs(seq_lens, dev, 64, 128)) if sq.nseq]
             long_lens = [L for L in seq_lens if L > cut]
@@ -604,12 +606,12 @@ class Stack:
         # still reading them on a second stream would race with the refill, so everything runs on one stream
         # (a partially recomputed stack - engine.RECOMPUTE a fraction - uses the second stream for the blocks that keep their own buffers and
         #  joins it in front of the first recomputed block, see the loop)
-        mode = "0" if self.nrecomp >= self.nblocks else WGRAD_STREAM_MODE
+        mode = "0" if (self.nrecomp >= self.nblocks or self.opts.deterministic) else self.opts.wgrad_stream
         side = _side_stream(dxo.device) if mode in ("1", "2") else _Inline()
         excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
         grp = excl or mode == "0"     # the block's fc2 / fc1 / proj weight gradients are issued together (one grouped launch); mode 1
                                       # issues each as early as its operands exist
-        g16 = GRAD_STREAM == "bf16"   # the residual gradient travels between the LayerNorm backwards in bf16 only
+        g16 = self.opts.grad_stream == "bf16"   # the residual gradient travels between the LayerNorm backwards in bf16 only
 
         done = set()
 
@@ -640,7 +642,7 @@ class Stack:
                         ops.gemm_tn_fp8_group(jobs8, hi - lo)
                         continue
                     trip = [(a[lo:], b[lo:], getattr(bl[blk], name).gw) for a, b, name in jobs]
-                    if WGRAD_GROUP:
+                    if self.opts.wgrad_group:
                         ops.gemm_tn_group(trip, hi - lo)
                     else:
                         for A, B, C in trip:
@@ -814,10 +816,11 @@ def _fold_frames(imgs, T):
 class ContrastivePass:
     """Pass 1 (forward_encoder_mmixed + forward_contrastive, cav_mae_base.py:508-594,641-661)."""
 
-    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, world=1, rank=0, comm=None, pool=None):
+    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, world=1, rank=0, comm=None, pool=None, opts=None):
         self.arena, self.cfg, self.B, self.dev, self.world, self.rank = arena, cfg, batch, dev, world, rank
         self.comm = comm
         self.pool = pool
+        self.opts = opts = opts if opts is not None else EngineOptions.from_env()
         if pool is not None:
             pool.rewind()                      # (BufferPool: this pass's stacks start at the first byte, over the other pass's)
         assert world == 1 or comm is not None, "data parallel needs a collective (model.set_distributed)"
@@ -833,7 +836,7 @@ class ContrastivePass:
         rows = self.rows_a + self.rows_v
         self.rows = rows
         row_mod = torch.cat([torch.zeros(self.rows_a, dtype=U8), torch.ones(self.rows_v, dtype=U8)]).to(dev)
-        self.stack = Stack(dev, rows, D, cfg.num_heads, D * cfg.mlp_ratio, lens_a + lens_v, cfg.depth, row_mod, pool=pool)
+        self.stack = Stack(dev, rows, D, cfg.num_heads, D * cfg.mlp_ratio, lens_a + lens_v, cfg.depth, row_mod, pool=pool, opts=opts)
         self.blocks = [BlockParams(arena, f"vit_base.blocks.{i}", "_a", "_v") for i in range(cfg.depth)]
         self.final = [Norm(arena, "vit_base.norm_a"), Norm(arena, "vit_base.norm")]
         self.row_src_all, self.row_tok_all = _z((rows,), I32, dev), _z((rows,), I32, dev)
@@ -1038,9 +1041,10 @@ class MaePass:
     """Pass 2 (forward_encoder + mm layers + forward_decoder + forward_mae_loss, cav_mae_base.py:441-504,597-638,
     663-683,694-707)."""
 
-    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, pool=None):
+    def __init__(self, arena: ParamArena, cfg: AVSiamConfig, batch, dev, pool=None, opts=None):
         self.arena, self.cfg, self.B, self.dev = arena, cfg, batch, dev
         self.pool = pool
+        self.opts = opts = opts if opts is not None else EngineOptions.from_env()
         if pool is not None:
             pool.rewind()
         B, T, D, Dd = batch, cfg.frames, cfg.embed_dim, cfg.dec_dim
@@ -1052,16 +1056,16 @@ class MaePass:
         # The audio tower (ast_base blocks, plain norms) and the visual tower (vit_base blocks, '_v' norms) are independent and
         # structurally identical: when the audio rows end on a 256-row tile boundary they run as ONE packed stack whose GEMMs
         # take both weight sets per launch (8 192 audio rows alone fill 37 % of the chip with 256^2 tiles).  Otherwise two stacks.
-        self.grouped = self.rows_a % 256 == 0 and os.environ.get("AVSIAM_GROUP_TOWERS", "1") != "0"      # env: A/B measurements
+        self.grouped = self.rows_a % 256 == 0 and opts.group_towers               # (EngineOptions.group_towers False: A/B measurements)
         if self.grouped:
             row_mod = torch.cat([torch.zeros(self.rows_a, dtype=U8), torch.ones(self.rows_v, dtype=U8)]).to(dev)
-            self.st_t = Stack(dev, self.rows_a + self.rows_v, D, cfg.num_heads, hid, [ka] * B + [kv] * (B * T), cfg.depth, row_mod, pool=pool)
+            self.st_t = Stack(dev, self.rows_a + self.rows_v, D, cfg.num_heads, hid, [ka] * B + [kv] * (B * T), cfg.depth, row_mod, pool=pool, opts=opts)
             self.st_a = self.st_v = None
         else:
-            self.st_a = Stack(dev, self.rows_a, D, cfg.num_heads, hid, [ka] * B, cfg.depth, pool=pool)
-            self.st_v = Stack(dev, self.rows_v, D, cfg.num_heads, hid, [kv] * (B * T), cfg.depth, pool=pool)
-        self.st_mm = Stack(dev, B * self.n_enc, D, cfg.num_heads, hid, [self.n_enc] * B, 2, pool=pool)
-        self.st_dec = Stack(dev, B * self.Ltot, Dd, cfg.dec_heads, Dd * cfg.mlp_ratio, [self.Ltot] * B, cfg.dec_depth, pool=pool)
+            self.st_a = Stack(dev, self.rows_a, D, cfg.num_heads, hid, [ka] * B, cfg.depth, pool=pool, opts=opts)
+            self.st_v = Stack(dev, self.rows_v, D, cfg.num_heads, hid, [kv] * (B * T), cfg.depth, pool=pool, opts=opts)
+        self.st_mm = Stack(dev, B * self.n_enc, D, cfg.num_heads, hid, [self.n_enc] * B, 2, pool=pool, opts=opts)
+        self.st_dec = Stack(dev, B * self.Ltot, Dd, cfg.dec_heads, Dd * cfg.mlp_ratio, [self.Ltot] * B, cfg.dec_depth, pool=pool, opts=opts)
         self.blk_a = [BlockParams(arena, f"ast_base.blocks.{i}", "") for i in range(cfg.depth)]      # :489
         self.blk_v = [BlockParams(arena, f"vit_base.blocks.{i}", "_v") for i in range(cfg.depth)]   # :487
         self.blk_mm = [BlockParams(arena, "mm_layer_1", "_a"), BlockParams(arena, "mm_layer_2", "_a")]   # :699-700
@@ -1236,7 +1240,7 @@ class MaePass:
         rows_j = B * self.n_enc
         ops.cast_scale(self.dde, self.dde_b, rows_j * Dd, 1.0)
         sm = self.st_mm
-        if GRAD_STREAM == "bf16":                       # the joint layers' backward starts from the bf16 gradient alone
+        if self.opts.grad_stream == "bf16":                       # the joint layers' backward starts from the bf16 gradient alone
             ops.gemm_nt(self.dde_b, self.dec_embed.wt, sm.dxb[0], rows_j)
         else:
             ops.gemm_nt(self.dde_b, self.dec_embed.wt, sm.dx[0], rows_j)
@@ -1248,7 +1252,7 @@ class MaePass:
             st, ra = self.st_t, self.rows_a
             for lo, fin, fstat, omap, rows, blks in ((0, self.fin_a, self.fstat_a, self.map_a, self.rows_a, self.blk_a),
                                                      (ra, self.fin_v, self.fstat_v, self.map_v, self.rows_v, self.blk_v)):
-                _ln_bwd(sm.dx[0], st.out[lo:], fstat[0], fstat[1], fin, None if GRAD_STREAM == "bf16" else st.dx[0][lo:], st.lnws, rows,
+                _ln_bwd(sm.dx[0], st.out[lo:], fstat[0], fstat[1], fin, None if self.opts.grad_stream == "bf16" else st.dx[0][lo:], st.lnws, rows,
                         out_map=omap, dx_bf16=st.dxb[0][lo:], dcol=blks[-1].fc2.gb)
             st.backward(self.blk_a, last_fc2_bias_done=True, blocks2=self.blk_v, split=ra, reducer=reducer, accumulate=accumulate)
             self.emb_a.backward(st.dx[0][:ra])

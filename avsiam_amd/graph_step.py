@@ -13,8 +13,8 @@ What changes from step to step must not be a kernel ARGUMENT (frozen at capture)
   * Adam's step count lives in device memory (`avs_adam_dev`), advanced by a node of the graph; the bias corrections are evaluated in
     the kernel (double, like torch.optim.Adam);
   * the batch: `a` / `v` are FIXED device buffers - copy each new batch into them (`.copy_`) before `step()`.
-The counters are re-written from the model's host-side state in front of every replay (three fill kernels), so eager steps and
-replayed steps may be mixed freely; results equal the eager step's (same kernels, same order, same keys -
+The counters are re-written from the model's host-side state and the host part of the contrastive draw is made in front of EVERY replay
+(three fill kernels, three small copies), so eager steps and replayed steps may be mixed freely; results equal the eager step's (same kernels, same order, same keys -
 tests/test_train_gpu.py::test_graphed_step_equals_the_eager_step).
 
 Single GPU only: the data-parallel reducer issues its collectives from the host as the backward proceeds."""
@@ -52,9 +52,13 @@ class GraphedTrainStep:
         n0 = _lib.calls
         model._graph = {"seed": self.seed_dev, "steps": self.steps_dev}
         try:
-            self.eng_c.draw_host(model._np_rng())         # (what the replayed step does in front of the graph; this draw is consumed by the first replay)
-            self._host_drawn = True
-            with torch.cuda.graph(self.graph):
+            # Nothing is drawn on the host here: the capture records the kernels with whatever the descriptor buffers hold (the warm-up's
+            # draw), and EVERY replay is preceded by its own draw_host() in step() - so an eager draw on the same engine between the capture
+            # and a replay (validate() at an epoch end, a recapture after a learning-rate change) cannot hand its permutation to the
+            # replayed step, and the numpy generator advances exactly once per step whichever way the step runs.
+            # capture_error_mode "thread_local": a HIP call from ANOTHER thread during the capture window (a DataLoader's pin-memory thread,
+            # a checkpoint writer) must not invalidate the capture; the step's own two streams belong to this thread.
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = train_step(model, a, v, self.lr)
         finally:
             model._graph = None
@@ -78,9 +82,7 @@ class GraphedTrainStep:
         (loss_pass2, loss_mae_a, loss_mae_v, loss_c, c_acc) - the SAME tensors every call (copy them to keep a history)"""
         m = self.model
         self._sync_counters()
-        if not self._host_drawn:
-            self.eng_c.draw_host(m._np_rng())
-        self._host_drawn = False
+        self.eng_c.draw_host(m._np_rng())                 # this replay's contrastive permutations / structured picks (host part of the draw)
         self.graph.replay()
         m._draws = getattr(m, "_draws", 0) + 2            # two plans were drawn (contrastive, MAE)
         for w in (P1, P2):

@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from .. import _lib
 from ..arena import ParamArena
-from ..config import AVSiamConfig
+from ..config import AVSiamConfig, EngineOptions
 from ..maskplan import ContrastivePlan, MaePlan, make_contrastive_plan, make_mae_plan
 from ..param_spec import P1, P2, build_spec
 from ..weights import synth_state
@@ -149,8 +149,16 @@ class CAVMAE_BASE(nn.Module):
     def __init__(self, img_size=224, audio_length=1024, patch_size=16, in_chans=3, embed_dim=768,
                  modality_specific_depth=23, num_heads=16, decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16,
                  mlp_ratio=4., norm_layer=nn.LayerNorm, norm_pix_loss=False, tr_pos=False, opt=None, *,
-                 cfg: AVSiamConfig = None, init_seed=0, init_mode="init", plan_seed=None, verbose=True, share_pass_buffers=None):
+                 cfg: AVSiamConfig = None, init_seed=0, init_mode="init", plan_seed=None, verbose=True, share_pass_buffers=None,
+                 fp8_mode=None, recompute=None, grad_stream=None, options: EngineOptions = None):
+        """Positional arguments: the reference's (cav_mae_base.py:219-222), accepted and - like there - mostly ignored.  Keyword-only
+        extensions: `cfg` (shape), `fp8_mode` ("0".."3"), `recompute` ("0" | "1" | fraction), `grad_stream` ("bf16" | "fp32"),
+        `share_pass_buffers`, or a whole `options` object (config.EngineOptions) - precision and memory policy belong to THIS model;
+        the AVSIAM_* environment only seeds what is not given."""
         super().__init__()
+        if options is not None and any(x is not None for x in (fp8_mode, recompute, grad_stream)):
+            raise ValueError("pass either `options` or the single keywords (fp8_mode / recompute / grad_stream), not both")
+        self.options = options.validated() if options is not None else EngineOptions.from_env(fp8=fp8_mode, recompute=recompute, grad_stream=grad_stream)
         # engine.BufferPool: the two passes of the training step (run one after the other) take their activation buffers from the SAME
         # memory - the card holds the larger pass, not the sum.  Opt-in (None: AVSIAM_SHARE_PASS_BUFFERS=1); a combined-loss forward WITH
         # gradients (both passes alive until one backward) is then refused.
@@ -190,6 +198,19 @@ class CAVMAE_BASE(nn.Module):
         self._plan_seed = plan_seed
         self._shadow_dirty = True
         self._graph = None                         # graph_step.GraphedTrainStep: {"seed": int64 [1], "steps": {P1: int32 [1], P2: int32 [1]}} on the device
+
+    def set_options(self, **kw):
+        """Change options of this model (config.EngineOptions).  A STRUCTURAL change (precision, recompute, gradient stream, ...) drops the
+        pass engines - activation buffers and fp8 records are rebuilt by the next forward; save `fp8_state()` first if the delayed scales are
+        to survive.  Runtime fields (wgrad_stream, wgrad_group, deterministic) take effect on the next backward."""
+        import dataclasses
+        new = dataclasses.replace(self.options, **kw).validated()
+        structural = any(getattr(new, f) != getattr(self.options, f) for f in EngineOptions.STRUCTURAL)
+        if structural:
+            self.release_buffers()
+        for f in dataclasses.fields(EngineOptions):                 # in place: the engines hold this object by reference
+            setattr(self.options, f.name, getattr(new, f.name))
+        return self.options
 
     # ---- device management: parameters are views of one flat buffer, so move the buffer and re-point them -------
     def _apply(self, fn, recurse=True):
@@ -237,7 +258,7 @@ class CAVMAE_BASE(nn.Module):
         # avs_tuning_set) - 8 by default when collectives are on the path (one per XCD; AVSIAM_CU_RESERVE overrides, 0 = none).
         # One blocking message after the backward (AVSIAM_DP_OVERLAP=0) needs no reservation.  Cost at one rank: DESIGN.md 5e.
         # (the knob is process-wide, like the device: the last model to call set_distributed decides)
-        if self.arena.p.is_cuda and os.environ.get("AVSIAM_CU_RESERVE") is None:
+        if self.arena.p.is_cuda and _lib.env_value("AVSIAM_CU_RESERVE") is None:
             overlap = os.environ.get("AVSIAM_DP_OVERLAP", "1") != "0"
             _lib.tuning_set("cu_reserve", 8 if (self._dp and overlap) else 0)
 
@@ -303,9 +324,9 @@ class CAVMAE_BASE(nn.Module):
                 from ..engine import BufferPool
                 self._pool = BufferPool(dev)
             if which == "mae":
-                self._engines[key] = MaePass(self.arena, self.cfg, batch, dev, pool=self._pool)
+                self._engines[key] = MaePass(self.arena, self.cfg, batch, dev, pool=self._pool, opts=self.options)
             else:
-                self._engines[key] = ContrastivePass(self.arena, self.cfg, batch, dev, self._world, self._rank, self._comm, pool=self._pool)
+                self._engines[key] = ContrastivePass(self.arena, self.cfg, batch, dev, self._world, self._rank, self._comm, pool=self._pool, opts=self.options)
             pend = getattr(self, "_fp8_pending", None)
             if pend:                                    # a restored run continues with the quantisation grids it was saved with
                 for name, st in self._fp8_stacks(which, self._engines[key]):
@@ -313,7 +334,7 @@ class CAVMAE_BASE(nn.Module):
                         st.load_fp8_state(pend[f"{which}/{batch}/{name}"])
         return self._engines[key]
 
-    # ---- fp8 mode (engine.FP8): delayed-scaling state travels with the checkpoint ---------------------------------
+    # ---- fp8 mode (EngineOptions.fp8): delayed-scaling state travels with the checkpoint ---------------------------------
     @staticmethod
     def _fp8_stacks(which, eng):
         for name in ("stack", "st_t", "st_a", "st_v", "st_mm", "st_dec"):
@@ -602,3 +623,27 @@ class _NoCtx:
 
 
 CAVMAE = CAVMAE_BASE          # north-star wording "CAVMAE": same signature family
+
+
+class CAVMAE_LARGE(CAVMAE_BASE):
+    """``models.CAVMAE_LARGE`` (/root/reference/src/models/__init__.py:9; its source file cav_mae_large.py is absent from the snapshot): the same
+    model on a ViT-L/16 skeleton - BASELINE.json configs[3].  Same constructor and forward as CAVMAE_BASE; the shape is ``config.vit_large()``
+    unless a ``cfg`` is given (frames, audio tokens).  Parity is pinned by the oracle only (no reference source for this width)."""
+
+    def __init__(self, *args, cfg: AVSiamConfig = None, **kw):
+        from ..config import vit_large
+        if cfg is not None and (cfg.embed_dim, cfg.num_heads) != (1024, 16):
+            raise ValueError("CAVMAE_LARGE: cfg must be a ViT-L shape (config.vit_large(...))")
+        super().__init__(*args, cfg=cfg if cfg is not None else vit_large(), **kw)
+
+
+class CAVMAE_HUGE(CAVMAE_BASE):
+    """``models.CAVMAE_HUGE`` (/root/reference/src/models/__init__.py:13; source file absent): ViT-H/14 skeleton - 1280 wide, 32 layers, 16 heads
+    of 80, 14 x 14 patches (256 tokens per frame, 9 x 73 audio tokens) - BASELINE.json configs[4].  ``fp8_mode="3"`` selects that config's
+    fp8 MFMA path for this model alone.  Shape ``config.vit_huge14()`` unless a ``cfg`` is given; oracle-only parity."""
+
+    def __init__(self, *args, cfg: AVSiamConfig = None, **kw):
+        from ..config import vit_huge14
+        if cfg is not None and (cfg.embed_dim, cfg.num_heads) != (1280, 16):
+            raise ValueError("CAVMAE_HUGE: cfg must be a ViT-H shape (config.vit_huge14(...) / config.vit_huge(...))")
+        super().__init__(*args, cfg=cfg if cfg is not None else vit_huge14(), **kw)

@@ -135,3 +135,27 @@ class CAVMAEFT_BASE(nn.Module):
         if is_eval:
             return res.clone()
         return tuple(r.clone() for r in res)
+
+
+CAVMAEFT = CAVMAEFT_BASE      # (/root/reference/src/models/__init__.py:8 exports the name; same signature family)
+
+
+class CAVMAEFT_LARGE(CAVMAEFT_BASE):
+    """``models.CAVMAEFT_LARGE`` (/root/reference/src/models/__init__.py:9; source file absent from the snapshot): the same inference modes on
+    the ViT-L/16 skeleton (``config.vit_large()``); oracle-only parity (oracle/ref_cpu.py::ft_forward is shape-generic)."""
+
+    def __init__(self, label_dim, *args, cfg: AVSiamConfig = None, **kw):
+        from ..config import vit_large
+        if cfg is not None and (cfg.embed_dim, cfg.num_heads) != (1024, 16):
+            raise ValueError("CAVMAEFT_LARGE: cfg must be a ViT-L shape (config.vit_large(...))")
+        super().__init__(label_dim, *args, cfg=cfg if cfg is not None else vit_large(), **kw)
+
+
+class CAVMAEFT_HUGE(CAVMAEFT_BASE):
+    """``models.CAVMAEFT_HUGE`` (/root/reference/src/models/__init__.py:13; source file absent): ViT-H/14 skeleton (``config.vit_huge14()``)."""
+
+    def __init__(self, label_dim, *args, cfg: AVSiamConfig = None, **kw):
+        from ..config import vit_huge14
+        if cfg is not None and (cfg.embed_dim, cfg.num_heads) != (1280, 16):
+            raise ValueError("CAVMAEFT_HUGE: cfg must be a ViT-H shape (config.vit_huge14(...) / config.vit_huge(...))")
+        super().__init__(label_dim, *args, cfg=cfg if cfg is not None else vit_huge14(), **kw)

@@ -20,6 +20,10 @@ import pickle
 import time
 
 
+# --model -> (class name in avsiam_amd.models, shape function in avsiam_amd.config, patch stride)
+MODELS = {"cav-mae": ("CAVMAE_BASE", "vit_base", 16), "cav-mae-large": ("CAVMAE_LARGE", "vit_large", 16), "cav-mae-huge14": ("CAVMAE_HUGE", "vit_huge14", 14)}
+
+
 def build_parser():
     parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     parser.add_argument("--data-train", type=str, default='', help="training data json ('' or 'synthetic': synthetic tensors)")
@@ -27,7 +31,9 @@ def build_parser():
     parser.add_argument("--data-eval", type=str, default=None, help="evaluation data json")
     parser.add_argument("--label-csv", type=str, default='', help="csv with class labels")
     parser.add_argument("--n_class", type=int, default=527, help="number of classes")
-    parser.add_argument("--model", type=str, default='cav-mae', help="the model used")
+    parser.add_argument("--model", type=str, default='cav-mae', choices=list(MODELS),
+                        help="the model used: cav-mae = models.CAVMAE_BASE (the only one the reference's entry point builds, :171-175); cav-mae-large / "
+                             "cav-mae-huge14 = models.CAVMAE_LARGE / CAVMAE_HUGE, the skeletons the reference exports by name (src/models/__init__.py:9,13)")
     parser.add_argument("--dataset", type=str, default="audioset", choices=["audioset", "esc50", "speechcommands", "fsd50k", "vggsound", "epic", "k400", "msrvtt"])
     parser.add_argument("--dataset_mean", type=float, default=-5.081)
     parser.add_argument("--dataset_std", type=float, default=4.4849)
@@ -66,6 +72,13 @@ def build_parser():
     parser.add_argument('--local_rank', default=-1, type=int)
     parser.add_argument('--dist_url', default='env://')
     # extensions
+    parser.add_argument('--fp8', default=None, choices=["0", "1", "2", "3"],
+                        help="fp8 MFMA path of THIS run's model (BASELINE configs[4]): 1 = e4m3 forward GEMMs, 2 = + e5m2 x e4m3 input gradients, "
+                             "3 = + fp8 weight gradients; default: AVSIAM_FP8 or 0 (bf16)")
+    parser.add_argument('--recompute', default=None, metavar="FRACTION", help="per-layer activation recompute: 0 | 1 | the share of every stack's leading blocks")
+    parser.add_argument('--share-pass-buffers', dest="share_pass_buffers", action="store_true", default=None,
+                        help="both passes of the step take their activation buffers from one pool (the card holds the larger pass, not the sum)")
+    parser.add_argument('--depth', default=None, type=int, help="(tests) encoder depth override of the chosen skeleton")
     parser.add_argument('--frames', default=1, type=int, help="frames per sample (extension; reference pre-training uses 1)")
     parser.add_argument('--steps-per-epoch', dest="steps_per_epoch", default=20, type=int, help="synthetic-data epoch length")
     parser.add_argument('--val-steps', dest="val_steps", default=2, type=int, help="synthetic validation batches per epoch")
@@ -125,11 +138,20 @@ def _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train):
     print('current mae loss {:.3f}, and contrastive loss {:.3f}'.format(args.mae_loss_weight, args.contrast_loss_weight))
     if args.data_train not in ('', 'synthetic'):
         raise SystemExit("only synthetic AudioSet-shaped data is supported on this path (see module docstring)")
-    if args.model != 'cav-mae':
-        raise ValueError('model not supported')
-    cfg = AVSiamConfig(audio_tokens=args.target_length // 16 * 8, frames=args.frames)
-    audio_model = models.CAVMAE_BASE(audio_length=args.target_length, norm_pix_loss=args.norm_pix_loss,
-                                     modality_specific_depth=23, tr_pos=args.tr_pos, opt=args, cfg=cfg)        # :175
+    if args.model not in MODELS:
+        raise ValueError('model not supported')                                # :177
+    from . import config as _config
+    cls_name, shape_fn, stride = MODELS[args.model]
+    freq = 128 // stride                                                       # frequency patches of the 128-bin fbank (8; 9 on the 14 x 14 grid)
+    kw = {"audio_tokens": args.target_length // stride * freq, "frames": args.frames}
+    if args.depth is not None:
+        kw["depth"] = args.depth
+    cfg = getattr(_config, shape_fn)(**kw)
+    if args.model == 'cav-mae':
+        print('pretrain a cav-mae model with 11 modality-specific layers and 1 modality-sharing layers')        # :172
+    audio_model = getattr(models, cls_name)(audio_length=args.target_length, norm_pix_loss=args.norm_pix_loss,
+                                            modality_specific_depth=23, tr_pos=args.tr_pos, opt=args, cfg=cfg,
+                                            fp8_mode=args.fp8, recompute=args.recompute, share_pass_buffers=args.share_pass_buffers)        # :175
     if args.pretrain_path not in ('None', '', None):
         # resume from a checkpoint this loop (or the reference's, traintest_cavmae_base.py:223-234: 'module.'-prefixed keys) wrote - the
         # reference carries the same load commented out (:181-198).  With the fp8 mode the delayed-scaling state saved beside the weights
@@ -163,8 +185,7 @@ def _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train):
                           'too (step {:d})'.format(audio_model._opt_state[P2]['step']) if os.path.exists(opt2) else 'restarts'))
         else:
             print('no best_optim_state.pth beside the checkpoint: weights-only warm start (both Adam states restart, bias correction from step 1)')
-        from . import engine as _engine
-        if _engine.FP8 != "0" and os.path.exists(args.pretrain_path + ".fp8"):
+        if audio_model.options.fp8 != "0" and os.path.exists(args.pretrain_path + ".fp8"):
             audio_model.load_fp8_state(torch.load(args.pretrain_path + ".fp8", map_location='cpu'))
             print('restored the fp8 delayed-scaling state from {:s}.fp8'.format(args.pretrain_path))
     if args.exp_dir and args.rank == 0:

@@ -375,14 +375,14 @@ def main():
                          "on 16x16 patches (use --batch 32: saved activations of batch 64 x 10 frames exceed 288 GB), vit_huge14 = the same on the "
                          "14x14 patch grid (256 tokens per frame, 657 audio tokens) - extra data points")
     ap.add_argument("--lr", type=float, default=2e-4)
-    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) forward GEMMs (engine.FP8): configs[4]'s fp8 MFMA path as an extra data point; "
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) forward GEMMs (EngineOptions.fp8): configs[4]'s fp8 MFMA path as an extra data point; "
                     "the line then says dtype fp8-forward/bf16-backward and is NOT the headline metric")
-    ap.add_argument("--fp8-dgrad", action="store_true", help="with --fp8: the four input-gradient GEMMs of a block on e5m2 gradient operands too (engine.FP8 = 2)")
-    ap.add_argument("--fp8-wgrad", action="store_true", help="with --fp8: input gradients AND the four weight gradients of a block on fp8 operands (engine.FP8 = 3)")
+    ap.add_argument("--fp8-dgrad", action="store_true", help="with --fp8: the four input-gradient GEMMs of a block on e5m2 gradient operands too (fp8 mode 2)")
+    ap.add_argument("--fp8-wgrad", action="store_true", help="with --fp8: input gradients AND the four weight gradients of a block on fp8 operands (fp8 mode 3)")
     ap.add_argument("--share-pass-buffers", action="store_true", help="the two passes of the step take their activation buffers from one pool "
                     "(CAVMAE_BASE(share_pass_buffers=True)): the card holds the larger pass instead of the sum - shapes that otherwise need --recompute")
     ap.add_argument("--recompute", nargs="?", const="1", default=None, metavar="FRACTION",
-                    help="per-layer activation recompute (engine.RECOMPUTE): for shapes whose saved activations do not fit the GPU, e.g. "
+                    help="per-layer activation recompute (EngineOptions.recompute): for shapes whose saved activations do not fit the GPU, e.g. "
                          "--model vit_huge14 at batch 64; with a FRACTION (0.375) only that share of every stack's blocks is recomputed and "
                          "the rest of the 288 GB holds saved activations; `auto` takes the smallest share that leaves a tenth of the card "
                          "free after one step; never for the headline metric")
@@ -456,13 +456,11 @@ def main():
              "vit_huge14": "ViT-H/14 (1280 wide, 32 layers, 16 heads of 80, 14x14 patches)"}[args.model]
     torch.manual_seed(87 + rank)
     log(f"building model (frames={args.frames}, batch={args.batch}/GPU, world={world})")
-    if args.recompute or args.fp8:
-        from avsiam_amd import engine as _engine
-        if args.recompute and args.recompute != "auto":
-            _engine.recompute_blocks(1, args.recompute)       # validates the value
-            _engine.RECOMPUTE = args.recompute
-        if args.fp8:
-            _engine.FP8 = "3" if args.fp8_wgrad else "2" if args.fp8_dgrad else "1"
+    # precision / recompute are options of the MODEL (config.EngineOptions; the AVSIAM_* environment seeds what the flags leave open)
+    from avsiam_amd.config import EngineOptions
+    fp8_mode = ("3" if args.fp8_wgrad else "2" if args.fp8_dgrad else "1") if args.fp8 else None
+    recompute = [args.recompute if (args.recompute and args.recompute != "auto") else None]
+    EngineOptions.from_env(fp8=fp8_mode, recompute=recompute[0])          # validates the values before anything is built
     comm = None
     if share and world > 1:
         from avsiam_amd.comm import HostStagedComm
@@ -475,7 +473,8 @@ def main():
     a, v = a.to(dev), v.to(dev)
 
     def build():
-        m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank, share_pass_buffers=args.share_pass_buffers).to(dev)
+        m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87 + rank, share_pass_buffers=args.share_pass_buffers, fp8_mode=fp8_mode,
+                        recompute=recompute[0]).to(dev)
         m.set_distributed(world, rank, comm)
         m.publish_grads = False
         return m
@@ -486,7 +485,7 @@ def main():
         import gc
         model = None
         for frac in ("0", "0.125", "0.25", "0.375", "0.5", "0.625", "0.75", "1"):
-            _engine.RECOMPUTE = frac
+            recompute[0] = frac
             try:
                 model = build()
                 train_step(model, a, v, args.lr)
@@ -542,11 +541,11 @@ def main():
     # The other kernels that matter: weight-gradient GEMM, decoder attention (hd 32), LayerNorm backward.  In the timed
     # region the weight gradients run on a second stream beside attention / LayerNorm backward, so a launch-to-end time there
     # includes waiting for CUs.  Their rooflines are therefore taken in a short SEPARATE pass after the timed region, with
-    # everything on one stream (engine.WGRAD_STREAM_MODE "0") and HIP events around every launch of those families.
+    # everything on one stream (EngineOptions.wgrad_stream "0") and HIP events around every launch of those families.
     prof2 = None
     if not args.no_kernel_events and world == 1 and args.roofline_steps > 0:
-        from avsiam_amd import engine as _eng
-        mode, _eng.WGRAD_STREAM_MODE = _eng.WGRAD_STREAM_MODE, "0"
+        mode = model.options.wgrad_stream
+        model.set_options(wgrad_stream="0")
         train_step(model, a, v, args.lr)
         torch.cuda.synchronize()
         ops.prof = ops.KernelProfiler()                  # every launch of every kernel family (outside the timed region: the event cost is free here)
@@ -554,7 +553,7 @@ def main():
             train_step(model, a, v, args.lr)
         torch.cuda.synchronize()
         prof2, ops.prof = ops.prof, None
-        _eng.WGRAD_STREAM_MODE = mode
+        model.set_options(wgrad_stream=mode)
     # per-rank times of the timed region (a straggler must be visible in the line): max = the metric's clock, min beside it
     tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
     tmin = tmax.clone()
@@ -569,6 +568,9 @@ def main():
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
     dt_min = float(tmin.item())
     dt = float(tmax.item())
+    # the headline workload's peak, read BEFORE the secondary shapes build their own models beside this one (the figure used to
+    # include them - 106 GiB reported for a 79.8 GiB step)
+    peak_gib = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
     secondary = None
     if world == 1 and not args.force_dp and args.secondary_steps > 0 and args.model == "vit_base" and not (args.fp8 or args.recompute):
         secondary = secondary_shapes(args, dev)
@@ -584,13 +586,21 @@ def main():
                                    f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
                        "parallelism": f"dp{world}", "gflop_per_sample": gf,
-                       "residual_gradient_stream": __import__("avsiam_amd.engine", fromlist=["GRAD_STREAM"]).GRAD_STREAM,   # bf16 (default) | fp32
+                       "residual_gradient_stream": model.options.grad_stream,   # bf16 (default) | fp32
+                       "options": model.options.describe(),
                        # what the collective library itself reports: the size of the process group the step's collectives ran in
                        **({"collectives": {"backend": dist.get_backend(), "library": "gloo, staged through the host (rehearsal)" if share else "RCCL (torch.distributed 'nccl' on ROCm)", "group_world_size": dist.get_world_size(),
-                                           "comm": "host-staged" if share else os.environ.get("AVSIAM_COMM", "torch"), "allreduce_messages_last_backward": model.last_reduce_messages}}
-                          if world > 1 else {}), **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
-                       **({"fp8_8bit_only_outputs": __import__("avsiam_amd.engine", fromlist=["FP8_LEAN"]).FP8_LEAN} if args.fp8_wgrad else {}),
-                       "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                                           "comm": "host-staged" if share else os.environ.get("AVSIAM_COMM", "torch"), "allreduce_messages_last_backward": model.last_reduce_messages,
+                                           # what the first scaling line has to say about itself: CUs every persistent kernel leaves to the
+                                           # collectives, whether the gradient all-reduce overlaps the backward, and what travels on xGMI
+                                           "cu_reserve": _lib.tuning_get("cu_reserve"), "persistent_cu_slots": _lib.load().avs_persistent_cu_slots(),
+                                           "gradient_allreduce": ("chunked, overlapped with the backward (AVSIAM_DP_OVERLAP=1)" if os.environ.get("AVSIAM_DP_OVERLAP", "1") != "0"
+                                                                  else "one blocking message after the backward (AVSIAM_DP_OVERLAP=0)"),
+                                           "wire_format": model.dp_wire, "defer_mae_only_update": bool(model.defer_p2),
+                                           "embedding_allgather": "one packed [2, B, D] fp32 message per rank and step"}}
+                          if (world > 1 or args.force_dp) else {}), **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
+                       **({"fp8_8bit_only_outputs": model.options.fp8_lean} if args.fp8_wgrad else {}),
+                       "peak_memory_gib": peak_gib,
                        **({"share_pass_buffers": True, "activation_pool_gib": round(model._pool.nbytes() / 2 ** 30, 2),
                            "activation_pool_live_gib_last_pass": round(model._pool.used() / 2 ** 30, 2)} if args.share_pass_buffers and model._pool is not None else {}),
                        **({"rehearsal": "AVSIAM_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo + host-staged collectives - not a throughput figure"} if share else {}),

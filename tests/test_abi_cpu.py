@@ -31,7 +31,7 @@ def test_no_undeclared_exports(lib_path):
 
 def test_abi_version_and_error_string(lib_path):
     lib = _lib.load()
-    assert lib.avs_abi_version() == 1
+    assert lib.avs_abi_version() == 2          # round 6: stricter attention strides, gelu' codes, ln_dma 0 | 1 (api.cpp)
     assert isinstance(lib.avs_last_error(), bytes)
     # argument validation happens before any launch, so it is testable without a GPU
     rc = lib.avs_gemm_nt_bf16(None, 0, None, 0, 10, 100, 64, None, None, 0, None, None, 0, None, 0, 0, None, 0, 1.0, 0, 0, 1.0, None, None)
@@ -67,6 +67,8 @@ def test_tuning_knobs_are_set_through_the_abi_only(lib_path):
             _lib.tuning_set("nt_tile_h", 100)
         with pytest.raises(_lib.AvsiamHipError):
             _lib.tuning_set("no_such_knob", 1)
+        with pytest.raises(_lib.AvsiamHipError):
+            _lib.tuning_set("ln_dma", 2)               # (the value 2 never had a meaning)
         for k in ("gemm_tile", "gemm_persistent", "gemm_nt8", "nt_tile_h", "nt_grid", "ln_dma", "ln_rpw", "attn_ring", "nt_big_min"):
             _lib.tuning_get(k)
     finally:
@@ -74,6 +76,23 @@ def test_tuning_knobs_are_set_through_the_abi_only(lib_path):
     import subprocess
     undefined = subprocess.check_output(["nm", "-D", "--undefined-only", lib_path], text=True)
     assert "getenv" not in undefined, "the library must not read the environment"
+
+
+def test_a_rejected_environment_knob_fails_every_load_the_same_way(monkeypatch):
+    """load() used to publish the library BEFORE applying the AVSIAM_* knobs, so a rejected value raised once and every later load()
+    returned a half-configured library silently.  Now the library is published only after every knob is applied; an empty value means unset."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("AVSIAM_GEMM_TILE", "64")
+    for _ in range(2):
+        with pytest.raises(_lib.AvsiamHipError, match="AVSIAM_GEMM_TILE"):
+            _lib.load()
+        assert _lib._lib is None
+    monkeypatch.setenv("AVSIAM_GEMM_TILE", "abc")
+    with pytest.raises(_lib.AvsiamHipError, match="not an integer"):
+        _lib.load()
+    monkeypatch.setenv("AVSIAM_GEMM_TILE", "")
+    monkeypatch.setenv("AVSIAM_CU_RESERVE", "")
+    assert _lib.load() is not None and _lib.env_value("AVSIAM_CU_RESERVE") is None and _lib.tuning_get("gemm_tile") == 0
 
 
 def test_missing_library_raises(monkeypatch):

@@ -289,6 +289,51 @@ def test_entry_point_main_runs_two_steps(tmp_path, capsys):
                 os.environ[k] = val
 
 
+def test_entry_point_runs_vit_huge14_in_fp8_mode3(tmp_path, capsys):
+    """BASELINE.json configs[4] through the reference's own entry point: `--model cav-mae-huge14 --fp8 3` builds
+    models.CAVMAE_HUGE (the name /root/reference/src/models/__init__.py:13 exports; selection by args.model as src/run_cavmae_pretrain_base.py:171-175)
+    with the fp8 MFMA path as a property of THAT model, trains two steps at depth 2 (the calibration step and one on delayed scales), validates,
+    and writes the checkpoint with its '.fp8' delayed-scaling state - which a second invocation resumes from.  The same process then builds the
+    default bf16 model through the same entry point: no process-wide precision switch is left behind."""
+    from avsiam_amd import run_cavmae_pretrain_base as entry
+    from avsiam_amd.models import CAVMAE_BASE, CAVMAE_HUGE
+    exp = tmp_path / "exp_h14"
+    env_keep = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AVSIAM_FP8")}
+    common = ["--dataset", "audioset", "--target_length", "1024", "--batch-size", "2", "--lr", "1e-4", "--n-epochs", "1", "--n-print-steps", "1",
+              "--save_model", "True", "--mae_loss_weight", "3.0", "--contrast_loss_weight", "0.01"]
+    try:
+        model = entry.main(["--model", "cav-mae-huge14", "--fp8", "3", "--depth", "2", "--steps-per-epoch", "2", "--exp-dir", str(exp),
+                            "--data-val", "synthetic", "--val-steps", "1"] + common)
+        out = capsys.readouterr().out
+        assert isinstance(model, CAVMAE_HUGE) and model.options.fp8 == "3"
+        assert (model.cfg.embed_dim, model.cfg.head_dim, model.cfg.st, model.cfg.audio_tokens, model.cfg.video_tokens) == (1280, 80, 14, 657, 256)
+        assert "Epoch: [1][1/2]" in out and "Eval Total Loss" in out and "training diverged" not in out
+        res = np.loadtxt(exp / "result.csv", delimiter=",").reshape(1, 10)
+        assert np.isfinite(res).all() and res[0, 3] > 0 and res[0, 7] > 0
+        # every stack of both passes ran on fp8 operands (forward, input gradients, weight gradients) and is calibrated; nothing saturated
+        stacks = [st for (which, _), eng in model._engines.items() for _, st in model._fp8_stacks(which, eng)]
+        assert len(stacks) >= 4 and all(st.fp8_wgrad and len(st.f8_seen) == 4 * st.nblocks for st in stacks)
+        assert model.fp8_saturation_events() <= 4
+        assert (exp / "models" / "best_audio_model.pth.fp8").exists()
+        resumed = entry.main(["--model", "cav-mae-huge14", "--fp8", "3", "--depth", "2", "--steps-per-epoch", "1", "--exp-dir", str(tmp_path / "exp_h14b"),
+                              "--pretrain_path", str(exp / "models" / "best_audio_model.pth")] + common)
+        out = capsys.readouterr().out
+        assert "restored the fp8 delayed-scaling state" in out and "missing keys: 0, unexpected keys: 0" in out
+        assert resumed.options.fp8 == "3"
+        # the default model of the same process is the bf16 ViT-B (the precision travelled with the model object, not with the process)
+        base = entry.main(["--model", "cav-mae", "--steps-per-epoch", "1", "--exp-dir", str(tmp_path / "exp_b"), "--target_length", "256",
+                           "--dataset", "audioset", "--batch-size", "2", "--lr", "1e-4", "--n-epochs", "1", "--save_model", "False"])
+        capsys.readouterr()
+        assert type(base) is CAVMAE_BASE and base.options.fp8 == "0" and base.cfg.embed_dim == 768
+        assert not any(getattr(st, "fp8", False) for eng in base._engines.values() for st in vars(eng).values() if hasattr(st, "nblocks"))
+        with pytest.raises(SystemExit):                                    # argparse: a name outside the reference's export list
+            entry.main(["--model", "cav-mae-giant"])
+    finally:
+        for k, val in env_keep.items():
+            if val is not None:
+                os.environ[k] = val
+
+
 def test_torchrun_entry_forms_the_rccl_group_and_runs(tmp_path):
     """The way the reference is launched (torchrun, one process per GPU): utils.init_distributed_mode reads RANK / WORLD_SIZE /
     LOCAL_RANK, forms the "nccl" (= RCCL) process group - at world size 1 too, like the reference (utils.py:288) - and the

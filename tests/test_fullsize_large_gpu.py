@@ -16,15 +16,12 @@ pytestmark = pytest.mark.gpu
 # One property per model keeps the run inside the suite's time budget: the MAE pass over 64 clips equals the mean of its two 32-clip
 # halves with the same per-clip plans (loss rel 1e-5, masks bit-equal, whole flat gradient cosine / norm) - the small-shape results
 # of these models are anchored to the oracle by tests/test_parity_gpu.py (test_vit_large_*, test_vit_huge14_*).  ViT-H/14 needs
-# per-layer activation recompute to fit (engine.RECOMPUTE, DESIGN.md section 6: 75 GiB instead of 290 GB).
+# per-layer activation recompute to fit (CAVMAE_BASE(recompute=...), DESIGN.md section 6: 75 GiB instead of 290 GB).
 def _halves_property(cfg, seed, recompute):
     import gc
-    from avsiam_amd import engine
     from avsiam_amd.models import CAVMAE_BASE
-    old = engine.RECOMPUTE
-    engine.RECOMPUTE = "1" if recompute else "0"
     try:
-        m = CAVMAE_BASE(cfg=cfg, init_seed=seed, init_mode="random", verbose=False).cuda()
+        m = CAVMAE_BASE(cfg=cfg, init_seed=seed, init_mode="random", verbose=False, recompute="1" if recompute else "0").cuda()
         m.publish_grads = False
         a, v = synth_inputs(cfg, B, 7)
         a, v = a.cuda(), v.cuda()
@@ -52,7 +49,6 @@ def _halves_property(cfg, seed, recompute):
         _same_direction(g, acc)
         del m, g, acc
     finally:
-        engine.RECOMPUTE = old
         gc.collect(); torch.cuda.empty_cache()
 
 
@@ -115,7 +111,7 @@ def test_vit_large_full_size_contrastive_is_order_invariant():
 # configs[4] AT THE SIZE AND PRECISION IT NAMES (round 5): ViT-H/14, fp8 mode 3 (e4m3 forward operands, e5m2 gradient operands for the
 # input AND weight gradients), batch 64 x 10 frames, one activation pool, nothing recomputed (198 GiB).  The oracle is out of reach, so:
 # (1) three training steps with device-drawn plans stay finite and NO tensor leaves the range of the delayed scale it was quantised with
-#     (fp8_saturation_events() == 0: the margin-2 scales of engine.FP8 hold at the size the mode is meant for);
+#     (fp8_saturation_events() == 0: the margin-2 scales of the fp8 mode hold at the size the mode is meant for);
 # (2) the MAE pass over 64 clips equals the mean of its two 32-clip halves run with the same per-clip plans.  In bf16 that holds to fp32
 #     summation order (1e-5); in fp8 every quantised tensor of the 32-clip engines carries its OWN delayed scale (amax over other rows),
 #     so the operands round on slightly different grids: the stated tolerance is the fp8 noise, at ~3x the measurement
@@ -126,15 +122,13 @@ FP8_FULL_LOSS_RTOL, FP8_FULL_COS_MIN, FP8_FULL_RATIO_TOL = 1e-3, 0.997, 0.01    
 
 def test_vit_huge14_fp8_mode3_full_size_trains_and_mae_equals_mean_of_halves():
     import gc
-    from avsiam_amd import engine
     from avsiam_amd.config import vit_huge14
-    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.models import CAVMAE_HUGE
     from avsiam_amd.traintest_cavmae_base import train_step
     cfg = vit_huge14(frames=T)
-    old = (engine.FP8, engine.RECOMPUTE)
-    engine.FP8, engine.RECOMPUTE = "3", "0"
     try:
-        m = CAVMAE_BASE(cfg=cfg, init_seed=24, init_mode="random", verbose=False, plan_seed=5, share_pass_buffers=True).cuda()
+        # through the reference's name for this skeleton (src/models/__init__.py:13) with the precision as the model's own property
+        m = CAVMAE_HUGE(cfg=cfg, init_seed=24, init_mode="random", verbose=False, plan_seed=5, share_pass_buffers=True, fp8_mode="3", recompute="0").cuda()
         m.publish_grads = False
         a, v = synth_inputs(cfg, B, 7)
         a, v = a.cuda(), v.cuda()
@@ -174,5 +168,4 @@ def test_vit_huge14_fp8_mode3_full_size_trains_and_mae_equals_mean_of_halves():
         assert cos >= FP8_FULL_COS_MIN and abs(ratio - 1) <= FP8_FULL_RATIO_TOL, (cos, ratio)
         del m, g, acc
     finally:
-        engine.FP8, engine.RECOMPUTE = old
         gc.collect(); torch.cuda.empty_cache()

@@ -218,6 +218,11 @@ def test_entry_point_arguments_and_process_group_plumbing(monkeypatch, capsys):
     assert b.masking_ratio_a == 0.75 and b.num_workers == 6 and b.batch_size == 4 and b.lr == 5e-5 and b.n_epochs == 25 and b.save_model is True and b.noise is True and b.norm_pix_loss is True and b.tr_pos is False
     c = p.parse_args(["--frames", "10", "--graph-step", "--raw-input", "--steps-per-epoch", "7"])
     assert c.frames == 10 and c.graph_step and c.raw_input and c.steps_per_epoch == 7
+    assert (a.fp8, a.recompute, a.share_pass_buffers, a.depth) == (None, None, None, None)            # unset: the AVSIAM_* environment / defaults decide
+    d = p.parse_args(["--model", "cav-mae-huge14", "--fp8", "3", "--recompute", "0.25", "--share-pass-buffers"])
+    assert (d.model, d.fp8, d.recompute, d.share_pass_buffers) == ("cav-mae-huge14", "3", "0.25", True)
+    with pytest.raises(SystemExit):
+        p.parse_args(["--fp8", "4"])
     # no launcher: single process, rank 0, no process group
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
@@ -238,3 +243,47 @@ def test_entry_point_arguments_and_process_group_plumbing(monkeypatch, capsys):
     utils.init_seeds(87)
     x = torch.rand(1).item(); utils.init_seeds(87)
     assert torch.rand(1).item() == x
+
+
+def test_model_family_exports_and_per_model_options(monkeypatch):
+    """The reference's export list (/root/reference/src/models/__init__.py:8-13): CAVMAE, CAVMAE_BASE, CAVMAE_LARGE, CAVMAE_HUGE and their CAVMAEFT_*
+    classes exist with the reference constructor signature; the larger skeletons are parameterisations of the same class.  Precision / memory policy
+    are options of ONE model (config.EngineOptions): the AVSIAM_* environment seeds defaults at construction, keywords win, two models differ."""
+    import inspect
+    from avsiam_amd import models
+    from avsiam_amd.config import EngineOptions
+    for name in ("CAVMAE", "CAVMAE_BASE", "CAVMAE_LARGE", "CAVMAE_HUGE", "CAVMAEFT", "CAVMAEFT_BASE", "CAVMAEFT_LARGE", "CAVMAEFT_HUGE"):
+        assert hasattr(models, name), name
+    assert issubclass(models.CAVMAE_LARGE, models.CAVMAE_BASE) and issubclass(models.CAVMAE_HUGE, models.CAVMAE_BASE) and models.CAVMAE is models.CAVMAE_BASE
+    assert issubclass(models.CAVMAEFT_LARGE, models.CAVMAEFT_BASE) and issubclass(models.CAVMAEFT_HUGE, models.CAVMAEFT_BASE)
+    ref_ctor = ["img_size", "audio_length", "patch_size", "in_chans", "embed_dim", "modality_specific_depth", "num_heads", "decoder_embed_dim",
+                "decoder_depth", "decoder_num_heads", "mlp_ratio", "norm_layer", "norm_pix_loss", "tr_pos", "opt"]          # cav_mae_base.py:219-222
+    sig = inspect.signature(models.CAVMAE_BASE.__init__)
+    assert [p for p in sig.parameters if sig.parameters[p].kind == inspect.Parameter.POSITIONAL_OR_KEYWORD][1:] == ref_ctor
+    for k in ("cfg", "fp8_mode", "recompute", "grad_stream", "share_pass_buffers", "options"):
+        assert sig.parameters[k].kind == inspect.Parameter.KEYWORD_ONLY, k
+    for k in ("AVSIAM_FP8", "AVSIAM_RECOMPUTE", "AVSIAM_GRAD_STREAM", "AVSIAM_DETERMINISTIC"):
+        monkeypatch.delenv(k, raising=False)
+    d = EngineOptions.from_env()
+    assert (d.fp8, d.recompute, d.grad_stream, d.wgrad_stream, d.deterministic, d.prune_dead) == ("0", "0", "bf16", "2", False, True)
+    monkeypatch.setenv("AVSIAM_FP8", "2")
+    monkeypatch.setenv("AVSIAM_RECOMPUTE", "")                                                   # empty = unset
+    assert EngineOptions.from_env().fp8 == "2" and EngineOptions.from_env(fp8="3").fp8 == "3" and EngineOptions.from_env(fp8=None).recompute == "0"
+    with pytest.raises(ValueError):
+        EngineOptions.from_env(fp8="7")
+    with pytest.raises(ValueError):
+        EngineOptions.from_env(recompute="1.5")
+    monkeypatch.delenv("AVSIAM_FP8")
+    # two small models (depth 1; CPU construction only - forward needs the GPU): each owns its options object
+    small = {"depth": 1, "dec_depth": 1}
+    m0 = models.CAVMAE_BASE(cfg=AVSiamConfig(audio_tokens=128, **small), verbose=False)
+    m3 = models.CAVMAE_HUGE(cfg=vit_huge14(frames=1, **small), verbose=False, fp8_mode="3", recompute="0.5")
+    assert (m0.options.fp8, m3.options.fp8, m3.options.recompute) == ("0", "3", "0.5") and m0.options is not m3.options
+    assert (m3.cfg.embed_dim, m3.cfg.head_dim, m3.cfg.st) == (1280, 80, 14)
+    m0.set_options(deterministic=True)                                                           # a runtime field: no engine is dropped, m3 untouched
+    assert m0.options.deterministic and not m3.options.deterministic
+    with pytest.raises(ValueError):
+        models.CAVMAE_LARGE(cfg=AVSiamConfig(), verbose=False)
+    with pytest.raises(ValueError):
+        models.CAVMAE_BASE(cfg=AVSiamConfig(**small), verbose=False, fp8_mode="1", options=EngineOptions())
+    assert models.CAVMAE_LARGE(cfg=vit_large(audio_tokens=128, **small), verbose=False).cfg.embed_dim == 1024

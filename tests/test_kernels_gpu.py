@@ -84,7 +84,7 @@ def test_layernorm(D, rows):
     assert rel_err(dx2, dx) < 1e-6
     assert torch.equal(dxb, bf(dx2))
     assert rel_err(dcol, 1 + dx2.double().sum(0)) < 1e-5           # fused column sum (bias gradient), accumulated
-    # bf16 residual-gradient stream (engine.GRAD_STREAM): dres arrives in bf16, only the bf16 copy is written; the sum is formed in
+    # bf16 residual-gradient stream (EngineOptions.grad_stream): dres arrives in bf16, only the bf16 copy is written; the sum is formed in
     # fp32 and rounded once, so the result is the bf16 rounding of the fp32-path sum on the rounded dres
     dres_b = bf(dres)
     dxb2 = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
@@ -661,7 +661,7 @@ def test_gemm_tn_fp8_weight_gradients(M):
 
 @pytest.mark.parametrize("H,hd", [(2, 64), (3, 32), (2, 80)])
 def test_attention_bwd_writes_the_e5m2_copy_of_dqkv(H, hd):
-    """fp8 backward (engine.FP8 = 2): avs_attn_bwd_q8 / avs_attn_bwd_fused_q8 also write e5m2(dqkv * scale) - the gradient operand of the
+    """fp8 backward (fp8 mode 2): avs_attn_bwd_q8 / avs_attn_bwd_fused_q8 also write e5m2(dqkv * scale) - the gradient operand of the
     fp8 qkv input-gradient GEMM - and fold max |dqkv| into the device record.  The bf16 output must be BIT-identical to the plain call,
     the e5m2 copy must be the e5m2 rounding of what the kernels hold in fp32 (checked against the bf16 output: within one e5m2 step, 2^-2
     relative, plus the bf16 rounding), untouched outside the sequences' rows, and the record's amax must equal max |dqkv|."""
@@ -1136,7 +1136,7 @@ def test_fp8_delayed_scaling_records():
     assert float((deq - act.float()).abs().max()) <= 2 ** -4 * act.float().abs().max().item() + 1e-3       # e4m3: 3 mantissa bits
     assert rel_err(deq, act) < 0.04
     assert abs(rec.amax(3) - act.float().abs().max().item()) <= 1e-2 * act.float().abs().max().item()
-    # 8-bit-only output (fp8 mode 3, engine.FP8_LEAN): no bf16 gelu(x) - the e4m3 copy and gelu'(x) are the same bits
+    # 8-bit-only output (fp8 mode 3, EngineOptions.fp8_lean): no bf16 gelu(x) - the e4m3 copy and gelu'(x) are the same bits
     act8b, dact2 = torch.zeros_like(act8), torch.zeros_like(dact)
     o.gemm_nt_fp8(A8, W8, dact2, M, bias=b, out2=None, act=1, qa=ra, qw=rw, out8=act8b, q8=r8)
     assert torch.equal(act8b, act8) and torch.equal(dact2, dact)
@@ -1173,7 +1173,7 @@ def test_fp8_delayed_scaling_records():
     assert torch.equal(att, ref_att)                                       # the bf16 output does not change
     st_ = rec.q[5, 0].item()
     assert rel_err(att8[:2 * L].view(torch.float8_e4m3fn).float() / st_, att[:2 * L]) < 0.04
-    # ---- input-gradient form (engine.FP8 = "2"): e5m2 gradient operand x e4m3 transposed weight, records with fmax 57344
+    # ---- input-gradient form (fp8 mode 2): e5m2 gradient operand x e4m3 transposed weight, records with fmax 57344
     grec = o.Fp8Records(3, DEV, nhist=4, margin=2.0, fmax=o.BF8_MAX)
     rg, rg2 = grec.rec(0), grec.rec(1)
     dY = torch.randn(M, K, device=DEV, generator=g) * 1e-3                 # gradients are small: the scale moves them into e5m2's range

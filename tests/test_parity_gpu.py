@@ -33,9 +33,10 @@ GOLD_L2_C, GOLD_SAMP_C, GOLD_SUM_C = 0.01, 0.3, 0.25
 LOSS_RTOL, LOSS_RTOL_GOLD, LOGITS_ATOL, COS_MIN, RATIO_TOL = 2e-3, 6e-3, 0.01, 0.9998, 0.01
 
 
-def _model(cfg, seed=1234, mode="random"):
+def _model(cfg, seed=1234, mode="random", **kw):
+    """kw: per-model options (fp8_mode=, recompute=, grad_stream=, options=) - precision is a property of the model"""
     from avsiam_amd.models import CAVMAE_BASE
-    m = CAVMAE_BASE(cfg=cfg, init_seed=seed, init_mode=mode, verbose=False).cuda()
+    m = CAVMAE_BASE(cfg=cfg, init_seed=seed, init_mode=mode, verbose=False, **kw).cuda()
     return m
 
 
@@ -274,7 +275,7 @@ def test_vit_huge_width_matches_oracle(which):
 
 @pytest.mark.parametrize("which", ["mae", "contrastive"])
 def test_recompute_matches_saved_activations(which):
-    """engine.RECOMPUTE: every Stack keeps only its blocks' fp32 inputs and re-runs a block's forward in front of its backward ("1"), or
+    """EngineOptions.recompute (CAVMAE_BASE(recompute=...)): every Stack keeps only its blocks' fp32 inputs and re-runs a block's forward in front of its backward ("1"), or
     does so for the first half of its blocks only and saves the rest ("0.5").  The kernels are deterministic, so the loss is bitwise the
     same and the gradients differ only by the order of the fp32 atomics of the weight-gradient GEMMs."""
     import random
@@ -288,8 +289,7 @@ def test_recompute_matches_saved_activations(which):
     res = []
     try:
         for rec in ("0", "1", "0.5"):
-            engine.RECOMPUTE = rec
-            m = _model(cfg, 97)
+            m = _model(cfg, 97, recompute=rec)
             comm = None
             if rec == "0.5":           # with the data-parallel reducer attached: every element of the pass's range must be reduced exactly once
                 from tests.helpers import _Waited
@@ -325,7 +325,6 @@ def test_recompute_matches_saved_activations(which):
                 assert stacks and all(0 < st.nrecomp < st.nblocks for st in stacks), [(st.nrecomp, st.nblocks) for st in stacks]
                 assert all(st.act[0] is st.act[st.nrecomp - 1] and st.act[st.nrecomp] is not st.act[0] for st in stacks)
     finally:
-        engine.RECOMPUTE = "0"
         from avsiam_amd import _lib
         _lib.tuning_set("cu_reserve", 0)          # (the counting communicator is "active": set_distributed reserved CUs for collectives, process-wide)
     for r in res[1:]:
@@ -341,7 +340,7 @@ def test_recompute_matches_saved_activations(which):
 
 @pytest.mark.parametrize("which", ["mae", "contrastive"])
 def test_fp8_forward_mode_against_bf16(which):
-    """engine.FP8 (BASELINE configs[4]'s fp8 MFMA path, opt-in): the forward GEMMs of every block on e4m3 operands with per-tensor
+    """CAVMAE_BASE(fp8_mode=...) (BASELINE configs[4]'s fp8 MFMA path, opt-in): the forward GEMMs of every block on e4m3 operands with per-tensor
     delayed scaling, backward in bf16 (a self-comparison that isolates the quantisation; test_fp8_forward_mode_against_oracle is the pin).  Its own tolerance against the bf16 path (three mantissa bits per operand), at about 3x the measured error:
     losses within 0.3 % (measured 0.08 %), every live gradient tensor's cosine above 0.98 (0.9925) and norm within 6 % (2.2 %)."""
     import random
@@ -353,10 +352,9 @@ def test_fp8_forward_mode_against_bf16(which):
     mae = which == "mae"
     plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(8))
     res = []
-    try:
+    if True:
         for mode in ("0", "1"):
-            engine.FP8 = mode
-            m = _model(cfg, 96)
+            m = _model(cfg, 96, fp8_mode=mode)
             out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
             out[0].backward()
             torch.cuda.synchronize()
@@ -368,8 +366,6 @@ def test_fp8_forward_mode_against_bf16(which):
                 again = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)[0].item()
                 record_margin(f"fp8_forward_{which}", second_forward_loss_rel=abs(again - out[0].item()) / abs(out[0].item()))
                 assert abs(again - out[0].item()) <= 1.2e-2 * abs(out[0].item()), (again, out[0].item())
-    finally:
-        engine.FP8 = "0"
     l0, l1 = res[0][0], res[1][0]
     # MAE loss within 0.3 % (measured 0.05 %); the contrastive loss - 3 x 3 logits divided by tau = 0.05 - within 1.2 % (measured 0.34 %)
     assert l0 != l1 and abs(l1 - l0) <= (3e-3 if mae else 1.2e-2) * abs(l0), (l0, l1)
@@ -409,7 +405,7 @@ FP8W_MATRIX_COS_MIN = 0.90
 @pytest.mark.parametrize("shape", ["vit_base", "vit_huge14"])
 @pytest.mark.parametrize("mode", ["1", "2", "3"])
 def test_fp8_forward_mode_against_oracle(shape, which, mode):
-    """engine.FP8 (BASELINE.json configs[4]'s "fp8 MFMA path") pinned to oracle/ref_cpu.py (the fp32 restatement of
+    """CAVMAE_BASE(fp8_mode=...) (BASELINE.json configs[4]'s "fp8 MFMA path") pinned to oracle/ref_cpu.py (the fp32 restatement of
     /root/reference/src/models/cav_mae_base.py:685-741), not to the HIP bf16 path: losses, contrastive logits, and every live gradient
     tensor's cosine / norm ratio, at ViT-B and at the ViT-H/14 geometry the mode is meant for (2 layers, 2 frames).  Two steps are
     compared: the calibration step (scales from the first batch, activations quantised by a pass) and the step after it (delayed
@@ -426,9 +422,8 @@ def test_fp8_forward_mode_against_oracle(shape, which, mode):
     mae = which == "mae"
     plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(9))
     ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 93)
-    try:
-        engine.FP8 = mode
-        m = _model(cfg, 93)
+    if True:
+        m = _model(cfg, 93, fp8_mode=mode)
         for step in (0, 1):
             out = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
             out[0].backward()
@@ -449,8 +444,52 @@ def test_fp8_forward_mode_against_oracle(shape, which, mode):
                                          "3": (FP8W_COS_MIN, FP8W_RATIO_TOL, FP8W_WHOLE_COS)}[mode]
             _compare_grads(m, rgrads, cos_min=cos_min, ratio_tol=ratio_tol, tag=tag, whole_cos_min=whole,
                            matrix_cos_min=FP8W_MATRIX_COS_MIN if mode in ("2", "3") else None)
-    finally:
-        engine.FP8 = "0"
+
+
+def test_bf16_and_fp8_models_live_side_by_side():
+    """Precision is a property of the MODEL (config.EngineOptions): a bf16 model and an fp8 mode-3 model are held alive in one
+    process and stepped ALTERNATELY - forward, backward, forward, backward - and each keeps its own parity against the oracle: the bf16 model its
+    tight margins (every tensor cosine >= 0.9998), the fp8 model the fp8 tolerances, on the calibration step and on the step after it.  With the
+    process-wide switch of rounds 3 - 5 the second model built decided the kernels of both."""
+    import random
+    from avsiam_amd.models import CAVMAE_BASE
+    cfg = AVSiamConfig(audio_tokens=128, frames=2)
+    B = 3
+    a, v = synth_inputs(cfg, B, 41)
+    gen = torch.Generator().manual_seed(9)
+    plans = {"mae": make_mae_plan(cfg, B, gen), "contrastive": make_contrastive_plan(cfg, B, gen, random.Random(9))}
+    refs = {which: _oracle(cfg, a, v, plan, which == "mae", 93) for which, plan in plans.items()}
+    m16 = CAVMAE_BASE(cfg=cfg, init_seed=93, init_mode="random", verbose=False, fp8_mode="0").cuda()
+    m8 = CAVMAE_BASE(cfg=cfg, init_seed=93, init_mode="random", verbose=False, fp8_mode="3").cuda()
+    assert m16.options is not m8.options and (m16.options.fp8, m8.options.fp8) == ("0", "3")
+    for step in (0, 1):
+        for which, plan in plans.items():
+            mae = which == "mae"
+            ref, extras, rgrads = refs[which]
+            outs = {}
+            for name, m in (("bf16", m16), ("fp8", m8)):            # both forwards first, then both backwards: the engines interleave
+                for p in m._params.values():
+                    p.grad = None
+                outs[name] = m(a.cuda(), v.cuda(), mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, mask_plan=plan)
+            for name, m in (("fp8", m8), ("bf16", m16)):
+                outs[name][0].backward()
+            torch.cuda.synchronize()
+            for name, m, ltol in (("bf16", m16, LOSS_RTOL), ("fp8", m8, FP8_LOSS_RTOL)):
+                out = outs[name]
+                for i in (0, 1, 2, 3, 4):
+                    if ref[i].item() != 0:
+                        assert abs(out[i].item() - ref[i].item()) <= ltol * abs(ref[i].item()), (name, which, step, i, out[i].item(), ref[i].item())
+            _compare_grads(m16, rgrads, tag=f"coexist_bf16_{which}_step{step}")
+            _compare_grads(m8, rgrads, cos_min=FP8W_COS_MIN, ratio_tol=FP8W_RATIO_TOL, tag=f"coexist_fp8m3_{which}_step{step}", whole_cos_min=FP8W_WHOLE_COS,
+                           matrix_cos_min=FP8W_MATRIX_COS_MIN)
+    eng16, eng8 = m16._engine("contrastive", B), m8._engine("contrastive", B)
+    assert not eng16.stack.fp8 and eng8.stack.fp8_wgrad
+    assert m8.fp8_saturation_events() == 0 and m16.fp8_state() == {}
+    # a structural option can be changed on a live model: the engines are rebuilt, the other model is untouched
+    m16.set_options(fp8="1")
+    out = m16(a.cuda(), v.cuda(), mae_loss_weight=1, contrast_loss_weight=0, mask_plan=plans["mae"])
+    assert m16._engine("mae", B).st_dec.fp8 and not m16._engine("mae", B).st_dec.fp8_bwd and m8.options.fp8 == "3"
+    assert abs(out[0].item() - refs["mae"][0][0].item()) <= FP8_LOSS_RTOL * abs(refs["mae"][0][0].item())
 
 
 @pytest.mark.parametrize("which", ["mae", "contrastive"])
@@ -557,11 +596,9 @@ def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():
         refs[which] = ([float(o.item()) for o in out[:5]], extras.get("logits"), {k: p.grad for k, p in P.items()})
         del P, out
         gc.collect()
-    old = engine.FP8
     try:
         for mode in ("0", "3"):
-            engine.FP8 = mode
-            m.release_buffers()                          # the stacks read engine.FP8 when they are built
+            m.set_options(fp8=mode)                      # a structural option: the pass engines are rebuilt for the mode
             for which, plan in plans.items():
                 mae = which == "mae"
                 ref, logits, rgrads = refs[which]
@@ -588,6 +625,5 @@ def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():
             if mode == "3":
                 assert m.fp8_saturation_events() == 0
     finally:
-        engine.FP8 = old
         del m
         gc.collect(); torch.cuda.empty_cache()

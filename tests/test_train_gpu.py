@@ -92,9 +92,8 @@ def test_fp8_forward_with_recompute_trains_at_the_14x14_geometry(mode, recompute
     cfg = vit_huge14(frames=2, depth=2)
     a, v = synth_inputs(cfg, 4, 41)
     a, v = a.cuda(), v.cuda()
-    try:
-        engine.FP8, engine.RECOMPUTE = mode, recompute
-        m = CAVMAE_BASE(cfg=cfg, init_seed=7, init_mode="random", verbose=False, plan_seed=9).cuda()
+    if True:
+        m = CAVMAE_BASE(cfg=cfg, init_seed=7, init_mode="random", verbose=False, plan_seed=9, fp8_mode=mode, recompute=recompute).cuda()
         m.publish_grads = False
         hist, sat = [], []
         for _ in range(10):
@@ -108,7 +107,7 @@ def test_fp8_forward_with_recompute_trains_at_the_14x14_geometry(mode, recompute
         assert sat[-1] <= 4 and sat[-1] == sat[-5], sat
         st = m.fp8_state()
         assert st and all(len(v["seen"]) > 0 and float(v["q"][:, 0].max()) > 0 for v in st.values()), list(st)
-        m2 = CAVMAE_BASE(cfg=cfg, init_seed=7, init_mode="random", verbose=False, plan_seed=9).cuda()
+        m2 = CAVMAE_BASE(cfg=cfg, init_seed=7, init_mode="random", verbose=False, plan_seed=9, fp8_mode=mode, recompute=recompute).cuda()
         m2.load_state_dict(m.state_dict())
         m2.load_fp8_state(st)
         m2.publish_grads = False
@@ -117,8 +116,6 @@ def test_fp8_forward_with_recompute_trains_at_the_14x14_geometry(mode, recompute
             o1 = m(a, v, mae_loss_weight=1, contrast_loss_weight=0, mask_plan=plans[0])
             o2 = m2(a, v, mae_loss_weight=1, contrast_loss_weight=0, mask_plan=plans[0])
         assert abs(o1[0].item() - o2[0].item()) <= 2e-3 * abs(o1[0].item()), (o1[0].item(), o2[0].item())
-    finally:
-        engine.FP8, engine.RECOMPUTE = "0", "0"
     assert all(x == x and abs(x) < 1e4 for h in hist for x in h), hist
     assert hist[-1][0] < hist[0][0], (hist[0], hist[-1])          # loss_mae
 
@@ -139,11 +136,10 @@ def test_shared_activation_pool_is_the_same_training(mode):
     a, v = a.cuda(), v.cuda()
     gen = torch.Generator().manual_seed(4)
     pm, pc = make_mae_plan(cfg, B, gen), make_contrastive_plan(cfg, B, gen, random.Random(4))
-    try:
-        engine.FP8 = mode
+    if True:
         grads = {}
         for shared in (False, True):
-            m = CAVMAE_BASE(cfg=cfg, init_seed=3, init_mode="random", verbose=False, share_pass_buffers=shared).cuda()
+            m = CAVMAE_BASE(cfg=cfg, init_seed=3, init_mode="random", verbose=False, share_pass_buffers=shared, fp8_mode=mode).cuda()
             m.publish_grads = False
             torch.cuda.synchronize()
             base = torch.cuda.memory_allocated()                  # (parameters, gradients: everything but the passes' buffers)
@@ -176,8 +172,6 @@ def test_shared_activation_pool_is_the_same_training(mode):
         rel = float((g0 - g1).double().norm() / g0.double().norm())
         assert rel < (2e-2 if mode == "3" else 1e-4), rel          # bf16: the order of the fp32 atomics; fp8: amax atomics may move a scale by an ulp
         assert mem1 < 0.8 * mem0, (mem0, mem1)                    # the passes' buffers: the larger pass (+ chunk slack) instead of the sum
-    finally:
-        engine.FP8 = "0"
 
 
 @pytest.mark.parametrize("mode", ["0", "3"])
@@ -196,12 +190,10 @@ def test_contrastive_training_learns_an_audio_visual_correspondence(mode):
     from tests.helpers import correlated_av_batch, record_margin
     cfg = AVSiamConfig(audio_tokens=128, frames=1)
     B, steps = 16, 40
-    old = engine.FP8
-    engine.FP8 = mode
-    try:
+    if True:
         res = {}
         for shuffled in (False, True):
-            m = CAVMAE_BASE(cfg=cfg, init_seed=0, init_mode="init", verbose=False, plan_seed=3).cuda()
+            m = CAVMAE_BASE(cfg=cfg, init_seed=0, init_mode="init", verbose=False, plan_seed=3, fp8_mode=mode).cuda()
             m.publish_grads = False
             hist = []
             for step in range(steps):
@@ -220,8 +212,6 @@ def test_contrastive_training_learns_an_audio_visual_correspondence(mode):
         # (the MAE loss is recorded, not asserted: on fresh batches it follows each batch's latent energy - the reconstruction side of
         #  training is pinned on a fixed batch by test_fp8_forward_with_recompute_trains_at_the_14x14_geometry and the oracle-Adam step test)
         assert not (lc_s < 0.8 * math.log(B) and acc_s >= 4.0 / B), ("the control learned a correspondence that is not there", lc_s, acc_s)
-    finally:
-        engine.FP8 = old
 
 
 @pytest.mark.parametrize("fp8", ["0", "3"])
@@ -241,11 +231,9 @@ def test_graphed_step_equals_the_eager_step(fp8):
     B = 4
     a, v = synth_inputs(cfg, B, 11)
     a, v = a.cuda(), v.cuda()
-    old_fp8 = engine.FP8
-    engine.FP8 = fp8
 
     def fresh():
-        m = CAVMAE_BASE(cfg=cfg, init_seed=2, init_mode="random", verbose=False, plan_seed=21).cuda()
+        m = CAVMAE_BASE(cfg=cfg, init_seed=2, init_mode="random", verbose=False, plan_seed=21, fp8_mode=fp8).cuda()
         m.publish_grads = False
         return m
 
@@ -289,4 +277,4 @@ def test_graphed_step_equals_the_eager_step(fp8):
         og = [float(x.item()) for x in gs.step()]
         assert close(oe, og), (oe, og)
     finally:
-        engine.FP8 = old_fp8
+        pass
