@@ -225,7 +225,15 @@ struct AttnArgs {
                                                 // input-gradient GEMM - scaled by the device record qd8, whose running amax takes the largest |dqkv|
     int kv16;                                   // bwd with dqkv8: 0 = the key / value thirds of the bf16 dqkv are NOT written (fp8 mode 3: the input- and
                                                 // weight-gradient GEMMs read the e5m2 copy, only the query third's column sum - the bias gradient - reads bf16)
+    int lq;                                     // > 0 (equal-length sequences only): only the FIRST lq rows of every sequence are queries - keys / values are all
+                                                // of its rows - and `out` / `dout` are COMPACT: sequence s (= first row / length) owns their rows s * lq .. + lq - 1.
+                                                // The decoder's last block (cav_mae_base.py:629-635,679-682): rows whose prediction is never scored (mask 0) feed
+                                                // nothing but the keys and values of that block; lse / delta / dqkv keep the packed row numbering.  0: every row.
 };
+
+// queries of a sequence of length L, and the row of `out` / `dout` that holds the sequence's first query (AttnArgs::lq)
+__device__ __forceinline__ int attn_lq(const AttnArgs& a, int L) { return a.lq > 0 ? a.lq : L; }
+__device__ __forceinline__ size_t attn_orow0(const AttnArgs& a, int seq0, int L) { return a.lq > 0 ? (size_t)(seq0 / L) * (size_t)a.lq : (size_t)seq0; }
 
 // four consecutive gradient values -> one dword of e5m2 at `dst` (scaled, clamped to the e5m2 range), their |max| folded into gmax
 __device__ __forceinline__ void store_bf8x4(uint8_t* dst, float v0, float v1, float v2, float v3, float scale, float& gmax) {
@@ -260,9 +268,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int head = lid / a.ntiles, tix = lid - head * a.ntiles;
     const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int Lq = attn_lq(a, L);                       // (AttnArgs::lq: the queries are the first Lq rows of the sequence; normally all L)
+    if (a.tile_q0[tix] >= Lq) return;                   // block-uniform, before any barrier: a tile of rows that are keys / values only
+    const size_t orow0 = attn_orow0(a, seq0, L);
     const int qw = a.tile_q0[tix] + 32 * wave;          // first query of this wave
-    const bool active = qw < L;
-    const int q = min(qw + (lane & 31), L - 1);
+    const bool active = qw < Lq;
+    const int q = min(qw + (lane & 31), Lq - 1);
     const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HG;
 
     bf16x8 qf[NKK];
@@ -400,9 +411,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     const float inv = 1.0f / l_tot;
     const int qq = qw + (lane & 31);
     float omax = 0.f;
-    if (qq < L) {
-        bf16_t* orow = a.out + (size_t)(seq0 + qq) * a.ldo + head * HG;
-        uint8_t* orow8 = a.out8 ? a.out8 + (size_t)(seq0 + qq) * a.ldo8 + head * HG : nullptr;
+    if (qq < Lq) {
+        bf16_t* orow = a.out + (orow0 + qq) * a.ldo + head * HG;
+        uint8_t* orow8 = a.out8 ? a.out8 + (orow0 + qq) * a.ldo8 + head * HG : nullptr;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) store_block<HG, false>(orow, d, hh, o[d], inv, orow8, q8s, omax);      // (columns of the image beyond the real head dim are skipped)
         if (hh == 0) a.lse[(size_t)head * a.rows_total + seq0 + qq] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
@@ -739,9 +750,12 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : (HD == 64 && N
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int head = lid / a.ntiles, tix = lid - head * a.ntiles;
     const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int Lq = attn_lq(a, L);                       // (AttnArgs::lq)
+    if (a.tile_q0[tix] >= Lq) return;                   // block-uniform, before any barrier
+    const size_t orow0 = attn_orow0(a, seq0, L);
     const int qw = a.tile_q0[tix] + 32 * wave;
-    const bool active = qw < L;
-    const int q = min(qw + (lane & 31), L - 1);
+    const bool active = qw < Lq;
+    const int q = min(qw + (lane & 31), Lq - 1);
     const bf16_t* base = a.qkv + (size_t)seq0 * a.ld + head * HG;
 
     bf16x8 qf[NKK], dof[NKK];
@@ -749,14 +763,14 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : (HD == 64 && N
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) {
         qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)q * a.ld + (2 * kk + hh) * 8);
-        dof[kk] = *reinterpret_cast<const bf16x8*>(a.dout + (size_t)(seq0 + q) * a.ldo + head * HG + (2 * kk + hh) * 8);
-        const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.out + (size_t)(seq0 + q) * a.ldo + head * HG + (2 * kk + hh) * 8);
+        dof[kk] = *reinterpret_cast<const bf16x8*>(a.dout + (orow0 + q) * a.ldo + head * HG + (2 * kk + hh) * 8);
+        const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.out + (orow0 + q) * a.ldo + head * HG + (2 * kk + hh) * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) dpart += bf2f((bf16_t)dof[kk][j]) * bf2f((bf16_t)of[j]);
     }
     const float delta = dpart + __shfl_xor(dpart, 32, 64);
     const float lse2 = a.lse[(size_t)head * a.rows_total + seq0 + q] * 1.4426950408889634f;
-    if (active && hh == 0 && qw + (lane & 31) < L) a.delta[(size_t)head * a.rows_total + seq0 + q] = delta;
+    if (active && hh == 0 && qw + (lane & 31) < Lq) a.delta[(size_t)head * a.rows_total + seq0 + q] = delta;
     // the query is on the lane, so -lse and -delta are per-lane constants: as the accumulators' initial values they make
     // the MFMAs deliver log2(p) and (dP - delta) with no VALU work.  Only for hd 32 (VALU-bound, registers to spare): at
     // hd 64 the two 16-register tuples cost an occupancy step (174 vs 142 VGPRs) that outweighs two VALU ops per score.
@@ -831,7 +845,7 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : (HD == 64 && N
     float g8s = 0.f, g8seen = 0.f, g8max = 0.f;
     if (G8) { g8s = a.qd8[AVS_Q_SCALE]; g8seen = a.qd8[AVS_Q_AMAX]; }
     const int qq = qw + (lane & 31);
-    if (qq < L) {
+    if (qq < Lq) {
         bf16_t* drow = a.dqkv + (size_t)(seq0 + qq) * a.ld + head * HG;
         uint8_t* drow8 = G8 ? a.dqkv8 + (size_t)(seq0 + qq) * a.ld8 + head * HG : nullptr;
 #pragma unroll
@@ -1010,7 +1024,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
 
-    const bf16_t* dobase = a.dout + (size_t)seq0 * a.ldo + head * HG;
+    // the query side: the sequence's first Lq rows (AttnArgs::lq; normally all L), dO in the compact row numbering when lq is set
+    const int Lq = attn_lq(a, L);
+    const bf16_t* dobase = a.dout + attn_orow0(a, seq0, L) * a.ldo + head * HG;
     const float* lsebase = a.lse + (size_t)head * a.rows_total + seq0;
     const float* delbase = a.delta + (size_t)head * a.rows_total + seq0;
     TileRegs<HD, NTH> rq, rdo;
@@ -1018,22 +1034,22 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
     toq.init(a.ld, tid);
     tod.init(a.ldo, tid);
     float rl = 0.f, rd = 0.f;
-    tile_load<HD, NTH, HG>(rq, toq, base, a.ld, 0, L - 1, tid);
-    tile_load<HD, NTH, HG>(rdo, tod, dobase, a.ldo, 0, L - 1, tid);
-    if (tid < 64) { rl = lsebase[min(tid, L - 1)]; rd = delbase[min(tid, L - 1)]; }
-    for (int q0 = 0; q0 < L; q0 += 64) {
+    tile_load<HD, NTH, HG>(rq, toq, base, a.ld, 0, Lq - 1, tid);
+    tile_load<HD, NTH, HG>(rdo, tod, dobase, a.ldo, 0, Lq - 1, tid);
+    if (tid < 64) { rl = lsebase[min(tid, Lq - 1)]; rd = delbase[min(tid, Lq - 1)]; }
+    for (int q0 = 0; q0 < Lq; q0 += 64) {
         __syncthreads();
         tile_store<HD, NTH>(rq, sQ, tid);
         tile_store<HD, NTH>(rdo, sDO, tid);
         if (tid < 64) { sLse[tid] = -rl * 1.4426950408889634f; sDel[tid] = -rd; }    // negated: MFMA C operands
         __syncthreads();
-        if (q0 + 64 < L) {
-            tile_load<HD, NTH, HG>(rq, toq, base, a.ld, q0 + 64, L - 1, tid);
-            tile_load<HD, NTH, HG>(rdo, tod, dobase, a.ldo, q0 + 64, L - 1, tid);
-            if (tid < 64) { rl = lsebase[min(q0 + 64 + tid, L - 1)]; rd = delbase[min(q0 + 64 + tid, L - 1)]; }
+        if (q0 + 64 < Lq) {
+            tile_load<HD, NTH, HG>(rq, toq, base, a.ld, q0 + 64, Lq - 1, tid);
+            tile_load<HD, NTH, HG>(rdo, tod, dobase, a.ldo, q0 + 64, Lq - 1, tid);
+            if (tid < 64) { rl = lsebase[min(q0 + 64 + tid, Lq - 1)]; rd = delbase[min(q0 + 64 + tid, Lq - 1)]; }
         }
         if (!active) continue;
-        const bool tail_tile = q0 + 64 > L;                 // block-uniform
+        const bool tail_tile = q0 + 64 > Lq;                 // block-uniform
         auto q_block = [&](int qb) {
             // the query is on the accumulator ROWS here: -lse / -delta of the 16 rows this lane holds come straight from LDS
             // into the C operands
@@ -1056,7 +1072,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
                 asm volatile("; tail query tile: mask" ::: "memory");
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (q0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -INFINITY;     // -> p = exp2(-inf) = 0
+                    if (q0 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= Lq) s[r] = -INFINITY;     // -> p = exp2(-inf) = 0
             }
             float p[16], ds[16];
 #pragma unroll
@@ -1259,9 +1275,10 @@ static int check_common(const char* name, const void* qkv, long long ld, int D, 
 }
 
 // out8 / ldo8 / q8 (all or none): also write e4m3(clamp(out * q8[0], +-448)) - the fp8 operand of the proj GEMM - and fold max |out| into q8[2]
-extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
-                               const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
-                               uint8_t* out8, long long ldo8, float* q8, hipStream_t stream) {
+static int attn_fwd_impl(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                         const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
+                         uint8_t* out8, long long ldo8, float* q8, int lq, hipStream_t stream) {
+    AVS_CHECK_ARG(lq >= 0, "attn_fwd: lq < 0");
     AVS_CHECK_ARG((out8 == nullptr) == (q8 == nullptr) && (!out8 || (ldo8 >= D && (ldo8 % 16) == 0)), "attn_fwd: out8 and q8 go together, ldo8 %% 16 == 0");
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_fwd: tile_rows must be 64 or 128");
     AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_fwd: head dim 80 runs with 128-row tiles only");
@@ -1270,10 +1287,10 @@ extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
     AVS_CHECK_ARG(out && lse, "attn_fwd: null output");
     AVS_CHECK_ARG((ldo % 8) == 0 && ldo >= D, "attn_fwd: ldo=%lld must be a multiple of 8 (the epilogue stores 16 bytes per lane) and >= D", ldo);
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd),
-               out8, ldo8, q8, nullptr, 0, nullptr};
+               out8, ldo8, q8, nullptr, 0, nullptr, 1, lq};
     dim3 grid(ntiles * H);
     // hd 80 (ViT-H: 1280 / 16 heads): a 96-wide LDS image whose last 16 columns are zero, five contraction steps, 128-row tiles only
-    const bool ring = avs_tuning().attn_ring != 0;          // K / V tiles by LDS-DMA ring (hd 32 / 64; bitwise the register-staged kernels' results)
+    const bool ring = avs_tuning().attn_ring != 0 && lq == 0;          // K / V tiles by LDS-DMA ring (hd 32 / 64; bitwise the register-staged kernels' results)
     if (hd == 80) attn_fwd_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
     else if (tile_rows == 128) {
         if (hd == 64) { if (ring) attn_fwd_ring_kernel<64, 4, 3><<<grid, 256, 0, stream>>>(a); else attn_fwd_kernel<64, 4><<<grid, 256, 0, stream>>>(a); }
@@ -1286,6 +1303,21 @@ extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
     return 0;
 }
 
+extern "C" int avs_attn_fwd_q8(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                               const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
+                               uint8_t* out8, long long ldo8, float* q8, hipStream_t stream) {
+    return attn_fwd_impl(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, ldo, lse, rows_total, out8, ldo8, q8, 0, stream);
+}
+
+// The same with only the first `lq` rows of every sequence as QUERIES (all rows are keys / values) and a COMPACT output: sequence s owns rows
+// s * lq .. of `out`; every sequence of the launch must have the same length (tile_len), lse keeps the packed numbering (AttnArgs::lq).
+extern "C" int avs_attn_fwd_cq(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                               const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
+                               int lq, hipStream_t stream) {
+    AVS_CHECK_ARG(lq > 0, "attn_fwd_cq: lq must be positive");
+    return attn_fwd_impl(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, ldo, lse, rows_total, nullptr, 0, nullptr, lq, stream);
+}
+
 extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                             const int* tile_q0, int ntiles, int tile_rows, bf16_t* out, long long ldo, float* lse, int rows_total,
                             hipStream_t stream) {
@@ -1294,10 +1326,11 @@ extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const
 
 // dqkv8 / ld8 / qd8 (all or none): also write e5m2(clamp(dqkv * qd8[0], +-57344)) [rows, 3*D] / ld8 - the gradient operand of the fp8 qkv
 // input-gradient GEMM - and fold max |dqkv| into the device record qd8
-extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
-                               const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
-                               const float* lse, float* delta, int rows_total, bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
-                               int kv_bf16, hipStream_t stream) {
+static int attn_bwd_impl(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                         const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
+                         const float* lse, float* delta, int rows_total, bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
+                         int kv_bf16, int lq, hipStream_t stream) {
+    AVS_CHECK_ARG(lq >= 0, "attn_bwd: lq < 0");
     // kv_bf16 == 0 (with dqkv8 only): the key and value thirds of the bf16 dqkv are left unwritten - their only readers take the e5m2 copy
     AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd: kv_bf16 = 0 needs the e5m2 copy");
     AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 16) == 0)), "attn_bwd: dqkv8 and its record go together, ld8 %% 16 == 0");
@@ -1308,7 +1341,7 @@ extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
     AVS_CHECK_ARG((ldo % 8) == 0 && ldo >= D, "attn_bwd: ldo=%lld must be a multiple of 8 (16-byte fragment loads of out / dO rows) and >= D", ldo);
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16};
+               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16, lq};
     dim3 grid(ntiles * H);
 #define ATTN_BWD2(K, G)                                                                                     \
     do {                                                                                                    \
@@ -1321,7 +1354,7 @@ extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
             else K<32, 2, 32, G><<<grid, 128, 0, stream>>>(a);                                              \
         }                                                                                                   \
     } while (0)
-    const bool ring = avs_tuning().attn_ring != 0 && hd != 80;
+    const bool ring = avs_tuning().attn_ring != 0 && hd != 80 && lq == 0;
 #define ATTN_BWD2R(K, G)                                                                                    \
     do {                                                                                                    \
         if (tile_rows == 128) {                                                                             \
@@ -1340,6 +1373,22 @@ extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, co
 #undef ATTN_BWD2
     AVS_LAUNCH_CHECK("attn_bwd_dkv");
     return 0;
+}
+
+extern "C" int avs_attn_bwd_q8(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                               const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
+                               const float* lse, float* delta, int rows_total, bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
+                               int kv_bf16, hipStream_t stream) {
+    return attn_bwd_impl(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, dout, ldo, lse, delta, rows_total, dqkv, dqkv8, ld8, qd8, kv_bf16, 0, stream);
+}
+
+// The backward of avs_attn_fwd_cq: `out` / `dout` compact (sequence s owns rows s * lq ..), dq is written for the first lq rows of every
+// sequence (the query third of the OTHER rows of dqkv is left untouched: the caller zeroes it), dk / dv for all rows.
+extern "C" int avs_attn_bwd_cq(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                               const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
+                               const float* lse, float* delta, int rows_total, bf16_t* dqkv, int lq, hipStream_t stream) {
+    AVS_CHECK_ARG(lq > 0, "attn_bwd_cq: lq must be positive");
+    return attn_bwd_impl(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, dout, ldo, lse, delta, rows_total, dqkv, nullptr, 0, nullptr, 1, lq, stream);
 }
 
 extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
@@ -1361,7 +1410,7 @@ extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int
                   "attn_bwd_fused: bad arguments (D=%d H=%d hd=%d ld=%lld nseq=%d)", D, H, hd, ld, nseq);
     AVS_CHECK_ARG(out && dout && lse && dqkv && (ldo % 8) == 0, "attn_bwd_fused: null pointer");
     AttnArgs a{qkv, ld, D, seq_start, seq_len, nullptr, nseq, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16};
+               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16, 0};
     dim3 grid(nseq * H);
 #define ATTN_BWDF(G)                                                                                        \
     do {                                                                                                    \

@@ -147,9 +147,11 @@ __global__ void unshuffle_fwd_kernel(const float* __restrict__ x, const int* __r
 // Backward of the un-shuffle.  One block per position l of [La + Lv]; it walks every (sample, frame) row at
 // that position: sums the positional gradient in registers (no atomics), routes kept rows back to the encoder
 // layout (dx[src] = dout row) and accumulates mask-token / modality sums (one atomic per column per block).
+// row_of_pos (may be NULL): the decoder row that holds position (b, l) when the decoder rows are not in position order (the grouped layout of
+// maskplan.hip: scored rows first); src_row is indexed by decoder row.
 __global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ src_row, int B, int T,
                                      int La, int Lv, float* __restrict__ dx, float* dpos_a, float* dpos_v,
-                                     float* dmask, float* dmod_a, float* dmod_v, int D) {
+                                     float* dmask, float* dmod_a, float* dmod_v, int D, const int* __restrict__ row_of_pos) {
     const int l = blockIdx.x;
     const bool audio = l < La;
     const int Ltot = La + T * Lv;
@@ -158,7 +160,8 @@ __global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* 
         const int reps = audio ? 1 : T;
         for (int b = 0; b < B; ++b)
             for (int t = 0; t < reps; ++t) {
-                const int r = b * Ltot + (audio ? l : La + t * Lv + (l - La));
+                const int rp = b * Ltot + (audio ? l : La + t * Lv + (l - La));
+                const int r = row_of_pos ? row_of_pos[rp] : rp;
                 const float4 g = reinterpret_cast<const float4*>(dout + (size_t)r * D)[c];
                 sp.x += g.x; sp.y += g.y; sp.z += g.z; sp.w += g.w;
                 const int s = src_row[r];
@@ -652,12 +655,46 @@ extern "C" int avs_unshuffle_fwd(const float* x, const int* src_row, const int* 
     return 0;
 }
 
+extern "C" int avs_unshuffle_bwd_map(const float* dout, const int* src_row, int B, int T, int La, int Lv, float* dx,
+                                     float* dpos_a, float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D,
+                                     const int* row_of_pos, hipStream_t stream) {
+    AVS_CHECK_ARG(B > 0 && T > 0 && (D % 4) == 0 && dout && src_row && dx, "unshuffle_bwd: bad args");
+    unshuffle_bwd_kernel<<<La + Lv, 128, 0, stream>>>(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, row_of_pos);
+    AVS_LAUNCH_CHECK("unshuffle_bwd");
+    return 0;
+}
+
 extern "C" int avs_unshuffle_bwd(const float* dout, const int* src_row, int B, int T, int La, int Lv, float* dx,
                                  float* dpos_a, float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D,
                                  hipStream_t stream) {
-    AVS_CHECK_ARG(B > 0 && T > 0 && (D % 4) == 0 && dout && src_row && dx, "unshuffle_bwd: bad args");
-    unshuffle_bwd_kernel<<<La + Lv, 128, 0, stream>>>(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D);
-    AVS_LAUNCH_CHECK("unshuffle_bwd");
+    return avs_unshuffle_bwd_map(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, nullptr, stream);
+}
+
+// out[r, 0:cols] = src_row[r] >= 0 ? in[src_row[r], 0:cols] : 0  (bf16 rows of `cols` values, a multiple of 8; leading dimensions in elements).
+// in == NULL: only the rows with src_row[r] < 0 are written (zeroed), the others are left as they are.  Used by the decoder's last block in
+// the pruned form (engine.Stack): the compact gradient of the scored rows back into the packed row numbering (zeros for the other rows), and the
+// zero query gradient of the rows that were keys / values only.
+__global__ void expand_rows_kernel(const bf16_t* __restrict__ in, long long ld_in, const int* __restrict__ src_row, bf16_t* __restrict__ out,
+                                   long long ld_out, int rows, int cols) {
+    const int per = cols / 8;                                  // 16-byte chunks per row
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)rows * per; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / per), c = (int)(i - (long long)r * per);
+        const int s = src_row[r];
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (s >= 0) {
+            if (!in) continue;
+            v = *reinterpret_cast<const uint4*>(in + (size_t)s * ld_in + c * 8);
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)r * ld_out + c * 8) = v;
+    }
+}
+
+extern "C" int avs_expand_rows_bf16(const bf16_t* in, long long ld_in, const int* src_row, bf16_t* out, long long ld_out, int rows, int cols,
+                                    hipStream_t stream) {
+    AVS_CHECK_ARG(src_row && out && rows > 0 && cols > 0 && (cols % 8) == 0 && (ld_out % 8) == 0 && ld_out >= cols && (!in || ((ld_in % 8) == 0 && ld_in >= cols)),
+                  "expand_rows: bad args (rows=%d cols=%d)", rows, cols);
+    expand_rows_kernel<<<grid_1d((long long)rows * (cols / 8), 256), 256, 0, stream>>>(in, ld_in, src_row, out, ld_out, rows, cols);
+    AVS_LAUNCH_CHECK("expand_rows");
     return 0;
 }
 

@@ -24,26 +24,29 @@ __device__ __forceinline__ float mae_target(const void* __restrict__ inp, int au
     return valid ? xf_video(inp, xf, (((size_t)n * C + c) * H + gy * S + p) * W + gx * S + q, c) : 0.f;
 }
 
+// row_id (may be NULL): prediction row pr scores token row_id[pr] - id_base of the [N * L] (sample, token) numbering the mask and the targets are
+// indexed by - COMPACT predictions: only the rows whose mask is 1 are computed at all (maskplan.hip: pred_id).  NULL: pr is that index itself.
 __global__ void mae_loss_fwd_kernel(const float* __restrict__ pred, const void* __restrict__ inp,
                                     const float* __restrict__ mask, float* __restrict__ row_loss, int audio, int L, int C,
-                                    int H, int W, int G, int P, int S, InXf xf) {
+                                    int H, int W, int G, int P, int S, InXf xf, const int* __restrict__ row_id, int id_base) {
     __shared__ float red[4];
-    const int r = blockIdx.x;
+    const int pr = blockIdx.x;
+    const int r = row_id ? row_id[pr] - id_base : pr;
     if (mask[r] == 0.f) {
-        if (threadIdx.x == 0) row_loss[r] = 0.f;
+        if (threadIdx.x == 0) row_loss[pr] = 0.f;
         return;
     }
     float s = 0.f;
     for (int e = threadIdx.x; e < P; e += blockDim.x) {
         bool valid;
         const float tg = mae_target(inp, audio, r, e, L, C, H, W, G, S, xf, valid);
-        const float d = valid ? pred[(size_t)r * P + e] - tg : 0.f;
+        const float d = valid ? pred[(size_t)pr * P + e] - tg : 0.f;
         s += d * d;
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) row_loss[r] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(P / 256 * S * S) * mask[r];      // mean over the scored elements
+    if (threadIdx.x == 0) row_loss[pr] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(P / 256 * S * S) * mask[r];      // mean over the scored elements
 }
 
 // deterministic single-block sum: out[0] = scale * sum(x); optionally total[0] = (total_init ? 0 : total[0]) + out[0]
@@ -66,8 +69,10 @@ __global__ void sum_scale_kernel(const float* __restrict__ x, int n, float scale
 // dpred[r, e] = g * 2 (pred - target) mask[r] / (P * nmask)   (bf16: operand of the prediction-head GEMMs)
 __global__ void mae_loss_bwd_kernel(const float* __restrict__ pred, const void* __restrict__ inp,
                                     const float* __restrict__ mask, const float* __restrict__ gout, bf16_t* __restrict__ dpred,
-                                    int audio, int L, int C, int H, int W, int G, int P, int S, float inv_nmask, InXf xf) {
-    const int r = blockIdx.x;
+                                    int audio, int L, int C, int H, int W, int G, int P, int S, float inv_nmask, InXf xf,
+                                    const int* __restrict__ row_id, int id_base) {
+    const int pr = blockIdx.x;
+    const int r = row_id ? row_id[pr] - id_base : pr;
     const float m = mask[r];
     const float k = gout[0] * 2.0f * m * inv_nmask / (float)(P / 256 * S * S);
     for (int e = threadIdx.x; e < P; e += blockDim.x) {
@@ -75,9 +80,9 @@ __global__ void mae_loss_bwd_kernel(const float* __restrict__ pred, const void* 
         if (m != 0.f) {
             bool valid;
             const float tg = mae_target(inp, audio, r, e, L, C, H, W, G, S, xf, valid);
-            if (valid) d = k * (pred[(size_t)r * P + e] - tg);
+            if (valid) d = k * (pred[(size_t)pr * P + e] - tg);
         }
-        dpred[(size_t)r * P + e] = f2bf(d);
+        dpred[(size_t)pr * P + e] = f2bf(d);
     }
 }
 
@@ -225,19 +230,25 @@ __global__ void infonce_dlogits_kernel(const float* __restrict__ total, const fl
 // ===================================================================================================
 int avs_make_xf(const avs_input_xf_t* x, int want_kind, InXf* out, const char* who);     // elementwise.hip
 
-extern "C" int avs_mae_loss_fwd_s(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss,
-                                  float* total, int total_init, int rows, int audio, int L, int C, int H, int W, float nmask,
-                                  int stride, const avs_input_xf_t* xf, hipStream_t stream) {
+extern "C" int avs_mae_loss_fwd_id(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss,
+                                   float* total, int total_init, int rows, int audio, int L, int C, int H, int W, float nmask,
+                                   int stride, const avs_input_xf_t* xf, const int* row_id, int id_base, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && pred && inp && mask && row_loss && loss && nmask > 0 && stride > 0 && stride <= 16, "mae_loss_fwd: bad args");
     InXf x;
     if (int rc = avs_make_xf(xf, audio ? 1 : 2, &x, "mae_loss_fwd")) return rc;
     const int G = audio ? H / stride : W / stride;
     const int P = 256 * (audio ? 1 : C);
-    mae_loss_fwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, row_loss, audio, L, C, H, W, G, P, stride, x);
+    mae_loss_fwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, row_loss, audio, L, C, H, W, G, P, stride, x, row_id, id_base);
     AVS_LAUNCH_CHECK("mae_loss_fwd");
     sum_scale_kernel<<<1, 1024, 0, stream>>>(row_loss, rows, 1.0f / nmask, loss, total, total_init);
     AVS_LAUNCH_CHECK("mae_loss_sum");
     return 0;
+}
+
+extern "C" int avs_mae_loss_fwd_s(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss,
+                                  float* total, int total_init, int rows, int audio, int L, int C, int H, int W, float nmask,
+                                  int stride, const avs_input_xf_t* xf, hipStream_t stream) {
+    return avs_mae_loss_fwd_id(pred, inp, mask, row_loss, loss, total, total_init, rows, audio, L, C, H, W, nmask, stride, xf, nullptr, 0, stream);
 }
 
 extern "C" int avs_mae_loss_fwd_xf(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss,
@@ -252,17 +263,23 @@ extern "C" int avs_mae_loss_fwd(const float* pred, const float* inp, const float
     return avs_mae_loss_fwd_xf(pred, inp, mask, row_loss, loss, total, total_init, rows, audio, L, C, H, W, nmask, nullptr, stream);
 }
 
-extern "C" int avs_mae_loss_bwd_s(const float* pred, const void* inp, const float* mask, const float* gout, bf16_t* dpred,
-                                  int rows, int audio, int L, int C, int H, int W, float nmask, int stride, const avs_input_xf_t* xf,
-                                  hipStream_t stream) {
+extern "C" int avs_mae_loss_bwd_id(const float* pred, const void* inp, const float* mask, const float* gout, bf16_t* dpred,
+                                   int rows, int audio, int L, int C, int H, int W, float nmask, int stride, const avs_input_xf_t* xf,
+                                   const int* row_id, int id_base, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && pred && inp && mask && gout && dpred && nmask > 0 && stride > 0 && stride <= 16, "mae_loss_bwd: bad args");
     InXf x;
     if (int rc = avs_make_xf(xf, audio ? 1 : 2, &x, "mae_loss_bwd")) return rc;
     const int G = audio ? H / stride : W / stride;
     const int P = 256 * (audio ? 1 : C);
-    mae_loss_bwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, gout, dpred, audio, L, C, H, W, G, P, stride, 1.0f / nmask, x);
+    mae_loss_bwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, gout, dpred, audio, L, C, H, W, G, P, stride, 1.0f / nmask, x, row_id, id_base);
     AVS_LAUNCH_CHECK("mae_loss_bwd");
     return 0;
+}
+
+extern "C" int avs_mae_loss_bwd_s(const float* pred, const void* inp, const float* mask, const float* gout, bf16_t* dpred,
+                                  int rows, int audio, int L, int C, int H, int W, float nmask, int stride, const avs_input_xf_t* xf,
+                                  hipStream_t stream) {
+    return avs_mae_loss_bwd_id(pred, inp, mask, gout, dpred, rows, audio, L, C, H, W, nmask, stride, xf, nullptr, 0, stream);
 }
 
 extern "C" int avs_mae_loss_bwd_xf(const float* pred, const void* inp, const float* mask, const float* gout, bf16_t* dpred,

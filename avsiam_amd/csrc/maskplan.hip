@@ -12,9 +12,16 @@
 //   src_row[dec_off + token]       = enc_base + j | -1             for the decoder un-shuffle
 //   mask[mask_off + token]         = 0 kept | 1 removed            the loss mask the forward returns (:385-388)
 //   ids_out[ids_off + j]           = j-th token of the shuffle     (optional: lets tests rebuild the plan)
+// GROUPED decoder layout (round 6; PlanSeq.dec_m_off >= 0, avs_mask_plan_grouped): the decoder rows of a sample are ordered
+// [tokens whose prediction is scored (mask 1) | kept tokens] instead of by position, so that the rows the LAST decoder block and the
+// prediction heads still have to compute (cav_mae_base.py:629-635,679-682: loss * mask) are the first rows of every sequence:
+//   src_row[dec row]               = enc_base + j | -1             dec row = dec_k_off + j (kept, j < keep) | dec_m_off + j - keep (masked)
+//   pos_row[dec row]               = pos_base + token              position of the row's token in the sample: which positional embedding it takes
+//   row_of_pos[dec_off + token]    = dec row                       the inverse (un-shuffle backward walks the positions)
+//   pred_id[pred_off + j - keep]   = mask_off + token              which (sample, token) a compact prediction row scores
 #include "common.h"
 
-struct PlanSeq {        // one sequence to draw (int32 x 12, filled by the host)
+struct PlanSeq {        // one sequence to draw (int32 x 16, filled by the host)
     int L;              // tokens before masking
     int keep;           // tokens kept
     int row_off;        // first row of this sequence in the packed token matrix
@@ -26,6 +33,10 @@ struct PlanSeq {        // one sequence to draw (int32 x 12, filled by the host)
     int mask_off;       // offset of this sequence in mask_out (loss-mask layout), used when dec_off >= 0
     int tmask_x;        // bits 64..95 of the structured time mask (grids of more than 64 time patches: 73 at patch stride 14)
     int pad1, pad2;
+    int dec_m_off;      // grouped decoder layout: decoder row of this sequence's first MASKED token, -1 = the classic (position-ordered) layout
+    int dec_k_off;      //   decoder row of its first KEPT token
+    int pred_off;       //   compact prediction row of its first masked token
+    int pos_base;       //   position of its token 0 inside the sample (audio: 0; frame t: La + t * Lv)
 };
 
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
@@ -48,7 +59,8 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const PlanSeq* __restric
                                                         unsigned seed_lo, unsigned seed_hi, int* __restrict__ row_src,
                                                         int* __restrict__ row_tok, int* __restrict__ src_row,
                                                         float* __restrict__ mask_out, int* __restrict__ ids_out,
-                                                        const unsigned long long* __restrict__ seed_dev) {
+                                                        const unsigned long long* __restrict__ seed_dev, int* __restrict__ pos_row,
+                                                        int* __restrict__ row_of_pos, int* __restrict__ pred_id) {
     __shared__ float key[1024];
     __shared__ short idx[1024];
     if (seed_dev) {                             // the key lives in device memory (a step replayed from a captured hipGraph: avs_mask_plan_dev)
@@ -98,7 +110,15 @@ __global__ __launch_bounds__(256) void mask_plan_kernel(const PlanSeq* __restric
             row_tok[s.row_off + j] = tok;
         }
         if (s.dec_off >= 0) {
-            src_row[s.dec_off + tok] = j < s.keep ? s.enc_base + j : -1;
+            if (s.dec_m_off >= 0) {                               // grouped decoder layout: scored rows first
+                const int dr = j < s.keep ? s.dec_k_off + j : s.dec_m_off + (j - s.keep);
+                src_row[dr] = j < s.keep ? s.enc_base + j : -1;
+                pos_row[dr] = s.pos_base + tok;
+                row_of_pos[s.dec_off + tok] = dr;
+                if (j >= s.keep) pred_id[s.pred_off + (j - s.keep)] = s.mask_off + tok;
+            } else {
+                src_row[s.dec_off + tok] = j < s.keep ? s.enc_base + j : -1;
+            }
             mask_out[s.mask_off + tok] = j < s.keep ? 0.0f : 1.0f;
         }
         if (s.ids_off >= 0) ids_out[s.ids_off + j] = tok;
@@ -110,7 +130,7 @@ extern "C" int avs_mask_plan(const int* seqs, int nseq, const unsigned* tmask_lo
                              hipStream_t stream) {
     AVS_CHECK_ARG(seqs && nseq > 0 && row_src && row_tok, "mask_plan: bad arguments");
     mask_plan_kernel<<<nseq, 256, 0, stream>>>(reinterpret_cast<const PlanSeq*>(seqs), tmask_lo, tmask_hi, fmask, (unsigned)seed,
-                                               (unsigned)(seed >> 32), row_src, row_tok, src_row, mask_out, ids_out, nullptr);
+                                               (unsigned)(seed >> 32), row_src, row_tok, src_row, mask_out, ids_out, nullptr, nullptr, nullptr, nullptr);
     AVS_LAUNCH_CHECK("mask_plan");
     return 0;
 }
@@ -122,7 +142,19 @@ extern "C" int avs_mask_plan_dev(const int* seqs, int nseq, const unsigned* tmas
                                  hipStream_t stream) {
     AVS_CHECK_ARG(seqs && nseq > 0 && row_src && row_tok && seed_dev, "mask_plan_dev: bad arguments");
     mask_plan_kernel<<<nseq, 256, 0, stream>>>(reinterpret_cast<const PlanSeq*>(seqs), tmask_lo, tmask_hi, fmask, 0u, 0u, row_src, row_tok, src_row,
-                                               mask_out, ids_out, seed_dev);
+                                               mask_out, ids_out, seed_dev, nullptr, nullptr, nullptr);
     AVS_LAUNCH_CHECK("mask_plan_dev");
+    return 0;
+}
+
+// Sequences whose descriptor says dec_m_off >= 0 are laid out in the GROUPED decoder order (file header) and need the three extra index
+// arrays; seed_dev (may be NULL): the Philox key in device memory, as avs_mask_plan_dev, else `seed`.
+extern "C" int avs_mask_plan_grouped(const int* seqs, int nseq, const unsigned* tmask_lo, const unsigned* tmask_hi, const unsigned* fmask,
+                                     unsigned long long seed, const unsigned long long* seed_dev, int* row_src, int* row_tok, int* src_row,
+                                     float* mask_out, int* ids_out, int* pos_row, int* row_of_pos, int* pred_id, hipStream_t stream) {
+    AVS_CHECK_ARG(seqs && nseq > 0 && row_src && row_tok && src_row && mask_out && pos_row && row_of_pos && pred_id, "mask_plan_grouped: bad arguments");
+    mask_plan_kernel<<<nseq, 256, 0, stream>>>(reinterpret_cast<const PlanSeq*>(seqs), tmask_lo, tmask_hi, fmask, (unsigned)seed, (unsigned)(seed >> 32),
+                                               row_src, row_tok, src_row, mask_out, ids_out, seed_dev, pos_row, row_of_pos, pred_id);
+    AVS_LAUNCH_CHECK("mask_plan_grouped");
     return 0;
 }

@@ -202,6 +202,17 @@ int avs_attn_bwd_q8(const avs_bf16* qkv, long long ld, int D, int H, const int* 
                     const int* tile_q0, int ntiles, int tile_rows, const avs_bf16* out, const avs_bf16* dout, long long ldo,
                     const float* lse, float* delta, int rows_total, avs_bf16* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
                     int kv_bf16, avs_stream_t stream);
+/* Pruned form for the LAST decoder block (forward_decoder + forward_mae_loss, cav_mae_base.py:629-635,679-682: rows with mask 0 contribute
+ * neither loss nor gradient, so in the last block they are needed as keys / values only).  Every sequence of the launch has the same length
+ * (tile_len); only its FIRST lq rows are queries, all rows are keys / values; `out` / `dout` are COMPACT [nseq * lq, D]: sequence s
+ * (= tile_start / tile_len) owns rows s * lq ..; lse / delta / dqkv keep the packed row numbering.  The backward writes dq for the first lq
+ * rows of every sequence only (the caller zeroes the query third of the other rows, avs_expand_rows_bf16) and dk / dv for all rows. */
+int avs_attn_fwd_cq(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                    const int* tile_q0, int ntiles, int tile_rows, avs_bf16* out, long long ldo, float* lse, int rows_total,
+                    int lq, avs_stream_t stream);
+int avs_attn_bwd_cq(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
+                    const int* tile_q0, int ntiles, int tile_rows, const avs_bf16* out, const avs_bf16* dout, long long ldo,
+                    const float* lse, float* delta, int rows_total, avs_bf16* dqkv, int lq, avs_stream_t stream);
 /* the same backward for sequences of at most rows_per_wg (64 | 128) tokens, in ONE kernel: a workgroup per (sequence, head) reads q, k,
  * v, dO, o once, evaluates S and its exponentials once and writes dq, dk and dv (hd 32 | 64).  seq_start / seq_len: [nseq] */
 int avs_attn_bwd_fused(const avs_bf16* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
@@ -248,8 +259,9 @@ int avs_im2col_audio_xf(const float* a, const int* row_b, const int* row_tok, av
 int avs_im2col_video_xf(const void* v, const int* row_img, const int* row_tok, avs_bf16* out, int rows, int C, int H, int W,
                         const avs_input_xf* xf, avs_stream_t stream);
 /* random masking on the device (random_masking_unstructured / _structured + the gather index build,
- * cav_mae_base.py:365-439): one workgroup per sequence; seqs = nseq x 12 int32 {L, keep, row_off, src_id, dec_off, enc_base,
- * t_patches, ids_off, mask_off, 0, 0, 0}; L <= 1024.  tmask_lo/hi, fmask (per sequence bit masks of the time columns /
+ * cav_mae_base.py:365-439): one workgroup per sequence; seqs = nseq x 16 int32 {L, keep, row_off, src_id, dec_off, enc_base,
+ * t_patches, ids_off, mask_off, tmask_x, 0, 0, dec_m_off, dec_k_off, pred_off, pos_base} (the last four: avs_mask_plan_grouped; dec_m_off
+ * must be -1 for the two entry points below); L <= 1024.  tmask_lo/hi, fmask (per sequence bit masks of the time columns /
  * frequency rows forced to be removed) are read only where t_patches > 0.  src_row / mask_out / ids_out may be NULL when no
  * sequence uses them. */
 int avs_mask_plan(const int* seqs, int nseq, const unsigned* tmask_lo, const unsigned* tmask_hi, const unsigned* fmask,
@@ -260,7 +272,19 @@ int avs_mask_plan(const int* seqs, int nseq, const unsigned* tmask_lo, const uns
 int avs_mask_plan_dev(const int* seqs, int nseq, const unsigned* tmask_lo, const unsigned* tmask_hi, const unsigned* fmask,
                       const unsigned long long* seed_dev, int* row_src, int* row_tok, int* src_row, float* mask_out, int* ids_out,
                       avs_stream_t stream);
+/* GROUPED decoder layout: for the sequences whose descriptor has dec_m_off >= 0 the decoder rows of a sample are ordered [tokens whose
+ * prediction is scored (mask 1) | kept tokens] instead of by position (forward_decoder's un-shuffle is a permutation of tokens that the
+ * attention blocks are equivariant to, cav_mae_base.py:604-626): src_row[dec row] = encoder row | -1 with dec row = dec_k_off + j (kept) |
+ * dec_m_off + j - keep (masked); pos_row[dec row] = pos_base + token (the positional embedding it takes); row_of_pos[dec_off + token] =
+ * dec row; pred_id[pred_off + j - keep] = mask_off + token (the (sample, token) a compact prediction row scores).  seed_dev may be NULL. */
+int avs_mask_plan_grouped(const int* seqs, int nseq, const unsigned* tmask_lo, const unsigned* tmask_hi, const unsigned* fmask,
+                          unsigned long long seed, const unsigned long long* seed_dev, int* row_src, int* row_tok, int* src_row,
+                          float* mask_out, int* ids_out, int* pos_row, int* row_of_pos, int* pred_id, avs_stream_t stream);
 int avs_cast_scale_bf16(const float* x, avs_bf16* y, long long n, float alpha, avs_stream_t stream);
+/* out[r, 0:cols] = src_row[r] >= 0 ? in[src_row[r], 0:cols] : 0 (bf16, cols % 8 == 0, leading dimensions in elements, % 8 == 0).
+ * in == NULL: only the rows with src_row[r] < 0 are written (zeroed).  No reference counterpart: bookkeeping of the pruned last decoder block */
+int avs_expand_rows_bf16(const avs_bf16* in, long long ld_in, const int* src_row, avs_bf16* out, long long ld_out, int rows, int cols,
+                         avs_stream_t stream);
 int avs_scatter_add_rows(const avs_bf16* src, const int* idx, float* dst, int rows, int D, float scale, avs_stream_t stream);
 /* out[c] += sum over rows of x[r][c], c < C (C % 64 == 0); ld: leading dimension of x (a column range of a wider matrix is allowed) */
 int avs_colsum_bf16(const avs_bf16* x, long long ld, float* out, int rows, int C, avs_stream_t stream);
@@ -274,6 +298,9 @@ int avs_unshuffle_fwd(const float* x, const int* src_row, const int* pos_row, co
                       const float* mod_v, float* out, int rows, int D, avs_stream_t stream);
 int avs_unshuffle_bwd(const float* dout, const int* src_row, int B, int T, int La, int Lv, float* dx, float* dpos_a,
                       float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D, avs_stream_t stream);
+/* the same when the decoder rows are not in position order (avs_mask_plan_grouped): row_of_pos[b * (La + T * Lv) + position] = decoder row */
+int avs_unshuffle_bwd_map(const float* dout, const int* src_row, int B, int T, int La, int Lv, float* dx, float* dpos_a,
+                          float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D, const int* row_of_pos, avs_stream_t stream);
 
 /* ---- token mean per packed sequence (.mean(dim=1), cav_mae_base.py:563,566).  row_map (may be NULL): segment s is row row_map[s]
  * of reps / dreps - the mixed encoder's inverse permutation (:584-590) folded into the reduction */
@@ -305,6 +332,14 @@ int avs_mae_loss_fwd_s(const float* pred, const void* inp, const float* mask, fl
                        avs_stream_t stream);
 int avs_mae_loss_bwd_s(const float* pred, const void* inp, const float* mask, const float* gout, avs_bf16* dpred, int rows, int audio,
                        int L, int C, int H, int W, float nmask, int stride, const avs_input_xf* xf, avs_stream_t stream);
+/* the same two on COMPACT predictions: only the rows whose mask is 1 exist; prediction row r scores (sample, token) row_id[r] - id_base of
+ * the [N * L] numbering mask and targets use (row_id: avs_mask_plan_grouped's pred_id; NULL = the two entry points above) */
+int avs_mae_loss_fwd_id(const float* pred, const void* inp, const float* mask, float* row_loss, float* loss, float* total,
+                        int total_init, int rows, int audio, int L, int C, int H, int W, float nmask, int stride, const avs_input_xf* xf,
+                        const int* row_id, int id_base, avs_stream_t stream);
+int avs_mae_loss_bwd_id(const float* pred, const void* inp, const float* mask, const float* gout, avs_bf16* dpred, int rows, int audio,
+                        int L, int C, int H, int W, float nmask, int stride, const avs_input_xf* xf, const int* row_id, int id_base,
+                        avs_stream_t stream);
 
 
 /* ---- bidirectional InfoNCE (forward_contrastive, cav_mae_base.py:641-661) */
