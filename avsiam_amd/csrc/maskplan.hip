@@ -16,7 +16,7 @@
 // [tokens whose prediction is scored (mask 1) | kept tokens] instead of by position, so that the rows the LAST decoder block and the
 // prediction heads still have to compute (cav_mae_base.py:629-635,679-682: loss * mask) are the first rows of every sequence:
 //   src_row[dec row]               = enc_base + j | -1             dec row = dec_k_off + j (kept, j < keep) | dec_m_off + j - keep (masked)
-//   pos_row[dec row]               = pos_base + token              position of the row's token in the sample: which positional embedding it takes
+//   pos_row[dec row]               = pos_base + token              which row of the positional table [pos_a ; pos_v] the row's token takes
 //   row_of_pos[dec_off + token]    = dec row                       the inverse (un-shuffle backward walks the positions)
 //   pred_id[pred_off + j - keep]   = mask_off + token              which (sample, token) a compact prediction row scores
 #include "common.h"
@@ -36,7 +36,7 @@ struct PlanSeq {        // one sequence to draw (int32 x 16, filled by the host)
     int dec_m_off;      // grouped decoder layout: decoder row of this sequence's first MASKED token, -1 = the classic (position-ordered) layout
     int dec_k_off;      //   decoder row of its first KEPT token
     int pred_off;       //   compact prediction row of its first masked token
-    int pos_base;       //   position of its token 0 inside the sample (audio: 0; frame t: La + t * Lv)
+    int pos_base;       //   row of the decoder's positional table [pos_a ; pos_v] its token 0 takes (audio: 0; every frame: La - the frames share pos_v)
 };
 
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }

@@ -277,12 +277,17 @@ class _Inline:
 class Stack:
     """`nblocks` transformer blocks over a packed [rows, D] fp32 residual stream with saved activations."""
 
-    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None, inference=False, pool=None, opts=None):
+    def __init__(self, dev, rows, D, H, hidden, seq_lens, nblocks, row_mod=None, inference=False, pool=None, opts=None, q_rows=0):
         """inference=True: forward only - no activation is kept, every block reuses one set of buffers (the residual stream
         ping-pongs between two) and the backward scratch is not allocated.
         pool (BufferPool): the stack's per-token buffers come from the model's shared activation pool instead of torch.zeros.
         opts (config.EngineOptions): the MODEL's options object, shared by reference - structural fields are read here, runtime fields
-        (wgrad_stream, wgrad_group, deterministic) on every backward."""
+        (wgrad_stream, wgrad_group, deterministic) on every backward.
+        q_rows > 0 (the decoder, EngineOptions.prune_dead): only the first q_rows rows of every (equal-length) sequence leave the LAST block - the rows
+        whose prediction is scored; the others are needed there as keys / values only (cav_mae_base.py:629-635,679-682: loss * mask).  The last
+        block then computes LayerNorm-1 and qkv for all rows, attention for q_rows queries per sequence against all keys, and proj / LayerNorm-2 /
+        MLP on the COMPACT rows [nseq * q_rows] (sequence s owns rows s * q_rows ..): its att / xmid / ln2 / fc1 / act buffers, x[nblocks] and the
+        gradient the backward starts from (dxb[0]) are compact.  `self.lq` says whether the form applies (else 0: plain stack)."""
         assert sum(seq_lens) == rows
         assert pool is None or not inference
         self.pool = pool
@@ -406,6 +411,26 @@ class Stack:
         self.dqkv = _z((rp, 3 * D), BF16, dev)
         self.delta = _z((H, rp), F32, dev)
         self.lnws = _z((ops.layernorm_ws(rows, D),), F32, dev)
+        # ---- pruned last block (q_rows): applies to bf16 stacks of equal-length sequences with plain norms, the bf16 gradient stream and the
+        # two-kernel attention backward (the decoder: 2 472-token sequences)
+        self.lq = 0
+        if (q_rows and not self.fp8 and row_mod is None and opts.grad_stream == "bf16" and self.tiles.uniform_len and self.tiles_bwd.uniform_len
+                and not self.fused_bwd and 0 < q_rows < seq_lens[0] and nblocks >= 1):
+            L, nseq = seq_lens[0], len(seq_lens)
+            self.lq, self.Mq = int(q_rows), nseq * int(q_rows)
+            c = torch.arange(self.Mq)
+            self.q_full = ((c // q_rows) * L + c % q_rows).to(I32).to(dev)                       # compact row -> packed row (residual gather of proj)
+            r = torch.arange(rows)
+            self.q_compact = torch.where(r % L < q_rows, (r // L) * q_rows + r % L, torch.full_like(r, -1)).to(I32).to(dev)     # packed row -> compact row | -1
+            # rows [Mq, next multiple of 128) of the compact activations are read by the weight-gradient GEMMs (whole 64-row stages): they must be
+            # zero whatever another block (shared recompute buffers) or another pass (pooled memory) left there
+            self._qpads = ops.ZeroTable()
+            last = nblocks - 1
+            padq = ops.pad_rows(self.Mq, 128)
+            if padq > self.Mq:
+                for buf in (self.att[last], self.ln2[last], self.act[last]):
+                    self._qpads.add(buf[self.Mq:padq])
+                self._qpads.build(dev)
 
     @property
     def out(self):
@@ -462,6 +487,21 @@ class Stack:
         n2 = bp.n2 if b2 is None else [bp.n2[0], b2.n2[0]]
         if self.fp8:
             return self._block_forward_fp8(i, bp, b2, split, last_gemm, n1, n2)
+        if self.lq and i == self.nblocks - 1:
+            # pruned last block (see __init__): every row is a key / value, the first lq rows of a sequence are the queries; from the attention
+            # output on the block lives on the compact rows
+            assert b2 is None
+            Mq = self.Mq
+            self._qpads.run()
+            _ln_fwd(x, n1, self.ln1[i], st[0], st[1], M, LN_EPS_BLOCK, None)
+            ops.gemm_nt(self.ln1[i], bp.qkv.w, self.qkv[i], M, bias=bp.qkv.b, scale_cols=self.D, col_scale=self.q_scale)
+            ops.attn_fwd(self.qkv[i], self.tiles, self.H, self.att[i], self.lse[i], lq=self.lq)
+            ops.gemm_nt(self.att[i], bp.proj.w, self.xmid[i], Mq, bias=bp.proj.b, res=x, res_idx=self.q_full)
+            _ln_fwd(self.xmid[i], n2, self.ln2[i], st[2], st[3], Mq, LN_EPS_BLOCK, None)
+            ops.gemm_nt(self.ln2[i], bp.fc1.w, self.fc1[i], Mq, bias=bp.fc1.b, out2=self.act[i], act=1)
+            if last_gemm:
+                ops.gemm_nt(self.act[i], bp.fc2.w, self.x[i + 1], Mq, bias=bp.fc2.b, res=self.xmid[i])
+            return
         dq = dp = d1 = d2 = None
         if b2 is not None:
             dq, dp = (split, b2.qkv.w, b2.qkv.b, None), (split, b2.proj.w, b2.proj.b, None)
@@ -626,9 +666,10 @@ class Stack:
                         for a, b in bl[j].ranges:
                             reducer.ready(a, b)
 
-        def wgrads(blk, key, *jobs):
+        def wgrads(blk, key, *jobs, rows=None):
+            """rows: the jobs' token rows when they are not the stack's (the pruned last block's compact rows)"""
             def fn():      # the jobs of one call share their token rows: one grouped launch per row range (ops.gemm_tn_group)
-                for lo, hi, bl in ranges:
+                for lo, hi, bl in (ranges if rows is None else [(0, rows, blocks)]):
                     if self.fp8_wgrad:
                         # fp8 mode 3: the e5m2 copy of the gradient (written by its producer or by the input-gradient GEMM's quantising
                         # pass just before) x the block's e4m3 copy of the layer input, with the two operands' device records
@@ -671,6 +712,9 @@ class Stack:
         for i in reversed(range(self.nblocks)):
             bp, st = blocks[i], self.stats[i]
             b2 = blocks2[i] if blocks2 is not None else None
+            pruned = bool(self.lq) and i == self.nblocks - 1        # the block's upper half (proj ... fc2) lives on the compact rows [0, Mq)
+            Mu = self.Mq if pruned else M
+            assert not pruned or (blocks2 is None and g16 and not f8b)
             if i < self.nrecomp:
                 if not isinstance(side, _Inline):      # from here down the blocks share one set of activation buffers: one stream
                     side.join()
@@ -691,22 +735,22 @@ class Stack:
                 self._dgrad_fp8(i, "dbo", "fc2", dbo, self.dx8[0], bp.fc2, b2.fc2 if b2 else None, split, None if self.fp8_lean and o8 is not None else self.dfc1, act=2, aux=self.fc1[i],
                                 colsum=bp.fc1.gb, colsum2=b2.fc1.gb if b2 else None, **({"out8": o8, "q8": r8_} if o8 is not None else {}))
             else:
-                ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, M, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,                # + fc1 bias gradient
+                ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, Mu, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,               # + fc1 bias gradient
                             dual=(split, b2.fc2.wt, None, b2.fc1.gb) if b2 is not None else None)
             if not grp:
-                wgrads(i, "dbo", (dbo, self.act[i], "fc2"))
+                wgrads(i, "dbo", (dbo, self.act[i], "fc2"), rows=Mu if pruned else None)
             if i == self.nblocks - 1 and not last_fc2_bias_done:
-                for lo, hi, bl in ranges:
+                for lo, hi, bl in (ranges if not pruned else [(0, Mu, blocks)]):
                     ops.colsum(dbo[lo:], bl[i].fc2.gb, hi - lo)
             # fc1
             if f8b:
                 self._dgrad_fp8(i, "dfc1", "fc1", self.dfc1, self.dfc1_8, bp.fc1, b2.fc1 if b2 else None, split, self.dln)
             else:
-                ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, M, dual=(split, b2.fc1.wt, None, None) if b2 is not None else None)
+                ops.gemm_nt(self.dfc1, bp.fc1.wt, self.dln, Mu, dual=(split, b2.fc1.wt, None, None) if b2 is not None else None)
             if not grp:
-                wgrads(i, "dfc1", (self.dfc1, self.ln2[i], "fc1"))
+                wgrads(i, "dfc1", (self.dfc1, self.ln2[i], "fc1"), rows=Mu if pruned else None)
                 side.before_write("dbm")
-            for lo, hi, bl in ranges:
+            for lo, hi, bl in (ranges if not pruned else [(0, Mu, blocks)]):
                 if accumulate:            # value third of the qkv bias gradient, below: minus what proj.gb holds before this block adds to it
                     ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * self.D:], -1.0)
                 d8, q8_ = g8rec(i, "dbm")
@@ -717,11 +761,11 @@ class Stack:
             if f8b:
                 self._dgrad_fp8(i, "dbm", "proj", dbm, self.dx8[1], bp.proj, b2.proj if b2 else None, split, self.datt)
             else:
-                ops.gemm_nt(dbm, bp.proj.wt, self.datt, M, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
+                ops.gemm_nt(dbm, bp.proj.wt, self.datt, Mu, dual=(split, b2.proj.wt, None, None) if b2 is not None else None)
             if grp:                   # the three wgrads whose operands exist now run beside the attention backward
-                wgrads(i, "blockA", (dbo, self.act[i], "fc2"), (self.dfc1, self.ln2[i], "fc1"), (dbm, self.att[i], "proj"))
+                wgrads(i, "blockA", (dbo, self.act[i], "fc2"), (self.dfc1, self.ln2[i], "fc1"), (dbm, self.att[i], "proj"), rows=Mu if pruned else None)
             else:
-                wgrads(i, "dbm", (dbm, self.att[i], "proj"))
+                wgrads(i, "dbm", (dbm, self.att[i], "proj"), rows=Mu if pruned else None)
                 side.before_write("dqkv")
             a8 = {}
             if f8b:                                # the attention backward kernels write the e5m2 copy of dqkv themselves once its record is calibrated
@@ -729,7 +773,14 @@ class Stack:
                 if d8 is not None:
                     # (lean mode 3: the qkv input- and weight-gradient GEMMs read the e5m2 copy; of the bf16 dqkv only the query third has a reader)
                     a8 = {"dqkv8": d8, "q8": q8_, "kv_bf16": not self.fp8_lean}
-            if self.tiles_bwd.ntiles:
+            if pruned:
+                # queries: the first lq rows of every sequence (out / dO compact); dk, dv for every row.  The query third of the other rows of dqkv
+                # is zero by definition (they asked nothing), and the residual gradient of the compact rows goes back into the packed numbering
+                # for LayerNorm-1's backward - zeros for the rows that were keys / values only - through the freed dO buffer
+                ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv, lq=self.lq)
+                ops.expand_rows(None, self.q_compact, self.dqkv, M, cols=self.D)
+                ops.expand_rows(dbm, self.q_compact, self.datt, M)
+            elif self.tiles_bwd.ntiles:
                 ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv, **a8)
             for sq in self.fused_bwd:
                 ops.attn_bwd_fused(self.qkv[i], sq, self.H, self.att[i], self.datt, self.lse[i], self.dqkv, **a8)
@@ -754,7 +805,7 @@ class Stack:
                 ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * D:])
                 d8, q8_ = g8rec(i - 1, "dbo")          # the block below reads this gradient through its fc2 input-gradient GEMM
                 _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, None if g16 and i > 0 else dxo[lo:], self.lnws,
-                        hi - lo, None if one else self.row_mod, dres=(dbm if g16 else dxm)[lo:], dx_bf16=dbo[lo:],
+                        hi - lo, None if one else self.row_mod, dres=(self.datt if pruned else dbm if g16 else dxm)[lo:], dx_bf16=dbo[lo:],
                         dcol=bl[i - 1].fc2.gb if i > 0 else None, dx8=d8[lo:] if d8 is not None else None, q8=q8_)
         side.join()
         for j in reversed(range(self.nblocks)):        # (mode 2 has reported all but block 0 on the way)
@@ -850,12 +901,12 @@ class ContrastivePass:
         off = 0
         for sl in range(batch):
             g = self.slot_group[sl]
-            d[sl] = [La, self.keep_a[g], off, 0, -1, 0, cfg.audio_t, sl * La, 0, 0, 0, 0]
+            d[sl] = [La, self.keep_a[g], off, 0, -1, 0, cfg.audio_t, sl * La, 0, 0, 0, 0] + ops.PLAN_CLASSIC
             off += self.keep_a[g]
         for sl in range(batch):
             g = self.slot_group[sl]
             for t in range(T):
-                d[batch + sl * T + t] = [Lv, self.keep_v[g], off, 0, -1, 0, 0, batch * La + (sl * T + t) * Lv, 0, 0, 0, 0]
+                d[batch + sl * T + t] = [Lv, self.keep_v[g], off, 0, -1, 0, 0, batch * La + (sl * T + t) * Lv, 0, 0, 0, 0] + ops.PLAN_CLASSIC
                 off += self.keep_v[g]
         assert off == rows
         self.desc_host = d
@@ -1065,7 +1116,13 @@ class MaePass:
             self.st_a = Stack(dev, self.rows_a, D, cfg.num_heads, hid, [ka] * B, cfg.depth, pool=pool, opts=opts)
             self.st_v = Stack(dev, self.rows_v, D, cfg.num_heads, hid, [kv] * (B * T), cfg.depth, pool=pool, opts=opts)
         self.st_mm = Stack(dev, B * self.n_enc, D, cfg.num_heads, hid, [self.n_enc] * B, 2, pool=pool, opts=opts)
-        self.st_dec = Stack(dev, B * self.Ltot, Dd, cfg.dec_heads, Dd * cfg.mlp_ratio, [self.Ltot] * B, cfg.dec_depth, pool=pool, opts=opts)
+        # EngineOptions.prune_dead: the decoder's rows are laid out [scored tokens (mask 1) | kept tokens] per sample and the last decoder block, decoder_norm,
+        # the prediction heads and the loss run on the scored rows only (Stack q_rows; exact: unscored rows have zero loss and zero gradient, :679-682)
+        self.ma, self.mv = La - ka, Lv - kv                                       # scored (masked) tokens per audio sequence / frame
+        self.lq = self.ma + T * self.mv
+        self.st_dec = Stack(dev, B * self.Ltot, Dd, cfg.dec_heads, Dd * cfg.mlp_ratio, [self.Ltot] * B, cfg.dec_depth, pool=pool, opts=opts,
+                            q_rows=self.lq if opts.prune_dead else 0)
+        self.prune = self.st_dec.lq > 0
         self.blk_a = [BlockParams(arena, f"ast_base.blocks.{i}", "") for i in range(cfg.depth)]      # :489
         self.blk_v = [BlockParams(arena, f"vit_base.blocks.{i}", "_v") for i in range(cfg.depth)]   # :487
         self.blk_mm = [BlockParams(arena, "mm_layer_1", "_a"), BlockParams(arena, "mm_layer_2", "_a")]   # :699-700
@@ -1091,24 +1148,42 @@ class MaePass:
         self.de = _z((rj, Dd), F32, dev)                      # decoder_embed output
         self.dde = _z((rj, Dd), F32, dev)
         self.dde_b = _z((rj, Dd), BF16, dev)
-        # un-shuffle index arrays (src_row depends on the plan; pos/modality are static)
+        # un-shuffle index arrays (src_row depends on the plan; pos/modality are static in the position-ordered layout)
         rows_d = B * self.Ltot
         self.src_row = _z((rows_d,), I32, dev)
-        pos = torch.cat([torch.arange(La), La + torch.arange(Lv).repeat(T)]).repeat(B)
-        self.pos_row = pos.to(I32).to(dev)
-        self.dmod = torch.cat([torch.zeros(La, dtype=U8), torch.ones(T * Lv, dtype=U8)]).repeat(B).to(dev)
-        # decoder_norm output, modality-major: [B*La audio rows | pad | B*T*Lv video rows | pad]
-        self.na_rows, self.nv_rows = B * La, B * T * Lv
-        self.v_off = ops.pad_rows(self.na_rows, 128)
-        l = torch.arange(self.Ltot).view(1, -1)
-        bb = torch.arange(B).view(B, 1)
-        omap = torch.where(l < La, bb * La + l, self.v_off + bb * (T * Lv) + (l - La))
+        P = cfg.patch * cfg.patch
+        ma, mv, lq = self.ma, self.mv, self.lq
+        if not self.prune:
+            pos = torch.cat([torch.arange(La), La + torch.arange(Lv).repeat(T)]).repeat(B)
+            self.pos_row = pos.to(I32).to(dev)
+            self.dmod = torch.cat([torch.zeros(La, dtype=U8), torch.ones(T * Lv, dtype=U8)]).repeat(B).to(dev)
+            # decoder_norm output, modality-major: [B*La audio rows | pad | B*T*Lv video rows | pad]
+            self.na_rows, self.nv_rows = B * La, B * T * Lv
+            self.dn_rows_in = rows_d
+            l = torch.arange(self.Ltot).view(1, -1)
+            bb = torch.arange(B).view(B, 1)
+            self.v_off = ops.pad_rows(self.na_rows, 128)
+            omap = torch.where(l < La, bb * La + l, self.v_off + bb * (T * Lv) + (l - La))
+            self.row_of_pos = self.pred_id = None
+        else:
+            # grouped layout of a sample's Ltot decoder rows: [scored audio (ma) | scored frame 0 .. T-1 (mv each) | kept audio (ka) | kept frames (kv each)];
+            # WHICH token sits in a row comes from the plan (pos_row / row_of_pos / pred_id: csrc/maskplan.hip), the modality of a row is static
+            self.pos_row = _z((rows_d,), I32, dev)
+            self.row_of_pos = _z((rows_d,), I32, dev)
+            self.pred_id = _z((B * ma + B * T * mv,), I32, dev)
+            self.dmod = torch.cat([torch.zeros(ma, dtype=U8), torch.ones(T * mv, dtype=U8), torch.zeros(ka, dtype=U8), torch.ones(T * kv, dtype=U8)]).repeat(B).to(dev)
+            # decoder_norm runs on the COMPACT rows the last block leaves (sample b: rows b * lq ..) -> modality-major compact predictions
+            self.na_rows, self.nv_rows = B * ma, B * T * mv
+            self.dn_rows_in = B * lq
+            j = torch.arange(lq).view(1, -1)
+            bb = torch.arange(B).view(B, 1)
+            self.v_off = ops.pad_rows(self.na_rows, 128)
+            omap = torch.where(j < ma, bb * ma + j, self.v_off + bb * (T * mv) + (j - ma))
         self.dn_map = omap.reshape(-1).to(I32).to(dev)
         dn_rows = self.v_off + ops.pad_rows(self.nv_rows, 128)
         self.dn = _z((dn_rows, Dd), BF16, dev)
         self.ddn = _z((dn_rows, Dd), BF16, dev)
         self.dn_stat = [_z((self.st_dec.rp,), F32, dev) for _ in range(2)]
-        P = cfg.patch * cfg.patch
         self.p_a = _z((ops.pad_rows(self.na_rows), P), F32, dev)
         self.p_v = _z((ops.pad_rows(self.nv_rows), P * cfg.in_chans), F32, dev)
         self.dp_a = _z((ops.pad_rows(self.na_rows), P), BF16, dev)
@@ -1119,16 +1194,21 @@ class MaePass:
         # device-side plan: every descriptor field is static for this pass (75 % unstructured on all sequences)
         nseq = B + B * T
         d = np.zeros((nseq, ops.PLAN_FIELDS), dtype=np.int32)
+        Lt = self.Ltot
         for b in range(B):
-            d[b] = [La, ka, b * ka, b, b * self.Ltot, b * self.n_enc, 0, b * La, b * La, 0, 0, 0]
+            g = [b * Lt, b * Lt + lq, b * ma, 0] if self.prune else ops.PLAN_CLASSIC       # dec_m_off, dec_k_off, pred_off, pos_base (csrc/maskplan.hip)
+            d[b] = [La, ka, b * ka, b, b * Lt, b * self.n_enc, 0, b * La, b * La, 0, 0, 0] + g
             for t in range(T):
                 i = b * T + t
-                d[B + i] = [Lv, kv, self.rows_a + i * kv, i, b * self.Ltot + La + t * Lv, b * self.n_enc + ka + t * kv, 0,
-                            B * La + i * Lv, B * La + i * Lv, 0, 0, 0]
+                # (pos_base La for every frame: the frames share ONE positional table, decoder_pos_embed_v - as `pos` of the classic layout above)
+                g = [b * Lt + ma + t * mv, b * Lt + lq + ka + t * kv, B * ma + i * mv, La] if self.prune else ops.PLAN_CLASSIC
+                d[B + i] = [Lv, kv, self.rows_a + i * kv, i, b * Lt + La + t * Lv, b * self.n_enc + ka + t * kv, 0,
+                            B * La + i * Lv, B * La + i * Lv, 0, 0, 0] + g
         self.desc_host = d
         self.desc_dev = torch.from_numpy(d).to(dev)
         self.ids_dev = _z((B * La + B * T * Lv,), I32, dev)
         self.rl_a, self.rl_v = _z((self.na_rows,), F32, dev), _z((self.nv_rows,), F32, dev)
+        self.pid_a, self.pid_v = (self.pred_id[:B * ma], self.pred_id[B * ma:]) if self.prune else (None, None)
         self.losses = _z((3,), F32, dev)                       # loss_a, loss_v, loss_mae
         self.nmask_a = float(B * (La - ka))
         self.nmask_v = float(B * T * (Lv - kv))
@@ -1149,15 +1229,42 @@ class MaePass:
         src_a = torch.where(ra < ka, b * self.n_enc + ra, torch.full_like(ra, -1))
         t = torch.arange(T).view(1, T, 1)
         src_v = torch.where(rv < kv, b.view(B, 1, 1) * self.n_enc + ka + t * kv + rv, torch.full_like(rv, -1))
-        src = torch.cat([src_a, src_v.reshape(B, T * Lv)], dim=1).reshape(-1).to(I32)
-        self.src_row.copy_(src, non_blocking=True)
+        src = torch.cat([src_a, src_v.reshape(B, T * Lv)], dim=1).reshape(-1).to(I32)            # indexed by POSITION (b, l)
+        if self.prune:
+            # the grouped decoder layout from an injected plan - what the plan kernel writes on the device (csrc/maskplan.hip): the rank of a token
+            # in its sequence's shuffle decides its decoder row
+            Lt, ma, mv, lq = self.Ltot, self.ma, self.mv, self.lq
+            bL = b * Lt
+            row_a = torch.where(ra < ka, bL + lq + ra, bL + (ra - ka))                                                        # [B, La]
+            row_v = torch.where(rv < kv, bL.view(B, 1, 1) + lq + ka + t * kv + rv, bL.view(B, 1, 1) + ma + t * mv + (rv - kv))    # [B, T, Lv]
+            rop = torch.cat([row_a, row_v.reshape(B, T * Lv)], dim=1).reshape(-1)                                             # position -> decoder row
+            pos = torch.cat([torch.arange(La), La + torch.arange(Lv).repeat(T)]).repeat(B)      # which positional row a position takes (frames share one table)
+            src_d = torch.empty_like(src)
+            src_d[rop] = src
+            pos_d = torch.empty(B * Lt, dtype=torch.int64)
+            pos_d[rop] = pos
+            pid = torch.empty(B * ma + B * T * mv, dtype=torch.int64)
+            tok_a = torch.arange(La).view(1, La).expand(B, La)
+            sel = ra >= ka
+            pid[(b * ma + (ra - ka))[sel]] = (b * La + tok_a)[sel]
+            it = (b.view(B, 1, 1) * T + t)                                                                                   # frame image index [B, T, 1]
+            tok_v = torch.arange(Lv).view(1, 1, Lv).expand(B, T, Lv)
+            selv = rv >= kv
+            pid[(B * ma + it * mv + (rv - kv))[selv]] = (B * La + it * Lv + tok_v)[selv]
+            self.src_row.copy_(src_d, non_blocking=True)
+            self.pos_row.copy_(pos_d.to(I32), non_blocking=True)
+            self.row_of_pos.copy_(rop.to(I32), non_blocking=True)
+            self.pred_id.copy_(pid.to(I32), non_blocking=True)
+        else:
+            self.src_row.copy_(src, non_blocking=True)
         self.mask_a.copy_((ra >= ka).float(), non_blocking=True)                         # :385-388
         self.mask_v.copy_((rv >= kv).float().reshape(B, T * Lv), non_blocking=True)
 
     def draw_device(self, seed, nprng=None, seed_dev=None, host=True):
         """75 % unstructured masks of every audio / video sequence, drawn on the device (one launch; no host part)."""
         ops.mask_plan(self.desc_dev, self.desc_host, seed, self.row_src_all, self.row_tok_all, src_row=self.src_row,
-                      mask_out=self.mask_all, ids_out=self.ids_dev, seed_dev=seed_dev)
+                      mask_out=self.mask_all, ids_out=self.ids_dev, seed_dev=seed_dev,
+                      grouped=(self.pos_row, self.row_of_pos, self.pred_id) if self.prune else None)
 
     def draw_host(self, nprng=None):
         pass
@@ -1206,22 +1313,40 @@ class MaePass:
                           self.tok["decoder_pos_embed_v"], self.tok["decoder_modality_a"], self.tok["decoder_modality_v"],
                           self.st_dec.x[0], rows_d)
         self.st_dec.forward(self.blk_dec)
-        _ln_fwd(self.st_dec.out, self.dec_norm, self.dn, self.dn_stat[0], self.dn_stat[1], rows_d, LN_EPS_BLOCK, out_map=self.dn_map)
+        # (prune: st_dec.out holds the scored rows only, compact; decoder_norm, the heads and the loss see nothing else)
+        _ln_fwd(self.st_dec.out, self.dec_norm, self.dn, self.dn_stat[0], self.dn_stat[1], self.dn_rows_in, LN_EPS_BLOCK, out_map=self.dn_map)
         ops.gemm_nt(self.dn[:self.v_off], self.pred_a.w, self.p_a, self.na_rows, bias=self.pred_a.b)       # :634
         ops.gemm_nt(self.dn[self.v_off:], self.pred_v.w, self.p_v, self.nv_rows, bias=self.pred_v.b)       # :635
         ops.mae_loss_fwd(self.p_a, audio, self.mask_a.view(-1), self.rl_a, self.losses[0:1], True, La, self.nmask_a,
-                         total=self.losses[2:3], total_init=True, xf=xf[0], stride=cfg.st)
+                         total=self.losses[2:3], total_init=True, xf=xf[0], stride=cfg.st, row_id=self.pid_a, id_base=0)
         ops.mae_loss_fwd(self.p_v, self.imgs, self.mask_v.view(-1), self.rl_v, self.losses[1:2], False, Lv, self.nmask_v,
-                         total=self.losses[2:3], total_init=False, xf=xf[1], stride=cfg.st)               # loss_mae = a + v (:707)
+                         total=self.losses[2:3], total_init=False, xf=xf[1], stride=cfg.st, row_id=self.pid_v, id_base=B * La)    # loss_mae = a + v (:707)
         return self.losses[2:3], self.losses[0:1], self.losses[1:2], self.mask_a, self.mask_v
+
+    def predictions(self):
+        """(pred_a [B, La, P], pred_v [B, T * Lv, P * C]) of the last forward, in the reference's layout (cav_mae_base.py:634-635).  With
+        EngineOptions.prune_dead only the scored rows (mask 1) were computed: the others read NaN.  Tests / debugging (synchronises)."""
+        cfg, B, T = self.cfg, self.B, self.cfg.frames
+        La, Lv = cfg.audio_tokens, cfg.video_tokens
+        pa, pv = self.p_a[:self.na_rows].float().cpu(), self.p_v[:self.nv_rows].float().cpu()
+        if not self.prune:
+            return pa.view(B, La, -1), pv.view(B, T * Lv, -1)
+        ida, idv = self.pid_a.cpu().long(), self.pid_v.cpu().long() - B * La
+        fa = torch.full((B * La, pa.shape[1]), float("nan"))
+        fv = torch.full((B * T * Lv, pv.shape[1]), float("nan"))
+        fa[ida] = pa
+        fv[idv] = pv
+        return fa.view(B, La, -1), fv.view(B, T * Lv, -1)
 
     def backward(self, gout, reducer=None, accumulate=False):
         cfg, B, T = self.cfg, self.B, self.cfg.frames
         if self.pool is not None and self.pool.owner is not self:
             raise RuntimeError("shared activation pool: another pass ran its forward since this one's - its activations are gone")
         La, Lv, D, Dd = cfg.audio_tokens, cfg.video_tokens, cfg.embed_dim, cfg.dec_dim
-        ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a, xf=self.xf[0], stride=cfg.st)
-        ops.mae_loss_bwd(self.p_v, self.imgs, self.mask_v.view(-1), gout, self.dp_v, False, Lv, self.nmask_v, xf=self.xf[1], stride=cfg.st)
+        ops.mae_loss_bwd(self.p_a, self.audio, self.mask_a.view(-1), gout, self.dp_a, True, La, self.nmask_a, xf=self.xf[0], stride=cfg.st,
+                         row_id=self.pid_a, id_base=0)
+        ops.mae_loss_bwd(self.p_v, self.imgs, self.mask_v.view(-1), gout, self.dp_v, False, Lv, self.nmask_v, xf=self.xf[1], stride=cfg.st,
+                         row_id=self.pid_v, id_base=B * La)
         # prediction heads
         ops.gemm_nt(self.dp_a, self.pred_a.wt, self.ddn[:self.v_off], self.na_rows)
         ops.gemm_tn(self.dp_a, self.dn[:self.v_off], self.pred_a.gw, self.na_rows)
@@ -1231,12 +1356,12 @@ class MaePass:
         ops.colsum(self.dp_v, self.pred_v.gb, self.nv_rows)
         sd = self.st_dec
         rows_d = B * self.Ltot
-        _ln_bwd(self.ddn, sd.out, self.dn_stat[0], self.dn_stat[1], self.dec_norm, _dx_in(sd), sd.lnws, rows_d,
+        _ln_bwd(self.ddn, sd.out, self.dn_stat[0], self.dn_stat[1], self.dec_norm, _dx_in(sd), sd.lnws, self.dn_rows_in,
                 out_map=self.dn_map, dx_bf16=sd.dxb[0], dcol=self.blk_dec[-1].fc2.gb)
         sd.backward(self.blk_dec, last_fc2_bias_done=True, reducer=reducer, accumulate=accumulate)
         g = self.gtok
         ops.unshuffle_bwd(sd.dx[0], self.src_row, B, T, La, Lv, self.dde, g["decoder_pos_embed_a"], g["decoder_pos_embed_v"],
-                          g["mask_token"], g["decoder_modality_a"], g["decoder_modality_v"])
+                          g["mask_token"], g["decoder_modality_a"], g["decoder_modality_v"], row_of_pos=self.row_of_pos)
         rows_j = B * self.n_enc
         ops.cast_scale(self.dde, self.dde_b, rows_j * Dd, 1.0)
         sm = self.st_mm

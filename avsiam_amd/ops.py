@@ -460,6 +460,8 @@ class AttnTiles:
         self.q0 = torch.tensor(q0s, dtype=I32, device=device)
         self.max_row = row
         self.sum_sq = float(sum(L * L for L in taken))           # sum of L^2: attention FLOPs = 4 * sum_sq * D
+        # the common length when every sequence has it and all of them have tiles (the pruned last decoder block needs both), else 0
+        self.uniform_len = seq_lens[0] if (len(seq_lens) and all(L == seq_lens[0] for L in seq_lens) and len(taken) == len(seq_lens) and start_row == 0) else 0
 
 
 def attn_q_scale(hd):
@@ -467,8 +469,21 @@ def attn_q_scale(hd):
     return hd ** -0.5 * 1.4426950408889634
 
 
-def attn_fwd(qkv, tiles, H, out, lse, out8=None, q8=None):
-    """out8 / q8 (fp8 mode): also write the e4m3 copy of the output for the proj GEMM, scaled by the device record q8"""
+def attn_fwd(qkv, tiles, H, out, lse, out8=None, q8=None, lq=0):
+    """out8 / q8 (fp8 mode): also write the e4m3 copy of the output for the proj GEMM, scaled by the device record q8.
+    lq > 0 (equal-length sequences; avs_attn_fwd_cq): only the first lq rows of every sequence are queries, `out` is compact
+    (sequence s owns rows s * lq ..) - the decoder's last block in the pruned form (engine.Stack)."""
+    if lq:
+        assert out8 is None and tiles.uniform_len and 0 < lq <= tiles.uniform_len
+        _chk(qkv, BF16, "attn.qkv", 2); _chk(out, BF16, "attn.out", 2); _chk(lse, F32, "attn.lse", 2)
+        D = qkv.shape[1] // 3
+        nseq = tiles.max_row // tiles.uniform_len
+        assert qkv.shape[1] == 3 * D and out.shape[1] == D and D % H == 0 and D // H in (32, 64, 80)
+        assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= nseq * lq and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
+        frac = lq / tiles.uniform_len
+        _launch("attn_fwd_hd%d" % (D // H), (4.0 * tiles.sum_sq * frac * D, tiles.rows * ((4.0 + 4.0 * frac) * D + 4.0 * H * frac)), "avs_attn_fwd_cq", qkv, qkv.stride(0), D, H,
+                tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, out.stride(0), lse, lse.shape[1], int(lq), _stream())
+        return
     _chk(qkv, BF16, "attn.qkv", 2); _chk(out, BF16, "attn.out", 2); _chk(lse, F32, "attn.lse", 2); _chk(out8, U8, "attn.out8", 2)
     assert (out8 is None) == (q8 is None) and (out8 is None or (out8.shape[0] >= tiles.max_row and out8.shape[1] == out.shape[1]))
     D = qkv.shape[1] // 3
@@ -480,11 +495,24 @@ def attn_fwd(qkv, tiles, H, out, lse, out8=None, q8=None):
             lse, lse.shape[1], out8, out8.stride(0) if out8 is not None else 0, _qrec(q8), _stream())
 
 
-def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None, kv_bf16=True):
+def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None, kv_bf16=True, lq=0):
     """dqkv8 / q8 (fp8 backward): also write the e5m2 copy of dqkv - the gradient operand of the fp8 qkv input-gradient GEMM - scaled by
     the device record q8, whose running amax takes the largest |dqkv| written.  kv_bf16=False (with dqkv8): the key / value thirds of
-    the bf16 dqkv are not written."""
+    the bf16 dqkv are not written.
+    lq > 0 (avs_attn_bwd_cq): the backward of attn_fwd(lq=): out / dout compact, dq written for the first lq rows of every sequence only."""
     assert kv_bf16 or dqkv8 is not None
+    if lq:
+        assert dqkv8 is None and tiles.uniform_len and 0 < lq <= tiles.uniform_len
+        _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2)
+        _chk(lse, F32, "attnb.lse", 2); _chk(delta, F32, "attnb.delta", 2); _chk(dqkv, BF16, "attnb.dqkv", 2)
+        D = qkv.shape[1] // 3
+        nseq = tiles.max_row // tiles.uniform_len
+        assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape and D // H in (32, 64, 80)
+        assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= nseq * lq and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
+        frac = lq / tiles.uniform_len
+        _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * frac * D, tiles.rows * ((16.0 + 8.0 * frac) * D + 16.0 * H * frac)), "avs_attn_bwd_cq", qkv, qkv.stride(0), D, H,
+                tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout, out.stride(0), lse, delta, lse.shape[1], dqkv, int(lq), _stream())
+        return
     _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2); _chk(dqkv8, U8, "attnb.dqkv8", 2)
     assert (dqkv8 is None) == (q8 is None) and (dqkv8 is None or (dqkv8.shape[0] >= tiles.max_row and dqkv8.shape[1] == qkv.shape[1]))
     _chk(lse, F32, "attnb.lse", 2); _chk(delta, F32, "attnb.delta", 2); _chk(dqkv, BF16, "attnb.dqkv", 2)
@@ -579,14 +607,17 @@ def im2col_video(v, row_img, row_tok, out, rows, xf=None, stride=16):
     _call("avs_im2col_video_s", v, row_img, row_tok, out, rows, C, H, W, int(stride), _xf_arg(xf, 2), _stream())
 
 
-PLAN_FIELDS = 12      # int32 per sequence descriptor of avs_mask_plan
+PLAN_FIELDS = 16      # int32 per sequence descriptor of avs_mask_plan (csrc/maskplan.hip PlanSeq; fields 12..15: the grouped decoder layout)
+PLAN_CLASSIC = [-1, 0, 0, 0]      # fields 12..15 of a sequence in the classic (position-ordered) decoder layout
 
 
 def mask_plan(seqs_dev, seqs_host, seed, row_src, row_tok, tmask_lo=None, tmask_hi=None, fmask=None, src_row=None, mask_out=None,
-              ids_out=None, seed_dev=None):
-    """Draw the random masks of every sequence in `seqs` on the device.  seqs_host (numpy int32 [nseq, 12]) is the host copy
+              ids_out=None, seed_dev=None, grouped=None):
+    """Draw the random masks of every sequence in `seqs` on the device.  seqs_host (numpy int32 [nseq, PLAN_FIELDS]) is the host copy
     of seqs_dev used to validate every offset before the launch.  seed_dev (int64 [1] device tensor): the Philox key is read from it
-    when the kernel runs instead of `seed` (graph_step: kernel arguments are frozen in a captured graph)."""
+    when the kernel runs instead of `seed` (graph_step: kernel arguments are frozen in a captured graph).
+    grouped = (pos_row, row_of_pos, pred_id): the sequences with a decoder part are laid out in the GROUPED decoder order (scored rows of a
+    sample first: csrc/maskplan.hip) and the three extra index arrays are written."""
     _chk(seqs_dev, I32, "plan.seqs", 2); _chk(row_src, I32, "plan.row_src"); _chk(row_tok, I32, "plan.row_tok")
     _chk(src_row, I32, "plan.src_row"); _chk(mask_out, F32, "plan.mask"); _chk(ids_out, I32, "plan.ids")
     for t in (tmask_lo, tmask_hi, fmask):
@@ -609,6 +640,24 @@ def mask_plan(seqs_dev, seqs_host, seed, row_src, row_tok, tmask_lo=None, tmask_
         sel = t_p > 0
         # time patches: 64 bits in tmask_lo / tmask_hi + 32 in the descriptor (field 9, PlanSeq.tmask_x); frequency patches: 32 bits
         assert (t_p[sel] <= 96).all() and (L[sel] % t_p[sel] == 0).all() and (L[sel] // t_p[sel] <= 32).all()
+    dm = seqs_host[:, 12]
+    if grouped is None:
+        assert (dm < 0).all(), "grouped decoder layout in the descriptors but no index arrays for it"
+    else:
+        pos_row, row_of_pos, pred_id = grouped
+        _chk(pos_row, I32, "plan.pos_row"); _chk(row_of_pos, I32, "plan.row_of_pos"); _chk(pred_id, I32, "plan.pred_id")
+        sel = dec_off >= 0
+        assert sel.any() and (dm[sel] >= 0).all() and src_row is not None and mask_out is not None
+        dk, po, pb = seqs_host[:, 13], seqs_host[:, 14], seqs_host[:, 15]
+        nm = L - keep
+        assert (dk[sel] >= 0).all() and (po[sel] >= 0).all() and (pb[sel] >= 0).all()
+        assert int((dm[sel] + nm[sel]).max()) <= min(src_row.numel(), pos_row.numel()) and int((dk[sel] + keep[sel]).max()) <= min(src_row.numel(), pos_row.numel())
+        assert int((dec_off[sel] + L[sel]).max()) <= row_of_pos.numel() and int((po[sel] + nm[sel]).max()) <= pred_id.numel()
+        if seed_dev is not None:
+            assert seed_dev.dtype == torch.int64 and seed_dev.is_cuda and seed_dev.numel() >= 1
+        _call("avs_mask_plan_grouped", seqs_dev, nseq, tmask_lo, tmask_hi, fmask, (int(seed) & 0xFFFFFFFFFFFFFFFF) if seed_dev is None else 0, seed_dev,
+              row_src, row_tok, src_row, mask_out, ids_out, pos_row, row_of_pos, pred_id, _stream())
+        return
     if seed_dev is not None:
         assert seed_dev.dtype == torch.int64 and seed_dev.is_cuda and seed_dev.numel() >= 1
         _call("avs_mask_plan_dev", seqs_dev, nseq, tmask_lo, tmask_hi, fmask, seed_dev, row_src, row_tok, src_row, mask_out, ids_out, _stream())
@@ -659,12 +708,22 @@ def unshuffle_fwd(x, src_row, pos_row, row_mod, mask_token, pos_a, pos_v, mod_a,
               rows, D, _stream())
 
 
-def unshuffle_bwd(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v):
-    _chk(dout, F32, "unshuffleb.dout", 2); _chk(dx, F32, "unshuffleb.dx", 2); _chk(src_row, I32, "unshuffleb.src")
+def unshuffle_bwd(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, row_of_pos=None):
+    """row_of_pos (grouped decoder layout): the decoder row of position (b, l); None: the rows are in position order"""
+    _chk(dout, F32, "unshuffleb.dout", 2); _chk(dx, F32, "unshuffleb.dx", 2); _chk(src_row, I32, "unshuffleb.src"); _chk(row_of_pos, I32, "unshuffleb.map")
     D = dout.shape[1]
     assert dout.shape[0] >= B * (La + T * Lv) and src_row.numel() >= B * (La + T * Lv) and dx.shape[1] == D
     assert dpos_a.numel() == La * D and dpos_v.numel() == Lv * D and dmask.numel() == D
-    _call("avs_unshuffle_bwd", dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, _stream())
+    assert row_of_pos is None or row_of_pos.numel() >= B * (La + T * Lv)
+    _call("avs_unshuffle_bwd_map", dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, row_of_pos, _stream())
+
+
+def expand_rows(inp, src_row, out, rows, cols=None):
+    """out[r, :cols] = inp[src_row[r], :cols] where src_row[r] >= 0, else 0 (bf16).  inp None: only the rows with src_row[r] < 0 are zeroed."""
+    _chk(inp, BF16, "expand.in", 2); _chk(out, BF16, "expand.out", 2); _chk(src_row, I32, "expand.src")
+    cols = out.shape[1] if cols is None else cols
+    assert out.shape[0] >= rows and src_row.numel() >= rows and cols <= out.shape[1] and (inp is None or inp.shape[1] >= cols)
+    _call("avs_expand_rows_bf16", inp, inp.stride(0) if inp is not None else 0, src_row, out, out.stride(0), rows, cols, _stream())
 
 
 def segment_mean_fwd(y, seg_start, reps, nseg, row_map=None, max_row=None):
@@ -682,7 +741,9 @@ def segment_mean_bwd(dreps, seg_start, dy, nseg, scale=1.0, row_map=None, max_ro
     _call("avs_segment_mean_bwd", dreps, seg_start, dy, nseg, dy.shape[1], float(scale), row_map, _stream())
 
 
-def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, total_init=True, xf=None, stride=16):
+def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, total_init=True, xf=None, stride=16, row_id=None, id_base=0):
+    """row_id / id_base (compact predictions: only the scored rows exist): prediction row r scores the (sample, token) row_id[r] - id_base of mask"""
+    _chk(row_id, I32, "mae.row_id")
     _chk(pred, F32, "mae.pred", 2); _chk(inp, U8 if (xf is not None and not audio) else F32, "mae.inp"); _chk(mask, F32, "mae.mask"); _chk(row_loss, F32, "mae.row_loss"); _chk(loss, F32, "mae.loss")
     _chk(total, F32, "mae.total")
     rows = mask.numel()
@@ -692,21 +753,24 @@ def mae_loss_fwd(pred, inp, mask, row_loss, loss, audio, L, nmask, total=None, t
     else:
         C, H, W = inp.shape[-3:]
         assert rows == inp.numel() // (C * H * W) * L and pred.shape[1] == 256 * C and (H // stride) * (W // stride) == L
-    assert pred.shape[0] >= rows and row_loss.numel() >= rows
-    _call("avs_mae_loss_fwd_s", pred, inp, mask, row_loss, loss, total, int(bool(total_init)), rows, int(audio), L, C, H, W,
-              float(nmask), int(stride), _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), _stream())
+    prows = rows if row_id is None else row_id.numel()
+    assert pred.shape[0] >= prows and row_loss.numel() >= prows
+    _call("avs_mae_loss_fwd_id", pred, inp, mask, row_loss, loss, total, int(bool(total_init)), prows, int(audio), L, C, H, W,
+              float(nmask), int(stride), _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), row_id, int(id_base), _stream())
 
 
-def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask, xf=None, stride=16):
+def mae_loss_bwd(pred, inp, mask, gout, dpred, audio, L, nmask, xf=None, stride=16, row_id=None, id_base=0):
+    _chk(row_id, I32, "maeb.row_id")
     _chk(pred, F32, "maeb.pred", 2); _chk(inp, U8 if (xf is not None and not audio) else F32, "maeb.inp"); _chk(mask, F32, "maeb.mask"); _chk(gout, F32, "maeb.gout"); _chk(dpred, BF16, "maeb.dpred", 2)
     rows = mask.numel()
     if audio:
         C, H, W = 1, inp.shape[1], inp.shape[2]
     else:
         C, H, W = inp.shape[-3:]
-    assert pred.shape[0] >= rows and dpred.shape[0] >= rows and dpred.shape[1] == pred.shape[1] == 256 * C
-    _call("avs_mae_loss_bwd_s", pred, inp, mask, gout, dpred, rows, int(audio), L, C, H, W, float(nmask), int(stride),
-              _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), _stream())
+    prows = rows if row_id is None else row_id.numel()
+    assert pred.shape[0] >= prows and dpred.shape[0] >= prows and dpred.shape[1] == pred.shape[1] == 256 * C
+    _call("avs_mae_loss_bwd_id", pred, inp, mask, gout, dpred, prows, int(audio), L, C, H, W, float(nmask), int(stride),
+              _xf_arg(xf, 1 if audio else 2, inp.shape[0] if audio else None), row_id, int(id_base), _stream())
 
 
 def l2norm_fwd(x, xn, norm):

@@ -948,7 +948,7 @@ def test_mask_plan_kernel_properties():
     dec = nseq * L
     for s in range(nseq):
         structured = s % 2 == 0
-        d[s] = [L, keep, s * keep, 1000 + s, s * L, s * 77, t_p if structured else 0, s * L, s * L, 0, 0, 0]
+        d[s] = [L, keep, s * keep, 1000 + s, s * L, s * 77, t_p if structured else 0, s * L, s * L, 0, 0, 0] + o.PLAN_CLASSIC
     rng = np.random.default_rng(0)
     tl = rng.integers(0, 2 ** 31, nseq).astype(np.int32) & 0x0F0F0F0F
     th = rng.integers(0, 2 ** 31, nseq).astype(np.int32) & 0x00FF00FF
@@ -989,6 +989,116 @@ def test_mask_plan_kernel_properties():
     assert torch.equal(ids2, ids)
     o.mask_plan(dev(d), d, 0x1234ABCD5679, row_src, row_tok, dev(tl), dev(th), dev(fm), src_row, mask, ids2)
     assert not torch.equal(ids2, ids)
+
+
+def test_mask_plan_grouped_decoder_layout():
+    """avs_mask_plan_grouped (round 6, EngineOptions.prune_dead): the decoder rows of a sample are ordered [scored tokens | kept tokens] instead of
+    by position.  Same Philox draws as the classic layout (ids equal for the same key); src_row / pos_row / row_of_pos / pred_id are consistent with
+    the shuffle: a kept token's row carries its encoder row, a scored token's row -1; row_of_pos inverts pos_row; the compact prediction rows
+    enumerate exactly the scored (sample, token) pairs in rank order."""
+    import numpy as np
+    o = ops()
+    B, T, La, Lv, ka, kv = 3, 2, 128, 196, 32, 49
+    ma, mv = La - ka, Lv - kv
+    Lt, lq, n_enc = La + T * Lv, ma + T * mv, ka + T * kv
+    nseq = B + B * T
+    d = np.zeros((nseq, o.PLAN_FIELDS), dtype=np.int32)
+    for b in range(B):
+        d[b] = [La, ka, b * ka, b, b * Lt, b * n_enc, 0, b * La, b * La, 0, 0, 0, b * Lt, b * Lt + lq, b * ma, 0]
+        for t in range(T):
+            i = b * T + t
+            d[B + i] = [Lv, kv, B * ka + i * kv, i, b * Lt + La + t * Lv, b * n_enc + ka + t * kv, 0, B * La + i * Lv, B * La + i * Lv, 0, 0, 0,
+                        b * Lt + ma + t * mv, b * Lt + lq + ka + t * kv, B * ma + i * mv, La]       # (every frame takes the one table pos_v: pos_base La)
+    dc = d.copy()
+    dc[:, 12:] = o.PLAN_CLASSIC
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    nrow = B * ka + B * T * kv
+    mk = lambda n, v=-7: torch.full((n,), v, dtype=torch.int32, device=DEV)
+    row_src, row_tok, src_row, ids = mk(nrow), mk(nrow), mk(B * Lt), mk(B * La + B * T * Lv)
+    pos_row, rop, pid = mk(B * Lt), mk(B * Lt), mk(B * ma + B * T * mv)
+    mask = torch.full((B * La + B * T * Lv,), -7.0, device=DEV)
+    o.mask_plan(dev(d), d, 0xFEED1234, row_src, row_tok, src_row=src_row, mask_out=mask, ids_out=ids, grouped=(pos_row, rop, pid))
+    src_c, ids_c, mask_c = mk(B * Lt), mk(B * La + B * T * Lv), torch.full_like(mask, -7.0)
+    o.mask_plan(dev(dc), dc, 0xFEED1234, mk(nrow), mk(nrow), src_row=src_c, mask_out=mask_c, ids_out=ids_c)
+    assert torch.equal(ids, ids_c) and torch.equal(mask, mask_c)                       # the same draws, the same loss masks
+    src_row, pos_row, rop, pid, src_c, mask_c = (x.cpu().long() for x in (src_row, pos_row, rop, pid, src_c, mask_c.int()))
+    assert torch.equal(rop.sort().values, torch.arange(B * Lt))                        # a permutation of the decoder rows
+    b_of = torch.arange(B * Lt) // Lt
+    pos_tab = torch.cat([torch.arange(La), La + torch.arange(Lv).repeat(T)]).repeat(B)  # the positional-table row of every position (frames share pos_v)
+    assert torch.equal(pos_row[rop], pos_tab)                                          # the row holding position p takes position p's table row
+    assert torch.equal(rop // Lt, b_of)                                                # ... and stays inside the sample
+    assert torch.equal(src_row[rop], src_c)                                            # the row holding position p carries what position p carried
+    for b in range(B):                                                                 # scored rows first, kept rows after
+        blk = src_row[b * Lt:(b + 1) * Lt]
+        assert (blk[:lq] == -1).all() and (blk[lq:] >= 0).all()
+        assert torch.equal(blk[lq:], b * n_enc + torch.arange(n_enc))                  # kept rows in encoder order: [audio | frame 0 | frame 1]
+    # compact prediction rows: audio row b * ma + r <-> the r-th scored token of the audio sequence, as (sample, token) of the mask numbering
+    mflat = mask_c
+    assert (mflat[pid] == 1).all() and pid.unique().numel() == pid.numel() == int(mflat.sum())
+    assert (pid[:B * ma] < B * La).all() and (pid[B * ma:] >= B * La).all()
+    # the decoder row of compact row (b, j) holds the same token: its position matches pred_id
+    inv = torch.empty_like(rop)
+    inv[rop] = torch.arange(B * Lt)                                                    # decoder row -> position b * Lt + l
+    for b in range(B):
+        pos = inv[b * Lt: b * Lt + lq] - b * Lt
+        tok_id = torch.where(pos < La, b * La + pos, B * La + (b * T + (pos - La) // Lv) * Lv + (pos - La) % Lv)
+        want = torch.cat([pid[b * ma:(b + 1) * ma]] + [pid[B * ma + (b * T + t) * mv: B * ma + (b * T + t + 1) * mv] for t in range(T)])
+        assert torch.equal(tok_id, want)
+
+
+@pytest.mark.parametrize("H,hd,L,lq", [(16, 32, 300, 203), (16, 32, 2472, 1854), (12, 64, 257, 128), (4, 80, 200, 77)])
+def test_attention_with_query_rows_limited_and_compact_output(H, hd, L, lq):
+    """avs_attn_fwd_cq / avs_attn_bwd_cq (the decoder's last block in the pruned form): only the first lq rows of every (equal-length) sequence
+    are queries, all rows are keys / values, out / dO are compact.  Against the full kernels: the compact output rows are BITWISE the full
+    output's rows of the same queries; the backward equals the full backward fed dO = 0 on the rows that are not queries - dq of the query
+    rows, dk and dv of every row, bitwise - and leaves the query third of the other rows untouched."""
+    o = ops()
+    D, nseq = H * hd, 3
+    rows = nseq * L
+    rp = o.pad_rows(rows)
+    qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(rows, 3 * D, device=DEV)
+    x[:, :D] *= o.attn_q_scale(hd)
+    qkv[:rows] = bf(x)
+    tiles = o.AttnTiles([L] * nseq, DEV, tile_rows=128)
+    assert tiles.uniform_len == L
+    out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(H, rp, device=DEV)
+    o.attn_fwd(qkv, tiles, H, out, lse)
+    cp = o.pad_rows(nseq * lq)
+    out_c = torch.full((cp, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    lse_c = torch.full((H, rp), 7.0, device=DEV)
+    o.attn_fwd(qkv, tiles, H, out_c, lse_c, lq=lq)
+    isq = torch.zeros(rows, dtype=torch.bool, device=DEV)
+    for s in range(nseq):
+        assert torch.equal(out_c[s * lq:(s + 1) * lq], out[s * L:s * L + lq])
+        assert torch.equal(lse_c[:, s * L:s * L + lq], lse[:, s * L:s * L + lq])
+        assert (lse_c[:, s * L + lq:(s + 1) * L] == 7.0).all()                        # rows that are keys / values only: nothing written
+        isq[s * L:s * L + lq] = True
+    assert (out_c[nseq * lq:] == 7.0).all()
+    dout = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
+    dout[:rows] = bf(torch.randn(rows, D, device=DEV))
+    dout[:rows][~isq] = 0
+    dout_c = torch.zeros(cp, D, device=DEV, dtype=torch.bfloat16)
+    for s in range(nseq):
+        dout_c[s * lq:(s + 1) * lq] = dout[s * L:s * L + lq]
+    dqkv, delta = torch.zeros_like(qkv), torch.zeros_like(lse)
+    o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv)
+    dqkv_c, delta_c = torch.full_like(qkv, 3.0), torch.zeros_like(lse)
+    o.attn_bwd(qkv, tiles, H, out_c, dout_c, lse_c, delta_c, dqkv_c, lq=lq)
+    assert torch.equal(dqkv_c[:rows, D:], dqkv[:rows, D:])                            # dk, dv: every row
+    assert torch.equal(dqkv_c[:rows, :D][isq], dqkv[:rows, :D][isq])                  # dq: the query rows
+    assert (dqkv_c[:rows, :D][~isq] == 3.0).all()                                     # ... the others are the caller's to zero
+    o.expand_rows(None, torch.where(isq, torch.arange(rows, device=DEV), torch.full((rows,), -1, device=DEV)).int(), dqkv_c, rows, cols=D)
+    assert (dqkv_c[:rows, :D][~isq] == 0).all() and torch.equal(dqkv_c[:rows, :D][isq], dqkv[:rows, :D][isq]) and torch.equal(dqkv_c[:rows, D:], dqkv[:rows, D:])
+    assert (dqkv[:rows, :D][~isq] == 0).all()                                         # (zero dO -> zero dq: what the pruned form relies on)
+    # expand_rows with a source: compact rows back into the packed numbering, zeros elsewhere
+    cmap = torch.full((rows,), -1, dtype=torch.int32, device=DEV)
+    for s in range(nseq):
+        cmap[s * L:s * L + lq] = torch.arange(s * lq, (s + 1) * lq, dtype=torch.int32, device=DEV)
+    back = torch.full((rp, D), 5.0, device=DEV, dtype=torch.bfloat16)
+    o.expand_rows(dout_c, cmap, back, rows)
+    assert torch.equal(back[:rows], dout[:rows]) and (back[rows:] == 5.0).all()
 
 
 def test_input_normalisation_matches_dataloader_formulas():
