@@ -118,7 +118,8 @@ class EngineOptions:
                   gradients (BASELINE.json configs[4]'s "fp8 MFMA path"; engine.Stack)                                           [structural]
     fp8_lean      mode 3: producers whose bf16 output has no reader left write the 8-bit copy only                                [structural]
     fp8_gelu8     modes 2 / 3: gelu'(x) travels between the fc1 forward and fc2 input-gradient epilogues as 8-bit codes           [structural]
-    gelu8         the same 8-bit gelu'(x) codes in the BF16 path (A/B of VERDICT r5 item 6a; default off)                         [structural]
+    gelu8         the same 8-bit gelu'(x) codes in the BF16 path (round 6, default ON: every golden / oracle assertion holds at unchanged
+                  tolerances with margins within 5 % of the bf16 operand's, +0.7 % throughput, -7 GiB; profiles/r06/ab_gelu8.txt)              [structural]
     recompute     "0" | "1" | fraction: leading blocks of every stack that keep no activations and re-run their forward           [structural]
     grad_stream   "bf16" | "fp32": the residual-GRADIENT stream between the blocks of a stack                                     [structural]
     attn_tile     0 automatic | 64 | 128: rows per attention workgroup (A/B)                                                      [structural]
@@ -136,7 +137,7 @@ class EngineOptions:
     fp8: str = "0"
     fp8_lean: bool = True
     fp8_gelu8: bool = True
-    gelu8: bool = False
+    gelu8: bool = True
     recompute: str = "0"
     grad_stream: str = "bf16"
     attn_tile: int = 0

@@ -273,7 +273,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                     if (ACT == 2) ax = pf.ax[mj][i];
                     const f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
                     const float4 bias_lo = make_float4(bq[0][0], bq[0][1], bq[0][2], bq[0][3]), bias_hi = make_float4(bq[1][0], bq[1][1], bq[1][2], bq[1][3]);
-                    if (ACT == 2 && Q8 == 2 && a.aux8) {          // the 8-bit gelu': one code per value, four per dword (hipcc turns the byte picks into v_cvt_f32_ubyteN)
+                    if (ACT == 2 && Q8 != 1 && a.aux8) {          // the 8-bit gelu': one code per value, four per dword (hipcc turns the byte picks into v_cvt_f32_ubyteN)
                         auto dec = [](float b) { return fmaf(b, 1.0f / GP8_STEPS, -GP8_BIAS); };
                         const float g0[4] = {dec((float)((ax[0] >> 0) & 0xffu)), dec((float)((ax[0] >> 8) & 0xffu)),
                                              dec((float)((ax[0] >> 16) & 0xffu)), dec((float)((ax[0] >> 24) & 0xffu))};
@@ -303,7 +303,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4]
                         o.z = pack_bf2(v1[0], v1[1]); o.w = pack_bf2(v1[2], v1[3]);
                     }
                     // (fp8 input-gradient form: `out` may be NULL - every reader of this gradient takes the e5m2 copy below; the bf16 kernels never test it)
-                    if (ACT == 1 && Q8 == 1 && a.aux8) {          // gelu'(x) as 8-bit codes (fp8 backward): 8 bytes per lane instead of 16
+                    if (ACT == 1 && Q8 != 2 && a.aux8) {          // gelu'(x) as 8-bit codes (fp8 backward; bf16 with EngineOptions.gelu8): 8 bytes per lane instead of 16
                         auto enc = [](float g, unsigned sel, unsigned old) { return __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g, GP8_STEPS, GP8_BIAS * GP8_STEPS), sel, old); };
                         unsigned c0 = enc(gelu_erf_grad(v0[0]), 0, 0); c0 = enc(gelu_erf_grad(v0[1]), 1, c0); c0 = enc(gelu_erf_grad(v0[2]), 2, c0); c0 = enc(gelu_erf_grad(v0[3]), 3, c0);
                         unsigned c1 = enc(gelu_erf_grad(v1[0]), 0, 0); c1 = enc(gelu_erf_grad(v1[1]), 1, c1); c1 = enc(gelu_erf_grad(v1[2]), 2, c1); c1 = enc(gelu_erf_grad(v1[3]), 3, c1);
@@ -1249,6 +1249,17 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
                           int m_split, const bf16_t* B2, const float* bias2, float* colsum2, hipStream_t stream) {
     AVS_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % BN) == 0 && (K % BK) == 0, "gemm_nt: need N%%128==0, K%%64==0 (M=%d N=%d K=%d)", M, N, K);
     AVS_CHECK_ARG(A && B && out, "gemm_nt: null operand");
+    // gelu'(x) as 8-bit fixed-point codes (GP8_*; round 6: the bf16 GEMMs too - EngineOptions.gelu8): out_f32 == 2 with act 1 - `out` receives one byte per
+    // value (ldo in BYTES); act == 3 = act 2 whose `aux` holds those codes (ldaux in bytes).  Same convention as avs_gemm_nt_fp8's out_f32 == 2 / a_e5m2 == 2.
+    int aux8 = 0;
+    if (out_f32 == 2) {
+        AVS_CHECK_ARG(act == 1 && (ldo % 8) == 0 && ldo >= N, "gemm_nt: out_f32 == 2 (8-bit gelu') goes with act 1");
+        out_f32 = 0; aux8 = 1;
+    }
+    if (act == 3) {
+        AVS_CHECK_ARG(aux && ldaux >= N, "gemm_nt: act 3 (act 2 with 8-bit gelu' codes) needs aux");
+        act = 2; aux8 = 1;
+    }
     AVS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && (ldo % (out_f32 ? 4 : 8)) == 0 && (!out2 || (ldo2 % 8) == 0) && (!aux || (ldaux % 8) == 0),
                   "gemm_nt: leading dimensions must keep 16-byte alignment");
     AVS_CHECK_ARG(act >= 0 && act <= 2 && (act != 1 || out2) && (act != 2 || aux), "gemm_nt: bad activation arguments");
@@ -1257,7 +1268,7 @@ static int gemm_nt_launch(const bf16_t* A, long long lda, const bf16_t* B, long 
     AVS_CHECK_ARG(!res || out_f32, "gemm_nt: the residual add is implemented for fp32 output");
     AVS_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && (scale_cols % 64) == 0, "gemm_nt: scale_cols must be a multiple of 64 within N");
     GemmNtArgs a{A, lda, B, ldb, M, N, K, bias, res, ldr, res_idx, aux, ldaux, out, ldo, out_f32, out2, ldo2, alpha, act, scale_cols, col_scale, colsum, M,
-                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+                 m_split, B2, bias2, colsum2, nullptr, 0, 1.0f, nullptr, nullptr, nullptr, nullptr, 0.f, 0, aux8};
     // 256^2 tiles once they give half the CUs a workgroup; otherwise 128^2 (4x the workgroups, two per CU).  Rounds 1 - 4 asked for 224 tiles; between
     // 128 and 224 the 128^2 tiling needs 512 ... 896 workgroups = a second round on 512 slots, and the persistent kernel on a part of the chip
     // runs at a higher clock: 135 tiles, K = 3072: 78.1 -> 63.8 us, K = 768: 25.8 -> 23.5; 192 tiles: 80.9 -> 68.9, 28.4 -> 25.7; under

@@ -394,7 +394,8 @@ class Stack:
         self.att = per_block((rp, D), BF16)
         # gelu'(fc1 output): all the backward needs of the pre-activation (gemm act 1 / 2).  With the fp8 backward (modes 2 / 3) it travels as 8-bit
         # fixed-point codes (ops.gemm_nt_fp8: a uint8 `out` / `aux`): half the bytes of the two epilogues that write and read it (AVSIAM_FP8_GELU8=0: A/B)
-        self.fc1 = per_block((rp, hidden), U8 if (getattr(self, "fp8_bwd", False) and FP8_GELU8) else BF16)
+        # EngineOptions.gelu8 (default on since round 6): the same codes in the bf16 path
+        self.fc1 = per_block((rp, hidden), U8 if ((getattr(self, "fp8_bwd", False) and FP8_GELU8) or (opts.gelu8 and not self.fp8 and not inference)) else BF16)
         self.act = (one_for_all if lean else per_block)((rp, hidden), BF16)
         self.lse = per_block((H, rp), F32)
         nshared = nblocks if inference else self.nrecomp

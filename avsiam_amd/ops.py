@@ -173,8 +173,13 @@ def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None
     colsum[n] += sum_m out[m, n] (bf16 output only).
     dual = (m_split, B2, bias2, colsum2): rows [m_split, M) use the second weight set (one launch for two towers)."""
     _chk(A, BF16, "gemm.A", 2); _chk(B, BF16, "gemm.B", 2); _chk(bias, F32, "gemm.bias"); _chk(res, F32, "gemm.res", 2)
-    _chk(res_idx, I32, "gemm.res_idx"); _chk(aux, BF16, "gemm.aux", 2); _chk(out2, BF16, "gemm.out2", 2)
-    if out.dtype not in (BF16, F32) or not out.is_cuda or not out.is_contiguous() or out.dim() != 2:
+    # gelu'(x) as 8-bit fixed-point codes (EngineOptions.gelu8; the fp8 GEMMs' convention, gemm_nt_fp8): a uint8 `out` with act 1 / a uint8 `aux` with act 2
+    gp8_out = out.dtype == U8
+    gp8_aux = aux is not None and aux.dtype == U8
+    assert not gp8_out or act == 1, "a uint8 `out` is the 8-bit gelu'(x) of act 1"
+    assert not gp8_aux or act == 2, "a uint8 `aux` is the 8-bit gelu'(x) read by act 2"
+    _chk(res_idx, I32, "gemm.res_idx"); _chk(aux, U8 if gp8_aux else BF16, "gemm.aux", 2); _chk(out2, BF16, "gemm.out2", 2)
+    if out.dtype not in (BF16, F32, U8) or not out.is_cuda or not out.is_contiguous() or out.dim() != 2:
         raise _lib.AvsiamHipError("gemm.out: need contiguous 2-D bf16/fp32 GPU tensor")
     N, K = B.shape
     assert A.shape[1] == K and A.shape[0] >= M and out.shape[0] >= M and out.shape[1] == N, (A.shape, B.shape, out.shape, M)
@@ -194,8 +199,8 @@ def gemm_nt(A, B, out, M, bias=None, res=None, res_idx=None, aux=None, out2=None
     if act == 2:
         assert aux is not None and aux.shape[0] >= M and aux.shape[1] == N
     args = (A, A.stride(0), B, B.stride(0), M, N, K, bias, res, res.stride(0) if res is not None else 0,
-            res_idx, aux, aux.stride(0) if aux is not None else 0, out, out.stride(0), 1 if out.dtype == F32 else 0, out2,
-            out2.stride(0) if out2 is not None else 0, float(alpha), act, int(scale_cols), float(col_scale), colsum)
+            res_idx, aux, aux.stride(0) if aux is not None else 0, out, out.stride(0), 2 if gp8_out else 1 if out.dtype == F32 else 0, out2,
+            out2.stride(0) if out2 is not None else 0, float(alpha), 3 if gp8_aux else act, int(scale_cols), float(col_scale), colsum)
     if dual is None:
         _launch("gemm_nt_act%d" % act, 2.0 * M * N * K, "avs_gemm_nt_bf16", *args, _stream())
     else:

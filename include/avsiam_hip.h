@@ -78,7 +78,10 @@ int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* m
  * uses it to hand the attention kernels q already multiplied by hd^-0.5 * log2(e), rounded to bf16 once.
  * colsum (bf16 output only, may be NULL): colsum[n] += sum over rows of the output - the bias gradient of the layer
  * whose output gradient this GEMM produces (fc1.bias from the fc2 dgrad), without re-reading the matrix.
- * fp32 output (out_f32) requires act 0. */
+ * fp32 output (out_f32 == 1) requires act 0.
+ * gelu'(x) as 8-bit fixed-point codes (ABI 2; round((g' + 0.1296875) * 202), g' in [-0.129, 1.129]: a step of 0.005): out_f32 == 2 with act 1 -
+ * `out` receives one byte per value, ldo in BYTES; act 3 = act 2 whose `aux` holds those codes (ldaux in bytes) - half the bytes of the one
+ * output / operand nothing else reads (as avs_gemm_nt_fp8's out_f32 == 2 / a_e5m2 == 2).  Opt-in (EngineOptions.gelu8). */
 int avs_gemm_nt_bf16(const avs_bf16* A, long long lda, const avs_bf16* B, long long ldb, int M, int N, int K,
                      const float* bias, const float* res, long long ldr, const int* res_idx, const avs_bf16* aux,
                      long long ldaux, void* out, long long ldo, int out_f32, avs_bf16* out2, long long ldo2, float alpha,

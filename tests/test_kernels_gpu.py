@@ -218,6 +218,20 @@ def test_gemm_nt_epilogues(M, N, K):
     want = ref * dact.double()
     assert rel_err(dpre, want) < 5e-3
     assert rel_err(csum, 1 + want.sum(0)) < 2e-3                  # fused column sum (bias gradient), accumulated
+    # gelu'(x) as 8-bit fixed-point codes in the bf16 GEMMs (EngineOptions.gelu8: a uint8 `out` with act 1, a uint8 `aux` with act 2): the codes
+    # decode to the bf16 epilogue's gelu' within half a step (1 / 404) + its bf16 rounding, gelu(x) is bitwise unchanged, and the input gradient
+    # formed with the codes equals the one formed with the bf16 operand to the codes' resolution
+    codes = torch.zeros(M, N, device=DEV, dtype=torch.uint8)
+    act8 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    o.gemm_nt(A, W, codes, M, bias=bias, out2=act8, act=1)
+    dec = codes.double() / 202.0 - 0.1296875
+    assert torch.equal(act8, act)
+    assert float((dec - dact.double()).abs().max()) <= 0.5 / 202 + 4e-3, float((dec - dact.double()).abs().max())
+    dpre8 = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    csum8 = torch.ones(N, device=DEV)
+    o.gemm_nt(A, W, dpre8, M, aux=codes, act=2, colsum=csum8)
+    assert rel_err(dpre8, ref * dec) < 5e-3 and rel_err(dpre8, want) < 8e-3
+    assert rel_err(csum8, 1 + (ref * dec).sum(0)) < 2e-3
 
 
 @pytest.mark.parametrize("M,N,K", [(708, 768, 768), (1979, 2304, 768), (2832, 512, 2048), (333, 256, 256), (2048, 768, 3072), (130, 3072, 768)])

@@ -262,8 +262,9 @@ def test_graphed_step_equals_the_eager_step(fp8):
             assert close(oe, og), (i, oe, og)
         assert me._opt_state[P1]["step"] == mg._opt_state[P1]["step"] == 5 and me._opt_state[P2]["step"] == mg._opt_state[P2]["step"] == 5
         rel = float((me.arena.p - mg.arena.p).double().norm() / me.arena.p.double().norm())
-        assert rel < 2e-3, rel        # measured 3.6e-4 after five updates: Adam's first steps move every weight by +-lr by the SIGN of its gradient
-                                      # element, and the order of the fp32 atomics decides the sign of the smallest ones
+        assert rel < (2e-3 if fp8 == "0" else 6e-3), rel      # measured 3.6e-4 (bf16) / 3e-4 .. 2.9e-3 (fp8 mode 3, box to box) after five updates: Adam's
+                                      # first steps move every weight by +-lr by the SIGN of its gradient element, and the order of the fp32 atomics
+                                      # decides the sign of the smallest ones; e5m2 gradient operands leave more of them near zero
         # mixed: an eager step on the graphed model, then a replay - the counters are re-written from the host state in front of every replay
         train_step(me, a, v, 2e-4); train_step(mg, a, v, 2e-4)
         oe = [float(x.item()) for x in train_step(me, a, v, 2e-4)]
