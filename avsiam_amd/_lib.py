@@ -88,7 +88,7 @@ def env_value(name):
 
 _ENV_KNOBS = {"AVSIAM_GEMM_TILE": "gemm_tile", "AVSIAM_GEMM_NT8": "gemm_nt8", "AVSIAM_NT_TILE_H": "nt_tile_h", "AVSIAM_NT_GRID": "nt_grid",
               "AVSIAM_CU_RESERVE": "cu_reserve", "AVSIAM_LN_DMA": "ln_dma", "AVSIAM_LN_RPW": "ln_rpw", "AVSIAM_ATTN_RING": "attn_ring", "AVSIAM_GEMM_RING": "gemm_ring",
-              "AVSIAM_NT_BIG_MIN": "nt_big_min"}
+              "AVSIAM_NT_BIG_MIN": "nt_big_min", "AVSIAM_DET": "det"}
 
 
 def tuning_set(name, value):

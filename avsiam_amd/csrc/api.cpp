@@ -18,7 +18,7 @@ extern "C" void avs_set_error(const char* fmt, ...) {
 extern "C" const char* avs_last_error(void) { return g_err; }
 
 // 2 (round 6): avs_attn_fwd / avs_attn_bwd need 16-byte-aligned rows (ldo % 8 == 0; was % 4), avs_gemm_nt_fp8 gives out_f32 == 2 / a_e5m2 == 2
-// a meaning (gelu'(x) as 8-bit codes), "ln_dma" is 0 | 1, the deterministic weight-gradient knob "tn_det" exists
+// a meaning (gelu'(x) as 8-bit codes), "ln_dma" is 0 | 1, the deterministic-reduction knob "det" exists
 extern "C" int avs_abi_version(void) { return 2; }
 
 // number of compute units of the current device (used by hosts to size split factors); <0 on error
@@ -33,7 +33,7 @@ extern "C" int avs_device_cu_count(void) {
 // avs_tuning_set (the host binding calls it once per knob at load, from the AVSIAM_* environment) before kernels are queued; launchers
 // read them, nothing is initialised lazily and nothing reads the environment.
 static AvsTuning g_tuning = {/*gemm_tile*/ 0, /*gemm_persistent*/ 1, /*gemm_nt8*/ 1, /*nt_tile_h*/ 0, /*nt_grid*/ 0, /*cu_reserve*/ 0,
-                             /*ln_dma*/ 1, /*ln_rpw*/ 0, /*gemm_ring*/ 2, /*attn_ring*/ 0, /*nt_big_min*/ 0};      // (attn_ring: measured neutral to slower in round 5 - DESIGN.md 5e - so off by default)
+                             /*ln_dma*/ 1, /*ln_rpw*/ 0, /*gemm_ring*/ 2, /*attn_ring*/ 0, /*nt_big_min*/ 0, /*det*/ 0};      // (attn_ring: measured neutral to slower in round 5 - DESIGN.md 5e - so off by default)
 AvsTuning& avs_tuning() { return g_tuning; }
 
 int avs_persistent_slots() {
@@ -51,7 +51,7 @@ static const Knob g_knobs[] = {
     {"gemm_tile", &AvsTuning::gemm_tile, 0, 256},   {"gemm_persistent", &AvsTuning::gemm_persistent, 0, 1}, {"gemm_nt8", &AvsTuning::gemm_nt8, 0, 1},
     {"nt_tile_h", &AvsTuning::nt_tile_h, 0, 256},   {"nt_grid", &AvsTuning::nt_grid, 0, 1 << 20},           {"cu_reserve", &AvsTuning::cu_reserve, 0, 128},
     {"ln_dma", &AvsTuning::ln_dma, 0, 1},           {"ln_rpw", &AvsTuning::ln_rpw, 0, 16},                  {"attn_ring", &AvsTuning::attn_ring, 0, 1},
-    {"gemm_ring", &AvsTuning::gemm_ring, 0, 2},     {"nt_big_min", &AvsTuning::nt_big_min, 0, 1 << 20},
+    {"gemm_ring", &AvsTuning::gemm_ring, 0, 2},     {"nt_big_min", &AvsTuning::nt_big_min, 0, 1 << 20},     {"det", &AvsTuning::det, 0, 1},
 };
 
 extern "C" int avs_tuning_set(const char* name, int value) {

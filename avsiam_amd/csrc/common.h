@@ -149,6 +149,10 @@ struct AvsTuning {
                            // bitwise the same results, measured neutral to slower                     AVSIAM_ATTN_RING
     int nt_big_min;        // forward / input-gradient GEMMs with at least this many 256^2 output tiles run the persistent 256^2 kernels, smaller
                            // ones the 128 x 128 kernels; 0 (default): half the persistent slots                      AVSIAM_NT_BIG_MIN
+    int det;               // 1: every reduction into a parameter gradient has ONE writer per element and a fixed order - the weight-gradient GEMMs do
+                           // not split their token rows (one workgroup per output tile), column sums / the vector-matrix product / the LayerNorm slab
+                           // reduce run as one block per column group, the positional-embedding scatter and the un-shuffle's token sums take their
+                           // atomics-free forms: two runs of a step give the same bits (debugging; slower).  0 (default)        AVSIAM_DET
 };
 AvsTuning& avs_tuning();
 extern "C" int avs_tuning_set(const char* name, int value);

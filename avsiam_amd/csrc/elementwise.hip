@@ -93,16 +93,25 @@ __global__ void scatter_add_rows_kernel(const bf16_t* __restrict__ src, const in
     for (int c = threadIdx.x; c < D; c += blockDim.x) atomicAdd(d + c, scale * bf2f(src[(size_t)r * D + c]));
 }
 
+// the same without atomics (AvsTuning::det): a block owns 64 columns and walks ALL rows in order - one writer per element, fixed order
+__global__ __launch_bounds__(64) void scatter_add_rows_det_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, float* dst,
+                                                                  int rows, int D, float scale) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= D) return;
+    for (int r = 0; r < rows; ++r) dst[(size_t)idx[r] * D + c] += scale * bf2f(src[(size_t)r * D + c]);
+}
+
 // out[c] += sum_r x[r, c]  (bias gradients).  A block owns 64 columns x COLSUM_ROWS rows: 8 threads cover the 64
 // columns with one 16-byte load each (a full 128-B line per row), 32 row-lanes stride the rows; partial sums are
 // combined through LDS and leave as one atomic per column per block.
 constexpr int COLSUM_ROWS = 512;
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long long ld, float* out, int rows) {
+// rows_per_block: COLSUM_ROWS, or all the rows (AvsTuning::det: one block - one adder - per 64 columns)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long long ld, float* out, int rows, int rows_per_block) {
     __shared__ float red[32][65];
     const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c0 = blockIdx.x * 64 + cg * 8;
-    const int r0 = blockIdx.y * COLSUM_ROWS;
-    const int r1 = min(rows, r0 + COLSUM_ROWS);
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = r0 + rl; r < r1; r += 32) {
         const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)r * ld + c0);
@@ -151,7 +160,7 @@ __global__ void unshuffle_fwd_kernel(const float* __restrict__ x, const int* __r
 // maskplan.hip: scored rows first); src_row is indexed by decoder row.
 __global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ src_row, int B, int T,
                                      int La, int Lv, float* __restrict__ dx, float* dpos_a, float* dpos_v,
-                                     float* dmask, float* dmod_a, float* dmod_v, int D, const int* __restrict__ row_of_pos) {
+                                     float* dmask, float* dmod_a, float* dmod_v, int D, const int* __restrict__ row_of_pos, int det) {
     const int l = blockIdx.x;
     const bool audio = l < La;
     const int Ltot = La + T * Lv;
@@ -171,6 +180,7 @@ __global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* 
         float* dp = audio ? dpos_a + (size_t)l * D : dpos_v + (size_t)(l - La) * D;
         float4 old = reinterpret_cast<float4*>(dp)[c];
         reinterpret_cast<float4*>(dp)[c] = make_float4(old.x + sp.x, old.y + sp.y, old.z + sp.z, old.w + sp.w);
+        if (det) continue;                                    // (AvsTuning::det: the token sums come from unshuffle_tokens_det_kernel, one writer each)
         float* dm = audio ? dmod_a : dmod_v;
         atomicAdd(dm + c * 4 + 0, sp.x); atomicAdd(dm + c * 4 + 1, sp.y);
         atomicAdd(dm + c * 4 + 2, sp.z); atomicAdd(dm + c * 4 + 3, sp.w);
@@ -433,6 +443,8 @@ extern "C" int avs_cast_scale_bf16(const float* x, bf16_t* y, long long n, float
 extern "C" int avs_scatter_add_rows(const bf16_t* src, const int* idx, float* dst, int rows, int D, float scale,
                                     hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && src && idx && dst, "scatter_add_rows: bad args");
+    if (avs_tuning().det) scatter_add_rows_det_kernel<<<ceil_div(D, 64), 64, 0, stream>>>(src, idx, dst, rows, D, scale);
+    else
     scatter_add_rows_kernel<<<rows, 256, 0, stream>>>(src, idx, dst, rows, D, scale);
     AVS_LAUNCH_CHECK("scatter_add_rows");
     return 0;
@@ -610,8 +622,9 @@ extern "C" int avs_fp8_scale_update(float* q, float* hist, int n, int nhist, int
 
 extern "C" int avs_colsum_bf16(const bf16_t* x, long long ld, float* out, int rows, int C, hipStream_t stream) {
     AVS_CHECK_ARG(rows > 0 && (C % 64) == 0 && ld >= C && (ld % 8) == 0 && x && out, "colsum: C must be a multiple of 64, ld of 8");
-    dim3 grid(C / 64, ceil_div(rows, COLSUM_ROWS));
-    colsum_bf16_kernel<<<grid, 256, 0, stream>>>(x, ld, out, rows);
+    const int rpb = avs_tuning().det ? rows : COLSUM_ROWS;
+    dim3 grid(C / 64, ceil_div(rows, rpb));
+    colsum_bf16_kernel<<<grid, 256, 0, stream>>>(x, ld, out, rows, rpb);
     AVS_LAUNCH_CHECK("colsum");
     return 0;
 }
@@ -638,8 +651,32 @@ __global__ __launch_bounds__(256) void vecmat_bf16_kernel(const float* __restric
     for (int j = 0; j < 4; ++j) atomicAdd(y + n + j, alpha * acc[j]);
 }
 
+// the same with one writer per element (AvsTuning::det): a block owns 256 columns and walks all of K, its four waves fold through LDS in a fixed order
+__global__ __launch_bounds__(256) void vecmat_bf16_det_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W, long long ld,
+                                                              float* y, int K, float alpha) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + lane * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = wave * 8; k0 < K; k0 += 32)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = x[k0 + j];
+            const uint2 w = *reinterpret_cast<const uint2*>(W + (size_t)(k0 + j) * ld + n);
+            acc[0] = fmaf(xv, __uint_as_float(w.x << 16), acc[0]); acc[1] = fmaf(xv, __uint_as_float(w.x & 0xffff0000u), acc[1]);
+            acc[2] = fmaf(xv, __uint_as_float(w.y << 16), acc[2]); acc[3] = fmaf(xv, __uint_as_float(w.y & 0xffff0000u), acc[3]);
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][lane * 4 + j] = acc[j];
+    __syncthreads();
+    const int c = threadIdx.x;
+    y[blockIdx.x * 256 + c] += alpha * ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+}
+
 extern "C" int avs_vecmat_bf16(const float* x, const bf16_t* W, long long ld, float* y, int K, int N, float alpha, hipStream_t stream) {
     AVS_CHECK_ARG(x && W && y && K > 0 && N > 0 && (N % 256) == 0 && (K % 32) == 0 && ld >= N && (ld % 4) == 0, "vecmat: N %% 256, K %% 32");
+    if (avs_tuning().det) vecmat_bf16_det_kernel<<<N / 256, 256, 0, stream>>>(x, W, ld, y, K, alpha);
+    else
     vecmat_bf16_kernel<<<dim3(N / 256, K / 32), 256, 0, stream>>>(x, W, ld, y, alpha);
     AVS_LAUNCH_CHECK("vecmat");
     return 0;
@@ -655,11 +692,39 @@ extern "C" int avs_unshuffle_fwd(const float* x, const int* src_row, const int* 
     return 0;
 }
 
+// The three sums over decoder rows that unshuffle_bwd_kernel forms with atomics - mask-token gradient (rows with no encoder source), the two
+// modality-embedding gradients - with ONE writer per element and a fixed order (AvsTuning::det): a block owns 64 columns, its four row lanes
+// stride the positions and fold through LDS.
+__global__ __launch_bounds__(256) void unshuffle_tokens_det_kernel(const float* __restrict__ dout, const int* __restrict__ src_row, int B, int T, int La, int Lv,
+                                                                   float* dmask, float* dmod_a, float* dmod_v, int D, const int* __restrict__ row_of_pos) {
+    __shared__ float red[3][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int Ltot = La + T * Lv;
+    float sm = 0.f, sa = 0.f, sv = 0.f;
+    if (c < D)
+        for (int rp = rl; rp < B * Ltot; rp += 4) {
+            const int r = row_of_pos ? row_of_pos[rp] : rp;
+            const float g = dout[(size_t)r * D + c];
+            if (rp % Ltot < La) sa += g; else sv += g;
+            if (src_row[r] < 0) sm += g;
+        }
+    red[0][rl][threadIdx.x & 63] = sm; red[1][rl][threadIdx.x & 63] = sa; red[2][rl][threadIdx.x & 63] = sv;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < D) {
+        const int t = threadIdx.x;
+        dmask[c] += (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+        dmod_a[c] += (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+        dmod_v[c] += (red[2][0][t] + red[2][1][t]) + (red[2][2][t] + red[2][3][t]);
+    }
+}
+
 extern "C" int avs_unshuffle_bwd_map(const float* dout, const int* src_row, int B, int T, int La, int Lv, float* dx,
                                      float* dpos_a, float* dpos_v, float* dmask, float* dmod_a, float* dmod_v, int D,
                                      const int* row_of_pos, hipStream_t stream) {
     AVS_CHECK_ARG(B > 0 && T > 0 && (D % 4) == 0 && dout && src_row && dx, "unshuffle_bwd: bad args");
-    unshuffle_bwd_kernel<<<La + Lv, 128, 0, stream>>>(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, row_of_pos);
+    const int det = avs_tuning().det;
+    unshuffle_bwd_kernel<<<La + Lv, 128, 0, stream>>>(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, row_of_pos, det);
+    if (det) unshuffle_tokens_det_kernel<<<ceil_div(D, 64), 256, 0, stream>>>(dout, src_row, B, T, La, Lv, dmask, dmod_a, dmod_v, D, row_of_pos);
     AVS_LAUNCH_CHECK("unshuffle_bwd");
     return 0;
 }

@@ -1497,6 +1497,7 @@ extern "C" int avs_gemm_nt_bf16_dual(const bf16_t* A, long long lda, const bf16_
 // fitted to that log: t_stage = 1.3 us per 64-row stage of a 256^2 tile (0.35 us for a 128^2 tile, two workgroups per CU), t_atomic = 0.2 us per
 // 256-KiB tile (0.065 us per 64 KiB).  Capped by one resident round, which is what the 256^2 kernels still get from ~20 000 rows up.
 static int tn_splits(int tiles, int nstages, int slots, double t_stage, double t_atomic) {
+    if (avs_tuning().det) return 1;          // deterministic mode: one workgroup - one writer, one contraction order - per output tile
     int cap = slots / tiles;
     if (cap < 1) cap = 1;
     int s = (int)(sqrt(t_stage * nstages / (t_atomic * tiles)) + 0.5);

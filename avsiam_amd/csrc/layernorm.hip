@@ -515,7 +515,7 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
 #undef LN_DMA
 #undef LN_DMA_
         AVS_LAUNCH_CHECK("layernorm_bwd_dma");
-        const int chunks_ = nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;
+        const int chunks_ = avs_tuning().det ? 1 : nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;       // (det: one adder per address)
         ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), LN_SETS, chunks_), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1, dcol);
         AVS_LAUNCH_CHECK("layernorm_bwd_reduce");
         return 0;
@@ -538,7 +538,7 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
 #undef LN_BWD
 #undef LN_BWD_R
     AVS_LAUNCH_CHECK("layernorm_bwd");
-    const int chunks = nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;
+    const int chunks = avs_tuning().det ? 1 : nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;            // (det: one adder per address)
     ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), LN_SETS, chunks), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1, dcol);
     AVS_LAUNCH_CHECK("layernorm_bwd_reduce");
     return 0;

@@ -653,6 +653,7 @@ class Stack:
         grp = excl or mode == "0"     # the block's fc2 / fc1 / proj weight gradients are issued together (one grouped launch); mode 1
                                       # issues each as early as its operands exist
         g16 = self.opts.grad_stream == "bf16"   # the residual gradient travels between the LayerNorm backwards in bf16 only
+        det = bool(self.opts.deterministic)     # one stream (above), no epilogue atomics; the library's own reductions follow the "det" knob (the model sets it)
 
         done = set()
 
@@ -733,11 +734,15 @@ class Stack:
             if f8b:
                 o8, r8_ = g8rec(i, "dfc1")
                 # (lean mode 3: once the e5m2 copy is written by this epilogue nothing reads the bf16 gradient - no bf16 output)
-                self._dgrad_fp8(i, "dbo", "fc2", dbo, self.dx8[0], bp.fc2, b2.fc2 if b2 else None, split, None if self.fp8_lean and o8 is not None else self.dfc1, act=2, aux=self.fc1[i],
-                                colsum=bp.fc1.gb, colsum2=b2.fc1.gb if b2 else None, **({"out8": o8, "q8": r8_} if o8 is not None else {}))
+                # (deterministic mode: the bf16 gradient is written even in the lean form - the column-sum kernel below reads it)
+                self._dgrad_fp8(i, "dbo", "fc2", dbo, self.dx8[0], bp.fc2, b2.fc2 if b2 else None, split, None if (self.fp8_lean and o8 is not None and not det) else self.dfc1, act=2, aux=self.fc1[i],
+                                colsum=None if det else bp.fc1.gb, colsum2=None if det else (b2.fc1.gb if b2 else None), **({"out8": o8, "q8": r8_} if o8 is not None else {}))
             else:
-                ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, Mu, aux=self.fc1[i], act=2, colsum=bp.fc1.gb,               # + fc1 bias gradient
-                            dual=(split, b2.fc2.wt, None, b2.fc1.gb) if b2 is not None else None)
+                ops.gemm_nt(dbo, bp.fc2.wt, self.dfc1, Mu, aux=self.fc1[i], act=2, colsum=None if det else bp.fc1.gb,   # + fc1 bias gradient
+                            dual=(split, b2.fc2.wt, None, None if det else b2.fc1.gb) if b2 is not None else None)
+            if det:                   # deterministic mode: the fc1 bias gradient by the column-sum kernel (one writer per element) instead of the epilogue's atomics
+                for lo, hi, bl in (ranges if not pruned else [(0, Mu, blocks)]):
+                    ops.colsum(self.dfc1[lo:], bl[i].fc1.gb, hi - lo)
             if not grp:
                 wgrads(i, "dbo", (dbo, self.act[i], "fc2"), rows=Mu if pruned else None)
             if i == self.nblocks - 1 and not last_fc2_bias_done:

@@ -86,6 +86,20 @@ class _HotPath(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_mae, g_c, *unused):
         model = ctx.model
+        if not model.options.deterministic:
+            return _HotPath._backward(ctx, g_mae, g_c)
+        # EngineOptions.deterministic: the library's reductions into parameter gradients take their one-writer forms while THIS model's backward is
+        # queued (the "det" knob is read by the launchers at enqueue time, host-side: set / restored around the schedule - another model is not affected)
+        old = _lib.tuning_get("det")
+        _lib.tuning_set("det", 1)
+        try:
+            return _HotPath._backward(ctx, g_mae, g_c)
+        finally:
+            _lib.tuning_set("det", old)
+
+    @staticmethod
+    def _backward(ctx, g_mae, g_c):
+        model = ctx.model
         arena = model.arena
         B = ctx.batch
         live = 0
@@ -150,15 +164,16 @@ class CAVMAE_BASE(nn.Module):
                  modality_specific_depth=23, num_heads=16, decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16,
                  mlp_ratio=4., norm_layer=nn.LayerNorm, norm_pix_loss=False, tr_pos=False, opt=None, *,
                  cfg: AVSiamConfig = None, init_seed=0, init_mode="init", plan_seed=None, verbose=True, share_pass_buffers=None,
-                 fp8_mode=None, recompute=None, grad_stream=None, options: EngineOptions = None):
+                 fp8_mode=None, recompute=None, grad_stream=None, deterministic=None, options: EngineOptions = None):
         """Positional arguments: the reference's (cav_mae_base.py:219-222), accepted and - like there - mostly ignored.  Keyword-only
         extensions: `cfg` (shape), `fp8_mode` ("0".."3"), `recompute` ("0" | "1" | fraction), `grad_stream` ("bf16" | "fp32"),
-        `share_pass_buffers`, or a whole `options` object (config.EngineOptions) - precision and memory policy belong to THIS model;
+        `deterministic` (bit-reproducible steps: one-writer reductions, one stream), `share_pass_buffers`, or a whole `options` object (config.EngineOptions) - precision and memory policy belong to THIS model;
         the AVSIAM_* environment only seeds what is not given."""
         super().__init__()
-        if options is not None and any(x is not None for x in (fp8_mode, recompute, grad_stream)):
-            raise ValueError("pass either `options` or the single keywords (fp8_mode / recompute / grad_stream), not both")
-        self.options = options.validated() if options is not None else EngineOptions.from_env(fp8=fp8_mode, recompute=recompute, grad_stream=grad_stream)
+        if options is not None and any(x is not None for x in (fp8_mode, recompute, grad_stream, deterministic)):
+            raise ValueError("pass either `options` or the single keywords (fp8_mode / recompute / grad_stream / deterministic), not both")
+        self.options = options.validated() if options is not None else EngineOptions.from_env(fp8=fp8_mode, recompute=recompute, grad_stream=grad_stream,
+                                                                                              deterministic=deterministic)
         # engine.BufferPool: the two passes of the training step (run one after the other) take their activation buffers from the SAME
         # memory - the card holds the larger pass, not the sum.  Opt-in (None: AVSIAM_SHARE_PASS_BUFFERS=1); a combined-loss forward WITH
         # gradients (both passes alive until one backward) is then refused.

@@ -78,6 +78,8 @@ def build_parser():
     parser.add_argument('--recompute', default=None, metavar="FRACTION", help="per-layer activation recompute: 0 | 1 | the share of every stack's leading blocks")
     parser.add_argument('--share-pass-buffers', dest="share_pass_buffers", action="store_true", default=None,
                         help="both passes of the step take their activation buffers from one pool (the card holds the larger pass, not the sum)")
+    parser.add_argument('--deterministic', action="store_true", default=None,
+                        help="bit-reproducible steps (one writer per gradient element, one stream; slower) - for debugging, e.g. the first multi-GPU session")
     parser.add_argument('--depth', default=None, type=int, help="(tests) encoder depth override of the chosen skeleton")
     parser.add_argument('--frames', default=1, type=int, help="frames per sample (extension; reference pre-training uses 1)")
     parser.add_argument('--steps-per-epoch', dest="steps_per_epoch", default=20, type=int, help="synthetic-data epoch length")
@@ -151,7 +153,8 @@ def _run(args, torch, models, AVSiamConfig, SyntheticAVLoader, train):
         print('pretrain a cav-mae model with 11 modality-specific layers and 1 modality-sharing layers')        # :172
     audio_model = getattr(models, cls_name)(audio_length=args.target_length, norm_pix_loss=args.norm_pix_loss,
                                             modality_specific_depth=23, tr_pos=args.tr_pos, opt=args, cfg=cfg,
-                                            fp8_mode=args.fp8, recompute=args.recompute, share_pass_buffers=args.share_pass_buffers)        # :175
+                                            fp8_mode=args.fp8, recompute=args.recompute, share_pass_buffers=args.share_pass_buffers,
+                                            deterministic=args.deterministic)        # :175
     if args.pretrain_path not in ('None', '', None):
         # resume from a checkpoint this loop (or the reference's, traintest_cavmae_base.py:223-234: 'module.'-prefixed keys) wrote - the
         # reference carries the same load commented out (:181-198).  With the fp8 mode the delayed-scaling state saved beside the weights

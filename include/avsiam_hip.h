@@ -39,6 +39,11 @@ int avs_device_cu_count(void);
  *   "nt_big_min" forward / input-gradient GEMMs with at least this many 256 x 256 output tiles run the persistent 256^2 kernels, smaller ones the
  *               128 x 128 kernels; 0 (default) = half the persistent CU slots
  *   "ln_dma" 0 | 1    "ln_rpw" 0 auto | 4 | 8 | 16    "attn_ring" 0 (default) | 1 (attention forward / dQ with K/V tiles by LDS-DMA ring: same bits, not faster)
+ *   "det" 0 (default) | 1: every reduction into a parameter gradient has one writer per element and a fixed order - weight-gradient GEMMs
+ *               without a split of their token rows, column sums / vector-matrix product / LayerNorm slab reduce as one block per column group,
+ *               atomics-free positional scatter and un-shuffle token sums: two runs of a step give the same bits (a debugging mode, slower;
+ *               the reference gets the same from torch.use_deterministic_algorithms).  The host also keeps the step on ONE stream and takes the
+ *               fc1 bias gradient by avs_colsum_bf16 instead of the GEMM epilogue's atomics (EngineOptions.deterministic)
  * avs_persistent_cu_slots(): the CUs a persistent grid fills now (device CUs - cu_reserve). */
 int avs_tuning_set(const char* name, int value);
 int avs_tuning_get(const char* name, int* value);

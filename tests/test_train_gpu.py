@@ -279,3 +279,48 @@ def test_graphed_step_equals_the_eager_step(fp8):
         assert close(oe, og), (oe, og)
     finally:
         pass
+
+
+@pytest.mark.parametrize("fp8", ["0", "3"])
+def test_deterministic_mode_gives_bit_identical_steps(fp8):
+    """EngineOptions.deterministic (what torch.use_deterministic_algorithms is to the reference's loop): every reduction into a
+    parameter gradient has one writer per element and a fixed order - weight-gradient GEMMs without a split of their token rows, bias column sums /
+    the LayerNorm slab reduce / the qkv-bias vector-matrix product as one block per column group, atomics-free positional scatter and un-shuffle token
+    sums, the fc1 bias gradient by the column-sum kernel instead of the GEMM epilogue's atomics, everything on one stream.  Two models from the same
+    seeds, three eager training steps each (device-drawn plans): losses, every weight, both Adam moments BITWISE equal - in bf16 and in fp8 mode 3
+    (whose amax atomics are max-reductions, order-free).  The default mode is what makes two runs differ (atomics order x Adam's sign sensitivity,
+    DESIGN.md 5d item 1): it must agree with the deterministic result to the noise it is known to have, which also checks that the one-writer
+    kernels compute the same sums."""
+    from avsiam_amd import _lib
+    from avsiam_amd.config import EngineOptions
+    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.param_spec import P1, P2
+    from avsiam_amd.traintest_cavmae_base import train_step
+    from avsiam_amd.weights import synth_inputs
+    cfg = AVSiamConfig(audio_tokens=128, frames=2)
+    B = 5
+    a, v = synth_inputs(cfg, B, 17)
+    a, v = a.cuda(), v.cuda()
+
+    def run(det, steps=3, lr=2e-4):
+        m = CAVMAE_BASE(cfg=cfg, init_seed=4, init_mode="random", verbose=False, plan_seed=33, options=EngineOptions(fp8=fp8, deterministic=det)).cuda()
+        m.publish_grads = False
+        outs = [[float(x.item()) for x in train_step(m, a, v, lr)] for _ in range(steps)]
+        torch.cuda.synchronize()
+        return m, outs
+
+    m1, o1 = run(True)
+    m2, o2 = run(True)
+    assert _lib.tuning_get("det") == 0                                  # the knob is set only while a deterministic model's backward is queued
+    assert o1 == o2, (o1, o2)
+    assert torch.equal(m1.arena.p, m2.arena.p) and torch.equal(m1.arena.g, m2.arena.g)
+    for w in (P1, P2):
+        assert torch.equal(m1._opt_state[w]["m"], m2._opt_state[w]["m"]) and torch.equal(m1._opt_state[w]["v"], m2._opt_state[w]["v"])
+    # one step of the default (atomics) mode from the same start at lr = 0 (identical weights in both passes): the same gradients up to summation order
+    md, od = run(False, steps=1, lr=0.0)
+    m3, o3 = run(True, steps=1, lr=0.0)
+    for x, y in zip(od[0][:4], o3[0][:4]):
+        assert abs(x - y) <= 1e-6 * abs(x), (od, o3)                    # losses: the forward has no atomics in either mode
+    g0, g1 = md.arena.g.double(), m3.arena.g.double()
+    rel = float((g0 - g1).norm() / g1.norm())
+    assert rel < (1e-5 if fp8 == "0" else 2e-2), rel                    # (fp8: an amax shard that lands an ulp apart moves a whole tensor's grid)
