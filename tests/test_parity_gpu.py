@@ -402,6 +402,12 @@ FP8_LOSS_RTOL, FP8_LOGITS_ATOL, FP8_COS_MIN, FP8_RATIO_TOL = 5e-3, 0.12, 0.975, 
 # a 1280-element bias of the batch-2 contrastive pass, it moves between runs; >= 0.956 at ViT-B, >= 0.986 in the MAE pass), norm within 30 %
 # (measured <= 11.6 %)  (fp8bwd_oracle_* in the margins file)
 FP8B_COS_MIN, FP8B_RATIO_TOL, FP8B_WHOLE_COS = 0.70, 0.30, 0.985
+# round 6: the per-tensor bounds of modes "2" / "3" per (shape, pass), at <= 3x the measured gap (parity_margins.json fp8bwd_oracle_* /
+# fp8wg_oracle_*); the ViT-H/14 contrastive case runs at batch 5 (one clip per mask-ratio group) instead of 2, where a 1280-element bias was mostly noise
+FP8BW_TOL = {("vit_base", "mae"): (0.95, 0.17), ("vit_base", "contrastive"): (0.86, 0.22), ("vit_huge14", "mae"): (0.95, 0.17),
+             ("vit_huge14", "contrastive"): (0.90, 0.07)}
+# measured worst single tensors: ViT-B MAE 0.984 / 5.6 %, ViT-B contrastive (batch 3) 0.953 / 7.3 %, ViT-H/14 MAE 0.987 / 5.6 %, ViT-H/14 contrastive at batch 5
+# 0.967 / 2.1 % (at batch 2: 0.877 / 11.6 % - the reason round 5 had to allow 0.70 / 30 % everywhere)
 # mode "3" (round 4: the weight gradients on e5m2 gradient x e4m3 activation operands as well): forward as above; the weight-gradient tensors
 # now carry the operands' 2- and 3-bit mantissas directly (each element a sum over the token rows, so the relative error falls with the row
 # count: these test shapes have 500 - 1500 rows, the step's 10^5).  Measured (fp8wg_oracle_* in the margins file): the whole gradient's
@@ -427,10 +433,10 @@ def test_fp8_forward_mode_against_oracle(shape, which, mode):
     from avsiam_amd import engine
     from avsiam_amd.config import vit_huge14
     cfg = vit_huge14(frames=2, depth=2) if shape == "vit_huge14" else AVSiamConfig(audio_tokens=128, frames=2)
-    B = 2 if shape == "vit_huge14" else 3
+    mae = which == "mae"
+    B = (2 if mae else 5) if shape == "vit_huge14" else 3
     a, v = synth_inputs(cfg, B, 41)
     gen = torch.Generator().manual_seed(9)
-    mae = which == "mae"
     plan = make_mae_plan(cfg, B, gen) if mae else make_contrastive_plan(cfg, B, gen, random.Random(9))
     ref, extras, rgrads = _oracle(cfg, a, v, plan, mae, 93)
     if True:
@@ -451,8 +457,8 @@ def test_fp8_forward_mode_against_oracle(shape, which, mode):
                 err = float((eng.total.detach().cpu().double() - extras["logits"].detach().double()).abs().max())
                 record_margin(tag, logits_abs=err)
                 assert err <= FP8_LOGITS_ATOL, err
-            cos_min, ratio_tol, whole = {"1": (FP8_COS_MIN, FP8_RATIO_TOL, None), "2": (FP8B_COS_MIN, FP8B_RATIO_TOL, FP8B_WHOLE_COS),
-                                         "3": (FP8W_COS_MIN, FP8W_RATIO_TOL, FP8W_WHOLE_COS)}[mode]
+            cos_min, ratio_tol, whole = {"1": (FP8_COS_MIN, FP8_RATIO_TOL, None), "2": FP8BW_TOL[(shape, which)] + (FP8B_WHOLE_COS,),
+                                         "3": FP8BW_TOL[(shape, which)] + (FP8W_WHOLE_COS,)}[mode]
             _compare_grads(m, rgrads, cos_min=cos_min, ratio_tol=ratio_tol, tag=tag, whole_cos_min=whole,
                            matrix_cos_min=FP8W_MATRIX_COS_MIN if mode in ("2", "3") else None)
 
@@ -572,8 +578,8 @@ def test_bf16_and_fp8_models_live_side_by_side():
             # (bf16 against the oracle at this batch of 3: the fc2 bias gradients of the last two blocks measure cosine 0.99954 in the contrastive pass -
             #  3 x 3 logits at tau = 0.05; every other case of this file holds 0.9998)
             _compare_grads(m16, rgrads, cos_min=0.9986, ratio_tol=0.025, tag=f"coexist_bf16_{which}_step{step}")
-            _compare_grads(m8, rgrads, cos_min=FP8W_COS_MIN, ratio_tol=FP8W_RATIO_TOL, tag=f"coexist_fp8m3_{which}_step{step}", whole_cos_min=FP8W_WHOLE_COS,
-                           matrix_cos_min=FP8W_MATRIX_COS_MIN)
+            _compare_grads(m8, rgrads, cos_min=FP8BW_TOL[("vit_base", which)][0], ratio_tol=FP8BW_TOL[("vit_base", which)][1], tag=f"coexist_fp8m3_{which}_step{step}",
+                           whole_cos_min=FP8W_WHOLE_COS, matrix_cos_min=FP8W_MATRIX_COS_MIN)
     eng16, eng8 = m16._engine("contrastive", B), m8._engine("contrastive", B)
     assert not eng16.stack.fp8 and eng8.stack.fp8_wgrad
     assert m8.fp8_saturation_events() == 0 and m16.fp8_state() == {}
@@ -654,33 +660,42 @@ def test_vit_huge14_device_drawn_plan():
 D32_BF16_COS_MIN, D32_BF16_RATIO_TOL = 0.9995, 0.03        # measured: worst tensor 0.99984 (a 1280-element LayerNorm bias), norm 1.1 %
 D32_FP8_LOSS_RTOL, D32_FP8_LOGITS_ATOL = 7e-3, 0.14         # measured: 2.2e-3, 0.045
 # fp8 mode 3 at depth 32, batch 2 (measured, profiles/r05/parity_margins.json vit_huge14_depth32_*_fp8m3_*):
-#   whole gradient            cosine 0.9870 (contrastive) / 0.9928 (MAE)                      -> >= 0.975
-#   every MATRIX              cosine >= 0.942 (contrastive: blocks.31.mlp.fc2) / 0.978 (MAE), norm within 3.7 %   -> >= 0.85, within 12 %
-#   the vector tensors, taken together as one vector      cosine 0.976                        -> >= 0.93
-#   a single vector tensor    is mostly noise in the batch-2 contrastive pass (2 x 2 logits): the worst, a 1280-element LayerNorm bias of
-#                             the LAST block, has cosine 0.70 and 1.6 x the norm - held only to cosine >= 0.35, norm within a factor 2.2
-D32_FP8_COS_MIN, D32_FP8_RATIO_TOL, D32_FP8_MATRIX_COS_MIN, D32_FP8_MATRIX_RATIO_TOL, D32_FP8_WHOLE_COS, D32_FP8_VECTORS_COS = 0.35, 1.2, 0.85, 0.12, 0.975, 0.93
+#   whole gradient            cosine 0.9886 (contrastive, batch 5) / 0.9929 (MAE)             -> >= 0.97
+#   every MATRIX              cosine >= 0.974 (contrastive) / 0.979 (MAE), norm within 4 %    -> >= 0.92, within 12 %
+#   the vector tensors, taken together as one vector      cosine 0.989 / 0.992                -> >= 0.97
+#   a single vector tensor    D32_FP8_VEC below (round 5 ran the contrastive pass at batch 2, where a 1280-element bias of the LAST block was mostly
+#                             noise - cosine 0.70, 1.6 x the norm - and could only be held to 0.35 / a factor 2.2)
+D32_FP8_MATRIX_COS_MIN, D32_FP8_MATRIX_RATIO_TOL, D32_FP8_WHOLE_COS, D32_FP8_VECTORS_COS = 0.92, 0.12, 0.97, 0.97
+# round 6: every single VECTOR tensor (1280-element biases / LayerNorm vectors) gets a bound of its own, per pass, at <= 3x the measured
+# gap (parity_margins.json vit_huge14_depth32_*_fp8m3_*): (cosine floor, norm ratio tolerance).  The contrastive pass runs at batch 5 for that.
+D32_CONTRASTIVE_BATCH = 5
+D32_FP8_VEC = {"mae": (0.93, 0.15), "contrastive": (0.86, 0.18)}         # measured: MAE 0.976 / 4.6 % (blocks.0.norm2_v.weight), contrastive at batch 5: 0.952 / 6.0 %
+                                                                         # (blocks.31.mlp.fc1.bias; 0.70 / 62 % at batch 2).  Oracle wall time: 16 s on the box's 16 cores
 
 
 def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():
     import gc
     import random
-    from avsiam_amd import engine
+    import time
     from avsiam_amd.config import vit_huge14
-    from avsiam_amd.models import CAVMAE_BASE
+    from avsiam_amd.models import CAVMAE_HUGE
     from oracle import ref_cpu
     cfg = vit_huge14(frames=1)
     assert cfg.depth == 32 and cfg.embed_dim == 1280 and cfg.head_dim == 80
-    B = 2
-    a, v = synth_inputs(cfg, B, 43)
+    # the MAE pass at batch 2; the contrastive pass at batch D32_CONTRASTIVE_BATCH (one clip per mask-ratio group, 5 x 5 logits): at batch 2 its 2 x 2
+    # logits leave a single 1280-element bias gradient mostly noise in fp8 (cosine 0.70 - round 5), which no per-tensor bound can be built on
+    batches = {"mae": 2, "contrastive": D32_CONTRASTIVE_BATCH}
     gen = torch.Generator().manual_seed(10)
-    plans = {"mae": make_mae_plan(cfg, B, gen), "contrastive": make_contrastive_plan(cfg, B, gen, random.Random(10))}
-    m = CAVMAE_BASE(cfg=cfg, init_seed=91, init_mode="random", verbose=False).cuda()       # (the 1.3 G-parameter synthesis: once)
+    data = {w: synth_inputs(cfg, B, 43) for w, B in batches.items()}
+    plans = {"mae": make_mae_plan(cfg, batches["mae"], gen), "contrastive": make_contrastive_plan(cfg, batches["contrastive"], gen, random.Random(10))}
+    m = CAVMAE_HUGE(cfg=cfg, init_seed=91, init_mode="random", verbose=False).cuda()       # (the 1.3 G-parameter synthesis: once)
     live = [info.name for info in build_spec(cfg) if info.live]
     torch.set_num_threads(16)
     refs = {}
+    t0 = time.time()
     for which, plan in plans.items():
         mae = which == "mae"
+        a, v = data[which]
         P = {k: m._params[k].detach().cpu().clone().requires_grad_(True) for k in live}
         extras = {}
         out = ref_cpu.forward(P, cfg, a, v, plan, mae_loss_weight=1 if mae else 0, contrast_loss_weight=0 if mae else 1, extras=extras)
@@ -688,11 +703,14 @@ def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():
         refs[which] = ([float(o.item()) for o in out[:5]], extras.get("logits"), {k: p.grad for k, p in P.items()})
         del P, out
         gc.collect()
+    record_margin("vit_huge14_depth32_oracle", wall_seconds=time.time() - t0, batches=str(batches))
     try:
         for mode in ("0", "3"):
             m.set_options(fp8=mode)                      # a structural option: the pass engines are rebuilt for the mode
             for which, plan in plans.items():
                 mae = which == "mae"
+                a, v = data[which]
+                B = batches[which]
                 ref, logits, rgrads = refs[which]
                 for step in ((0,) if mode == "0" else (0, 1)):       # fp8: the calibration step and the step on delayed scales
                     for p in m._params.values():                     # (.grad views of the arena outlive a pass: the other pass's are not this one's)
@@ -711,7 +729,8 @@ def test_vit_huge14_depth32_matches_oracle_in_bf16_and_fp8_mode3():
                     if mode == "0":
                         _compare_grads(m, rgrads, cos_min=D32_BF16_COS_MIN, ratio_tol=D32_BF16_RATIO_TOL, tag=tag)
                     else:
-                        _compare_grads(m, rgrads, cos_min=D32_FP8_COS_MIN, ratio_tol=D32_FP8_RATIO_TOL, tag=tag, whole_cos_min=D32_FP8_WHOLE_COS,
+                        cmin, rtol = D32_FP8_VEC[which]
+                        _compare_grads(m, rgrads, cos_min=cmin, ratio_tol=rtol, tag=tag, whole_cos_min=D32_FP8_WHOLE_COS,
                                        matrix_cos_min=D32_FP8_MATRIX_COS_MIN, matrix_ratio_tol=D32_FP8_MATRIX_RATIO_TOL,
                                        vectors_cos_min=D32_FP8_VECTORS_COS)
             if mode == "3":
