@@ -29,6 +29,9 @@
 #include <type_traits>
 
 #define LDS_AS __attribute__((address_space(3)))
+#ifndef ATTN_MFMA_ROWSUM
+#define ATTN_MFMA_ROWSUM 0          // 1: diagnostic builds only (attn_fwd_kernel)
+#endif
 
 template <int HD>
 struct Img {                                   // LDS image of a [rows][HD] bf16 tile
@@ -292,6 +295,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
     constexpr float LAZY_SUM = 1099511627776.0f;
     float m_run = 0.f, l_run = 0.f;
     f32x16 negm = splat16(0.f);
+#if ATTN_MFMA_ROWSUM
+    // DIAGNOSTIC build only (tools/ab_lib.sh with AVSIAM_HIPCC_EXTRA=-DATTN_MFMA_ROWSUM=1): the row sum of P on the matrix pipe - one
+    // extra product per 16-key step with an all-ones A operand (every row of the result is sum_k P[k][q]) - instead of 32 VALU adds per tile.  No
+    // lazy-rescale detector in this form (it would need the sum before the P.V products): timing on random data only.
+    f32x16 lsum = splat16(0.f);
+    const bf16x8 ones = {(bf16_t)0x3F80, (bf16_t)0x3F80, (bf16_t)0x3F80, (bf16_t)0x3F80, (bf16_t)0x3F80, (bf16_t)0x3F80, (bf16_t)0x3F80, (bf16_t)0x3F80};
+#endif
 
     TileRegs<HD, NTH> rk, rv;
     TileOff<HD, NTH> toff;
@@ -352,8 +362,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; r += 2) {
                     p[kb][r] = fast_exp2(s[kb][r]);
                     p[kb][r + 1] = fast_exp2(s[kb][r + 1]);
+#if !ATTN_MFMA_ROWSUM
                     ps0 = add1(ps0, p[kb][r]);
                     ps1 = add1(ps1, p[kb][r + 1]);
+#endif
                 }
             psum = ps0 + ps1;
         };
@@ -404,10 +416,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int d = 0; d < NDB; ++d)
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sV, kb * 32 + 16 * st, d, lane), pf, o[d], 0, 0, 0);
+#if ATTN_MFMA_ROWSUM
+                lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lsum, 0, 0, 0);
+#endif
             }
     }
     if (!active) return;
+#if ATTN_MFMA_ROWSUM
+    const float l_tot = lsum[0];
+#else
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+#endif
     const float inv = 1.0f / l_tot;
     const int qq = qw + (lane & 31);
     float omax = 0.f;

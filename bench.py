@@ -304,19 +304,28 @@ def secondary_shapes(args, dev):
     from avsiam_amd.traintest_cavmae_base import train_step
     from avsiam_amd.weights import synth_inputs
     out = []
-    for label, kw, B in (("C2 under the reference's one-frame semantics: batch 64, 1 frame x196 + 512 audio tokens", {"frames": 1, "audio_tokens": 512}, 64),
-                         ("reference launch geometry: batch 4 per GPU, 1 frame x196 + 512 audio tokens (run_pretrain_base.sh:30-31)", {"frames": 1, "audio_tokens": 512}, 4),
-                         ("C1: BASELINE configs[0], batch 4, 1 frame x196 + 128 audio tokens", {"frames": 1, "audio_tokens": 128}, 4)):
-        cfg = AVSiamConfig(**kw)
+    from avsiam_amd.config import vit_huge14
+    shapes = [("C2 under the reference's one-frame semantics: batch 64, 1 frame x196 + 512 audio tokens", AVSiamConfig(frames=1, audio_tokens=512), 64, {}),
+              ("reference launch geometry: batch 4 per GPU, 1 frame x196 + 512 audio tokens (run_pretrain_base.sh:30-31)", AVSiamConfig(frames=1, audio_tokens=512), 4, {}),
+              ("C1: BASELINE configs[0], batch 4, 1 frame x196 + 128 audio tokens", AVSiamConfig(frames=1, audio_tokens=128), 4, {})]
+    if args.secondary_huge:
+        # BASELINE.json configs[4] on ONE GPU, driver-timed: models.CAVMAE_HUGE, fp8 mode 3 (e4m3 forward, e5m2 x e4m3 input and weight
+        # gradients), both passes from one activation pool, nothing recomputed; 2 warm-up steps (the first calibrates the scales) + 3 timed
+        shapes.append(("configs[4] on one GPU: ViT-H/14 (models.CAVMAE_HUGE), fp8 mode 3, batch 64, 10 frames x256 + 657 audio tokens, one activation pool",
+                       vit_huge14(frames=10), 64, {"fp8_mode": "3", "share_pass_buffers": True, "steps": 3, "warm": 2, "cls": "CAVMAE_HUGE"}))
+    for label, cfg, B, kw in shapes:
         try:
-            m = CAVMAE_BASE(cfg=cfg, verbose=False, plan_seed=87).to(dev)
+            import avsiam_amd.models as _models
+            nsteps, nwarm = kw.get("steps", args.secondary_steps), kw.get("warm", 3)
+            m = getattr(_models, kw.get("cls", "CAVMAE_BASE"))(cfg=cfg, verbose=False, plan_seed=87, fp8_mode=kw.get("fp8_mode"),
+                                                               share_pass_buffers=kw.get("share_pass_buffers")).to(dev)
             m.publish_grads = False
             a, v = synth_inputs(cfg, B, 87)
             a, v = a.to(dev), v.to(dev)
             gf = gflop_per_sample(cfg, B)
 
-            def timed(step_fn, n):
-                for _ in range(3):
+            def timed(step_fn, n, warm=3):
+                for _ in range(warm):
                     step_fn()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -325,9 +334,14 @@ def secondary_shapes(args, dev):
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t0) / n
 
-            dt = timed(lambda: train_step(m, a, v, args.lr), args.secondary_steps)
-            rec = {"workload": label, "batch": B, "frames": 1, "audio_tokens": cfg.audio_tokens, "value": B / dt, "unit": "samples/s",
-                   "ms_per_step": 1e3 * dt, "gflop_per_sample": gf, "mfu": B / dt * gf / 1e3 / PEAK_BF16_TFLOPS, "steps": args.secondary_steps}
+            dt = timed(lambda: train_step(m, a, v, args.lr), nsteps, nwarm)
+            rec = {"workload": label, "batch": B, "frames": cfg.frames, "audio_tokens": cfg.audio_tokens, "value": B / dt, "unit": "samples/s",
+                   "ms_per_step": 1e3 * dt, "gflop_per_sample": gf, "mfu": B / dt * gf / 1e3 / PEAK_BF16_TFLOPS, "steps": nsteps, "warmup": nwarm,
+                   "dtype": "bf16" if not kw.get("fp8_mode") else "fp8 mode " + kw["fp8_mode"]}
+            if kw.get("fp8_mode"):
+                rec["mfu_note"] = "model FLOP rate against the dense BF16 peak (2.5 PFLOP/s), as every other `mfu` of this line; the fp8 GEMM launches are priced against 5 PFLOP/s by `bench.py --model vit_huge14 --fp8 --fp8-wgrad` (roofline_fp8)"
+                rec["fp8_saturation_events"] = float(m.fp8_saturation_events())
+                rec["peak_memory_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
             if B <= 8:
                 try:
                     from avsiam_amd.graph_step import GraphedTrainStep
@@ -394,6 +408,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--secondary-steps", type=int, default=10, help="timed steps of each reference-native shape measured after the timed region "
                     "(`secondary` in the line: one frame at batch 64, and BASELINE configs[0] = batch 4 / one frame / 128 audio tokens); 0 = skip")
+    ap.add_argument("--no-secondary-huge", dest="secondary_huge", action="store_false",
+                    help="skip the ViT-H/14 fp8 mode-3 line of `secondary` (BASELINE configs[4] on one GPU: ~190 GiB, ~1 minute)")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="HIP-event timing of every kernel family (default: the dominant kernel, gemm_nt, only - each timed "
                          "launch costs the stream ~5 us)")
@@ -571,10 +587,22 @@ def main():
     # the headline workload's peak, read BEFORE the secondary shapes build their own models beside this one (the figure used to
     # include them - 106 GiB reported for a 79.8 GiB step)
     peak_gib = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+    losses = [float(x.item()) for x in last]
+    # everything the line says about the headline model is read NOW: the model and its activations are dropped before the secondary shapes
+    # (the ViT-H/14 fp8 line alone needs ~190 GiB of the card)
+    minfo = {"options": model.options.describe(), "grad_stream": model.options.grad_stream, "fp8_lean": model.options.fp8_lean, "dp_wire": model.dp_wire,
+             "defer_p2": bool(model.defer_p2), "last_reduce_messages": model.last_reduce_messages,
+             "pool": ({"share_pass_buffers": True, "activation_pool_gib": round(model._pool.nbytes() / 2 ** 30, 2),
+                       "activation_pool_live_gib_last_pass": round(model._pool.used() / 2 ** 30, 2)} if args.share_pass_buffers and model._pool is not None else {})}
     secondary = None
     if world == 1 and not args.force_dp and args.secondary_steps > 0 and args.model == "vit_base" and not (args.fp8 or args.recompute):
+        import gc
+        model.release_buffers()
+        model = last = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
         secondary = secondary_shapes(args, dev)
-    losses = [float(x.item()) for x in last]
     if rank == 0:
         sps = world * args.batch * args.steps / dt
         gf = gflop_per_sample(cfg, args.batch)
@@ -586,27 +614,26 @@ def main():
                                    f"{cfg.audio_tokens} audio tokens, 75% mask, batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "frames": args.frames, "audio_tokens": cfg.audio_tokens,
                        "parallelism": f"dp{world}", "gflop_per_sample": gf,
-                       "residual_gradient_stream": model.options.grad_stream,   # bf16 (default) | fp32
-                       "options": model.options.describe(),
+                       "residual_gradient_stream": minfo["grad_stream"],   # bf16 (default) | fp32
+                       "options": minfo["options"],
                        # what the collective library itself reports: the size of the process group the step's collectives ran in
                        **({"collectives": {"backend": dist.get_backend(), "library": "gloo, staged through the host (rehearsal)" if share else "RCCL (torch.distributed 'nccl' on ROCm)", "group_world_size": dist.get_world_size(),
-                                           "comm": "host-staged" if share else os.environ.get("AVSIAM_COMM", "torch"), "allreduce_messages_last_backward": model.last_reduce_messages,
+                                           "comm": "host-staged" if share else os.environ.get("AVSIAM_COMM", "torch"), "allreduce_messages_last_backward": minfo["last_reduce_messages"],
                                            # what the first scaling line has to say about itself: CUs every persistent kernel leaves to the
                                            # collectives, whether the gradient all-reduce overlaps the backward, and what travels on xGMI
                                            "cu_reserve": _lib.tuning_get("cu_reserve"), "persistent_cu_slots": _lib.load().avs_persistent_cu_slots(),
                                            "gradient_allreduce": ("chunked, overlapped with the backward (AVSIAM_DP_OVERLAP=1)" if os.environ.get("AVSIAM_DP_OVERLAP", "1") != "0"
                                                                   else "one blocking message after the backward (AVSIAM_DP_OVERLAP=0)"),
-                                           "wire_format": model.dp_wire, "defer_mae_only_update": bool(model.defer_p2),
+                                           "wire_format": minfo["dp_wire"], "defer_mae_only_update": minfo["defer_p2"],
                                            "embedding_allgather": "one packed [2, B, D] fp32 message per rank and step"}}
                           if (world > 1 or args.force_dp) else {}), **({"activation_recompute": True if args.recompute == "1" else float(args.recompute)} if args.recompute else {}),
-                       **({"fp8_8bit_only_outputs": model.options.fp8_lean} if args.fp8_wgrad else {}),
+                       **({"fp8_8bit_only_outputs": minfo["fp8_lean"]} if args.fp8_wgrad else {}),
                        "peak_memory_gib": peak_gib,
-                       **({"share_pass_buffers": True, "activation_pool_gib": round(model._pool.nbytes() / 2 ** 30, 2),
-                           "activation_pool_live_gib_last_pass": round(model._pool.used() / 2 ** 30, 2)} if args.share_pass_buffers and model._pool is not None else {}),
+                       **minfo["pool"],
                        **({"rehearsal": "AVSIAM_BENCH_SHARE_GPU=1: all ranks on ONE GPU, gloo + host-staged collectives - not a throughput figure"} if share else {}),
                        **({"force_dp": {"comm": os.environ.get("AVSIAM_COMM", "torch"), "wire": os.environ.get("AVSIAM_DP_WIRE", "fp32"),
                                         "overlap": os.environ.get("AVSIAM_DP_OVERLAP", "1"), "defer_mae_only": os.environ.get("AVSIAM_DP_DEFER", "0"),
-                                        "allreduce_messages_last_backward": model.last_reduce_messages}}
+                                        "allreduce_messages_last_backward": minfo["last_reduce_messages"]}}
                           if args.force_dp else {})},
             "model_tflops": sps * gf / 1e3, "mfu_vs_dense_bf16_peak": sps * gf / 1e3 / (world * PEAK_BF16_TFLOPS),
             "final_losses": {"loss_mae": losses[0], "loss_mae_a": losses[1], "loss_mae_v": losses[2], "loss_c": losses[3], "c_acc": losses[4]},
