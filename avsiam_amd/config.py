@@ -124,6 +124,9 @@ class EngineOptions:
     grad_stream   "bf16" | "fp32": the residual-GRADIENT stream between the blocks of a stack                                     [structural]
     attn_tile     0 automatic | 64 | 128: rows per attention workgroup (A/B)                                                      [structural]
     attn_fused    sequences of at most 128 tokens take the single-workgroup attention backward                                    [structural]
+    attn_fused224 ... and those of 129 .. 224 tokens at head dim 64 the 7-wave form (round 6: bitwise-tested, measured 2 % SLOWER than the
+                  two-kernel form on the contrastive mix - one 142-KB workgroup per CU serialises load / phase 1 / phase 2 - so OFF by default;
+                  profiles/r06/attn_fused224_ab.log)                                                                              [structural]
     group_towers  the MAE pass's audio and visual towers as one packed stack with two weight sets per launch                      [structural]
     prune_dead    pass 2 skips the rows whose loss and gradient are identically zero: prediction heads and their backward on MASKED
                   rows only; in the last decoder block query / proj / LN2 / MLP / decoder_norm on masked rows only (K, V for all)     [structural]
@@ -142,17 +145,18 @@ class EngineOptions:
     grad_stream: str = "bf16"
     attn_tile: int = 0
     attn_fused: bool = True
+    attn_fused224: bool = False
     group_towers: bool = True
     prune_dead: bool = True
     wgrad_stream: str = "2"
     wgrad_group: bool = True
     deterministic: bool = False
 
-    STRUCTURAL = ("fp8", "fp8_lean", "fp8_gelu8", "gelu8", "recompute", "grad_stream", "attn_tile", "attn_fused", "group_towers", "prune_dead")
+    STRUCTURAL = ("fp8", "fp8_lean", "fp8_gelu8", "gelu8", "recompute", "grad_stream", "attn_tile", "attn_fused", "attn_fused224", "group_towers", "prune_dead")
 
     _ENV = {"fp8": ("AVSIAM_FP8", str), "fp8_lean": ("AVSIAM_FP8_LEAN", "flag"), "fp8_gelu8": ("AVSIAM_FP8_GELU8", "flag"), "gelu8": ("AVSIAM_GELU8", "flag"),
             "recompute": ("AVSIAM_RECOMPUTE", str), "grad_stream": ("AVSIAM_GRAD_STREAM", str), "attn_tile": ("AVSIAM_ATTN_TILE", int),
-            "attn_fused": ("AVSIAM_ATTN_FUSED", "flag"), "group_towers": ("AVSIAM_GROUP_TOWERS", "flag"), "prune_dead": ("AVSIAM_PRUNE_DEAD", "flag"),
+            "attn_fused": ("AVSIAM_ATTN_FUSED", "flag"), "attn_fused224": ("AVSIAM_ATTN_FUSED224", "flag"), "group_towers": ("AVSIAM_GROUP_TOWERS", "flag"), "prune_dead": ("AVSIAM_PRUNE_DEAD", "flag"),
             "wgrad_stream": ("AVSIAM_WGRAD_STREAM", str), "wgrad_group": ("AVSIAM_WGRAD_GROUP", "flag"), "deterministic": ("AVSIAM_DETERMINISTIC", "flag")}
 
     @classmethod

@@ -1283,6 +1283,154 @@ __global__ __launch_bounds__(64 * NW, (HD == 64 && NW == 2 && G8) ? 3 : 1) void 
     if (G8) q_amax_update(a.qd8, g8max, g8seen);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same fusion for sequences of 129 .. 224 tokens at head dim 64 (round 6: the encoder's 156 / 196-token frame sequences and 204-token audio
+// sequences - two thirds of the contrastive pass's rows, which the two-kernel form read twice and exponentiated twice).  Seven waves; wave w
+// owns keys 32w.. in phase 1 and queries 32w.. in phase 2, as above.  A [224][224] dS image would not fit beside the Q / dO / K images
+// (3 x 28 KB), so the queries are taken in two HALVES of 128: phase 1 over the half's query blocks (dK^T / dV^T keep accumulating in
+// registers) drops its dS tiles into a [224 keys][128 queries] image, phase 2 runs on the waves whose query block lies in that half
+// (waves 0-3, then 4-6: every wave forms dQ for its 32 queries exactly once), then the image is reused.  K has an image of its own
+// (the Q image is still read by the second half).  142 KB of LDS: one workgroup per CU.  Same products in the same order as the
+// two-kernel form for every (sequence, head).
+__global__ __launch_bounds__(448, 1) void attn_bwd_fused224_kernel(AttnArgs a) {
+    constexpr int HD = 64, R = 224, QH = 128;
+    constexpr int NKK = HD / 16, NDB = HD / 32;
+    constexpr int IMG = R * HD * 2;                       // bytes of a [R][HD] bf16 image
+    extern __shared__ __attribute__((aligned(16))) char smem_f224[];
+    char* sQ = smem_f224;
+    char* sDO = smem_f224 + IMG;
+    char* sK = smem_f224 + 2 * IMG;
+    char* sDS = smem_f224 + 3 * IMG;                      // [key][query of the half] bf16, Img<QH>
+    float* sLse = reinterpret_cast<float*>(smem_f224 + 3 * IMG + R * QH * 2);
+    float* sDel = sLse + R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int head = blockIdx.x / a.ntiles, tix = blockIdx.x - head * a.ntiles;
+    const int seq0 = a.tile_start[tix], L = a.tile_len[tix];
+    const int rl = 32 * wave + (lane & 31);               // this lane's row of the images: its key (phase 1) and its query (phase 2)
+    const int row = min(rl, L - 1);
+    const bool active = 32 * wave < L;
+    const bf16_t* qp = a.qkv + (size_t)(seq0 + row) * a.ld + head * HD;
+    const bf16_t* dop = a.dout + (size_t)(seq0 + row) * a.ldo + head * HD;
+    const bf16_t* op = a.out + (size_t)(seq0 + row) * a.ldo + head * HD;
+
+    bf16x8 kf[NKK], vf[NKK];
+    {
+        bf16x8 qv[NKK], dov[NKK], ov[NKK];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const int c = (2 * kk + hh) * 8;
+            qv[kk] = *reinterpret_cast<const bf16x8*>(qp + c);
+            kf[kk] = *reinterpret_cast<const bf16x8*>(qp + a.D + c);
+            vf[kk] = *reinterpret_cast<const bf16x8*>(qp + 2 * a.D + c);
+            dov[kk] = *reinterpret_cast<const bf16x8*>(dop + c);
+            ov[kk] = *reinterpret_cast<const bf16x8*>(op + c);
+        }
+        float dpart = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            *reinterpret_cast<bf16x8*>(sQ + Img<HD>::off(rl, 2 * kk + hh)) = qv[kk];
+            *reinterpret_cast<bf16x8*>(sDO + Img<HD>::off(rl, 2 * kk + hh)) = dov[kk];
+            *reinterpret_cast<bf16x8*>(sK + Img<HD>::off(rl, 2 * kk + hh)) = kf[kk];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dpart += bf2f((bf16_t)dov[kk][j]) * bf2f((bf16_t)ov[kk][j]);
+        }
+        const float delta = dpart + __shfl_xor(dpart, 32, 64);
+        if (hh == 0) {
+            sLse[rl] = -a.lse[(size_t)head * a.rows_total + seq0 + row] * 1.4426950408889634f;       // negated: MFMA C operands
+            sDel[rl] = -delta;
+        }
+    }
+    __syncthreads();
+
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+    const bool key_tail = 32 * wave + 32 > L;              // wave-uniform: some of this wave's keys lie beyond the sequence
+    const bool key_dead = rl >= L;
+    for (int h = 0; h * QH < L; ++h) {                      // the queries, 128 at a time
+        if (active) {
+            for (int qb = 4 * h; qb < 4 * h + 4 && qb * 32 < L; ++qb) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rb = qb * 32 + 8 * t + 4 * hh;
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + rb);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDel + rb);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s[4 * t + j] = l4[j]; dp[4 * t + j] = d4[j]; }
+                }
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sQ, qb * 32, kk, lane), kf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(sDO, qb * 32, kk, lane), vf[kk], dp, 0, 0, 0);
+                }
+                if (qb * 32 + 32 > L || key_tail) {
+                    // real branch (the empty asm blocks if-conversion): only blocks touching the end of the sequence pay for masking
+                    asm volatile("; sequence end: mask" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (key_dead || qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -INFINITY;      // -> p = exp2(-inf) = 0
+                }
+                float p[16], ds[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = fast_exp2(s[r]);
+                    ds[r] = p[r] * dp[r];
+                }
+                // dS for phase 2: rows 8t + 4hh .. +3 of this query block are 4 consecutive columns of the lane's key row (columns of the HALF)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint2 w;
+                    w.x = pack_bf2(ds[4 * t + 0], ds[4 * t + 1]);
+                    w.y = pack_bf2(ds[4 * t + 2], ds[4 * t + 3]);
+                    *reinterpret_cast<uint2*>(sDS + Img<QH>::off(rl, (qb - 4 * h) * 4 + t) + 8 * hh) = w;
+                }
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const bf16x8 pf = acc_frag(&p[8 * st]);
+                    const bf16x8 dsf = acc_frag(&ds[8 * st]);
+#pragma unroll
+                    for (int d = 0; d < NDB; ++d) {
+                        dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sDO, qb * 32 + 16 * st, d, lane), pf, dv[d], 0, 0, 0);
+                        dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sQ, qb * 32 + 16 * st, d, lane), dsf, dk[d], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                   // the half's dS tiles are written
+        if (active && (wave >> 2) == h) {                  // this wave's 32 queries lie in this half: dQ^T += K^T . dS^T over every key
+            f32x16 dq[NDB];
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+            for (int ks = 0; ks * 16 < L; ++ks) {
+                const bf16x8 dsf = tr_frag<QH>(sDS, 16 * ks, wave & 3, lane);       // B operand: k = keys 16ks.., n = this wave's queries
+#pragma unroll
+                for (int d = 0; d < NDB; ++d)
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sK, 16 * ks, d, lane), dsf, dq[d], 0, 0, 0);
+            }
+            if (rl < L) {
+                bf16_t* qrow = a.dqkv + (size_t)(seq0 + rl) * a.ld + head * HD;
+                float unused = 0.f;
+#pragma unroll
+                for (int d = 0; d < NDB; ++d) store_block<HD, true>(qrow, d, hh, dq[d], a.scale, nullptr, 0.f, unused);
+            }
+        }
+        __syncthreads();                                   // ... and read: the next half may overwrite the image
+    }
+    if (!active || rl >= L) return;
+    bf16_t* krow = a.dqkv + (size_t)(seq0 + rl) * a.ld + a.D + head * HD;
+    float unused = 0.f;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) {
+        store_block<HD, true>(krow, d, hh, dk[d], LN2, nullptr, 0.f, unused);      // dK = dS^T . (q * scale), the staged q is q * scale * log2(e)
+        store_block<HD, true>(krow + a.D, d, hh, dv[d], 1.0f, nullptr, 0.f, unused);
+    }
+}
+
 // ===================================================================================================
 static int check_common(const char* name, const void* qkv, long long ld, int D, int H, int hd, const int* ts, const int* tl,
                         const int* tq, int ntiles) {
@@ -1423,14 +1571,29 @@ extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int
                                      bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, hipStream_t stream) {
     AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd_fused: kv_bf16 = 0 needs the e5m2 copy");
     AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 16) == 0)), "attn_bwd_fused: dqkv8 and its record go together, ld8 %% 16 == 0");
-    AVS_CHECK_ARG(rows_per_wg == 64 || rows_per_wg == 128, "attn_bwd_fused: rows_per_wg must be 64 or 128");
+    AVS_CHECK_ARG(rows_per_wg == 64 || rows_per_wg == 128 || rows_per_wg == 224, "attn_bwd_fused: rows_per_wg must be 64, 128 or 224");
     const int hd = H > 0 ? D / H : 0;
     AVS_CHECK_ARG(qkv && seq_start && seq_len && nseq > 0 && H > 0 && (hd == 32 || hd == 64) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0,
                   "attn_bwd_fused: bad arguments (D=%d H=%d hd=%d ld=%lld nseq=%d)", D, H, hd, ld, nseq);
     AVS_CHECK_ARG(out && dout && lse && dqkv && (ldo % 8) == 0, "attn_bwd_fused: null pointer");
+    AVS_CHECK_ARG(rows_per_wg != 224 || (hd == 64 && !dqkv8), "attn_bwd_fused: 224-row workgroups exist for head dim 64 without the e5m2 copy");
     AttnArgs a{qkv, ld, D, seq_start, seq_len, nullptr, nseq, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
                dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16, 0};
     dim3 grid(nseq * H);
+    if (rows_per_wg == 224) {
+        constexpr int SMEM224 = 3 * 224 * 64 * 2 + 224 * 128 * 2 + 2 * 224 * 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void*)attn_bwd_fused224_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM224) != hipSuccess) {
+                avs_set_error("attn_bwd_fused: cannot reserve %d bytes of LDS", SMEM224);
+                return -1;
+            }
+            attr_done = true;
+        }
+        attn_bwd_fused224_kernel<<<grid, 448, SMEM224, stream>>>(a);
+        AVS_LAUNCH_CHECK("attn_bwd_fused224");
+        return 0;
+    }
 #define ATTN_BWDF(G)                                                                                        \
     do {                                                                                                    \
         if (rows_per_wg == 128) {                                                                           \

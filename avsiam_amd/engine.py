@@ -303,6 +303,7 @@ class Stack:
                 self._pads.add(t[rows:])
             return t
         self.rows, self.D, self.H, self.hidden, self.nblocks = rows, D, H, hidden, nblocks
+        self.lq = 0                             # (set below when the pruned last block applies)
         self.row_mod = row_mod
         self.inference = inference
         self.nrecomp = 0 if inference else recompute_blocks(nblocks, opts.recompute)     # blocks [0, nrecomp) keep no activations (one shared set)
@@ -367,6 +368,13 @@ class Stack:
             cut = 128 if (opts.attn_fused and D // H in (32, 64)) else 0
             if cut:
                 self.fused_bwd = [sq for sq in (ops.AttnSeqs(seq_lens, dev, 0, 64), ops.AttnSeqs(seq_lens, dev, 64, 128)) if sq.nseq]
+                # round 6: sequences of 129 .. 224 tokens at head dim 64 (the encoder's 156 / 196-token frames, 204-token audio) in one 7-wave workgroup
+                # per (sequence, head) whose dS image holds the queries in two halves (attn_bwd_fused224_kernel); not with the e5m2 copy of dqkv
+                if D // H == 64 and not self.fp8_bwd and opts.attn_fused224:
+                    big = ops.AttnSeqs(seq_lens, dev, 128, 224)
+                    if big.nseq:
+                        self.fused_bwd.append(big)
+                        cut = 224
             long_lens = [L for L in seq_lens if L > cut]
             mean_long = sum(long_lens) / max(1, len(long_lens))
             self.tiles_bwd = ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_long < 256 else 128), min_len=cut)

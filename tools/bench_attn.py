@@ -74,6 +74,19 @@ def run_case(name, H, hd, lens, dev, tile_rows=(128, 64)):
                 ops.attn_bwd_fused(qkv, sq, H, out, dout, lse, dqkv)
         tm = timeit(mixed, 10)
         msg += f"  [fused<=128] bwd {tm*1e6:7.1f} us"
+        if hd == 64 and any(128 < L <= 224 for L in lens):
+            # round 6: sequences of 129 .. 224 tokens through the 7-wave fused kernel as well (what the engine runs now)
+            f2 = f + [ops.AttnSeqs(lens, dev, 128, 224)]
+            ll = [L for L in lens if L > 224]
+            tl2 = ops.AttnTiles(lens, dev, tile_rows=64 if sum(ll) / max(1, len(ll)) < 256 else 128, min_len=224)
+
+            def mixed2():
+                if tl2.ntiles:
+                    ops.attn_bwd(qkv, tl2, H, out, dout, lse, delta, dqkv)
+                for sq in f2:
+                    ops.attn_bwd_fused(qkv, sq, H, out, dout, lse, dqkv)
+            tm2 = timeit(mixed2, 10)
+            msg += f"  [fused<=224] bwd {tm2*1e6:7.1f} us"
     print(msg, flush=True)
 
 
