@@ -131,7 +131,8 @@ class EngineOptions:
     prune_dead    pass 2 skips the rows whose loss and gradient are identically zero: prediction heads and their backward on MASKED
                   rows only; in the last decoder block query / proj / LN2 / MLP / decoder_norm on masked rows only (K, V for all)     [structural]
     wgrad_stream  "2" weight gradients on a second stream beside attention / LayerNorm backward | "1" beside everything | "0" one
-                  stream                                                                                                          [runtime]
+                  stream | "auto" (default): "2" for stacks of at least 32 768 packed rows (the headline shape: every stack), "1" below - the
+                  reference's one-frame shapes, whose forward / input-gradient GEMMs leave partial rounds for them to fill (+0.9 % at batch 64)      [runtime]
     wgrad_group   a block's fc2 / fc1 / proj weight gradients in one launch                                                       [runtime]
     deterministic weight gradients with ONE writer per output tile and an ordered contraction (no split over the token rows, no
                   cross-workgroup atomics), everything on one stream: two runs of a step are bit-identical.  For debugging (the
@@ -148,7 +149,7 @@ class EngineOptions:
     attn_fused224: bool = False
     group_towers: bool = True
     prune_dead: bool = True
-    wgrad_stream: str = "2"
+    wgrad_stream: str = "auto"
     wgrad_group: bool = True
     deterministic: bool = False
 
@@ -181,8 +182,8 @@ class EngineOptions:
             raise ValueError(f"recompute must be 0, 1 or a fraction between them, not {self.recompute!r}")
         if self.grad_stream not in ("bf16", "fp32"):
             raise ValueError(f"grad_stream must be bf16 or fp32, not {self.grad_stream!r}")
-        if self.wgrad_stream not in ("0", "1", "2"):
-            raise ValueError(f"wgrad_stream must be 0, 1 or 2, not {self.wgrad_stream!r}")
+        if self.wgrad_stream not in ("0", "1", "2", "auto"):
+            raise ValueError(f"wgrad_stream must be 0, 1, 2 or auto, not {self.wgrad_stream!r}")
         if self.attn_tile not in (0, 64, 128):
             raise ValueError(f"attn_tile must be 0, 64 or 128, not {self.attn_tile!r}")
         return self

@@ -656,6 +656,8 @@ class Stack:
         # (a partially recomputed stack - engine.RECOMPUTE a fraction - uses the second stream for the blocks that keep their own buffers and
         #  joins it in front of the first recomputed block, see the loop)
         mode = "0" if (self.nrecomp >= self.nblocks or self.opts.deterministic) else self.opts.wgrad_stream
+        if mode == "auto":            # small stacks: the weight gradients also fill the partial rounds of the forward / input-gradient GEMMs (config.EngineOptions)
+            mode = "2" if self.rows >= 32768 else "1"
         side = _side_stream(dxo.device) if mode in ("1", "2") else _Inline()
         excl = mode == "2"            # 2: wgrads run beside attention / LayerNorm / column sums only - every nt GEMM waits for them
         grp = excl or mode == "0"     # the block's fc2 / fc1 / proj weight gradients are issued together (one grouped launch); mode 1

@@ -265,7 +265,7 @@ def test_model_family_exports_and_per_model_options(monkeypatch):
     for k in ("AVSIAM_FP8", "AVSIAM_RECOMPUTE", "AVSIAM_GRAD_STREAM", "AVSIAM_DETERMINISTIC"):
         monkeypatch.delenv(k, raising=False)
     d = EngineOptions.from_env()
-    assert (d.fp8, d.recompute, d.grad_stream, d.wgrad_stream, d.deterministic, d.prune_dead) == ("0", "0", "bf16", "2", False, True)
+    assert (d.fp8, d.recompute, d.grad_stream, d.wgrad_stream, d.deterministic, d.prune_dead) == ("0", "0", "bf16", "auto", False, True)
     monkeypatch.setenv("AVSIAM_FP8", "2")
     monkeypatch.setenv("AVSIAM_RECOMPUTE", "")                                                   # empty = unset
     assert EngineOptions.from_env().fp8 == "2" and EngineOptions.from_env(fp8="3").fp8 == "3" and EngineOptions.from_env(fp8=None).recompute == "0"
