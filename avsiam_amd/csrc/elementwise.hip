@@ -651,6 +651,36 @@ __global__ __launch_bounds__(256) void vecmat_bf16_kernel(const float* __restric
     for (int j = 0; j < 4; ++j) atomicAdd(y + n + j, alpha * acc[j]);
 }
 
+// n such products in ONE launch (a stack's blocks: the value thirds of all their qkv bias gradients at the end of the backward instead of one
+// ~10-us launch per block inside it): desc[3 i .. 3 i + 2] = {x, W, y} of product i, all of the same K, N and leading dimension
+__global__ __launch_bounds__(256) void vecmat_bf16_batched_kernel(const long long* __restrict__ desc, long long ld, float alpha) {
+    const long long* d = desc + 3 * blockIdx.z;
+    const float* x = reinterpret_cast<const float*>(d[0]);
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(d[1]);
+    float* y = reinterpret_cast<float*>(d[2]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + lane * 4;
+    const int k0 = blockIdx.y * 32 + wave * 8;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xv = x[k0 + j];
+        const uint2 w = *reinterpret_cast<const uint2*>(W + (size_t)(k0 + j) * ld + n);
+        acc[0] = fmaf(xv, __uint_as_float(w.x << 16), acc[0]); acc[1] = fmaf(xv, __uint_as_float(w.x & 0xffff0000u), acc[1]);
+        acc[2] = fmaf(xv, __uint_as_float(w.y << 16), acc[2]); acc[3] = fmaf(xv, __uint_as_float(w.y & 0xffff0000u), acc[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(y + n + j, alpha * acc[j]);
+}
+
+extern "C" int avs_vecmat_bf16_batched(const long long* desc, int n, long long ld, int K, int N, float alpha, hipStream_t stream) {
+    AVS_CHECK_ARG(desc && n > 0 && n <= 65535 && K > 0 && N > 0 && (N % 256) == 0 && (K % 32) == 0 && ld >= N && (ld % 4) == 0, "vecmat_batched: N %% 256, K %% 32, n <= 65535");
+    AVS_CHECK_ARG(!avs_tuning().det, "vecmat_batched: not in the deterministic mode (one avs_vecmat_bf16 per product there)");
+    vecmat_bf16_batched_kernel<<<dim3(N / 256, K / 32, n), 256, 0, stream>>>(desc, ld, alpha);
+    AVS_LAUNCH_CHECK("vecmat_batched");
+    return 0;
+}
+
 // the same with one writer per element (AvsTuning::det): a block owns 256 columns and walks all of K, its four waves fold through LDS in a fixed order
 __global__ __launch_bounds__(256) void vecmat_bf16_det_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W, long long ld,
                                                               float* y, int K, float alpha) {

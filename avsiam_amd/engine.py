@@ -664,6 +664,21 @@ class Stack:
                                       # issues each as early as its operands exist
         g16 = self.opts.grad_stream == "bf16"   # the residual gradient travels between the LayerNorm backwards in bf16 only
         det = bool(self.opts.deterministic)     # one stream (above), no epilogue atomics; the library's own reductions follow the "det" knob (the model sets it)
+        # the value thirds of the blocks' qkv bias gradients (a [D] x [D, D] product each, below) in ONE launch at the end of the stack's backward instead
+        # of one ~10-us launch per block inside it - unless something wants a block's gradients final as it completes (the data-parallel reducer), the
+        # gradients accumulate over two passes, or the deterministic forms are asked for
+        vm_batch = None
+        if reducer is None and not accumulate and not det:
+            key = (id(blocks), id(blocks2), split)
+            cache = self.__dict__.setdefault("_vm_batches", {})
+            if key not in cache:
+                vb = ops.VecmatBatch()
+                for lo_, hi_, bl in ranges:
+                    for i in range(self.nblocks):
+                        vb.add(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * self.D:])
+                vb.build(dxo.device)
+                cache[key] = (vb, blocks, blocks2)                # (the parameter lists are kept alive with their id()s)
+            vm_batch = cache[key][0]
 
         done = set()
 
@@ -818,12 +833,15 @@ class Stack:
                 # (the vector-matrix product reads the WHOLE accumulated proj bias gradient: a second backward over the same block
                 #  between two zero-fills must say accumulate=True, or the value third would be counted twice - ADVICE r3)
                 #  - checked at the top of this method)
-                ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * D:])
+                if vm_batch is None:
+                    ops.vecmat(bl[i].proj.gb, bl[i].proj.w, bl[i].qkv.gb[2 * D:])
                 d8, q8_ = g8rec(i - 1, "dbo")          # the block below reads this gradient through its fc2 input-gradient GEMM
                 _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, None if g16 and i > 0 else dxo[lo:], self.lnws,
                         hi - lo, None if one else self.row_mod, dres=(self.datt if pruned else dbm if g16 else dxm)[lo:], dx_bf16=dbo[lo:],
                         dcol=bl[i - 1].fc2.gb if i > 0 else None, dx8=d8[lo:] if d8 is not None else None, q8=q8_)
         side.join()
+        if vm_batch is not None:
+            vm_batch.run()
         for j in reversed(range(self.nblocks)):        # (mode 2 has reported all but block 0 on the way)
             block_done(j)
 

@@ -702,6 +702,31 @@ def vecmat(x, W, y, alpha=1.0):
     _call("avs_vecmat_bf16", x, W, W.stride(0), y, K, N, float(alpha), _stream())
 
 
+class VecmatBatch:
+    """y_i += x_i . W_i for many (x, W, y) of one shape with ONE launch (avs_vecmat_bf16_batched): the value thirds of a stack's qkv bias gradients"""
+
+    def __init__(self):
+        self.entries, self.keep, self.desc, self.shape = [], [], None, None
+
+    def add(self, x, W, y):
+        assert self.desc is None, "table already built"
+        _chk(x, F32, "vecmat.x"); _chk(W, BF16, "vecmat.W", 2); _chk(y, F32, "vecmat.y")
+        K, N = W.shape
+        assert x.numel() == K and y.numel() == N and N % 256 == 0 and K % 32 == 0
+        shape = (K, N, W.stride(0))
+        assert self.shape in (None, shape), "one shape per batch"
+        self.shape = shape
+        self.entries.append((x.data_ptr(), W.data_ptr(), y.data_ptr()))
+        self.keep.append((x, W, y))
+
+    def build(self, dev):
+        self.desc = torch.tensor(self.entries, dtype=torch.int64, device=dev)
+
+    def run(self, alpha=1.0):
+        K, N, ld = self.shape
+        _call("avs_vecmat_bf16_batched", self.desc, len(self.entries), ld, K, N, float(alpha), _stream())
+
+
 def unshuffle_fwd(x, src_row, pos_row, row_mod, mask_token, pos_a, pos_v, mod_a, mod_v, out, rows):
     _chk(x, F32, "unshuffle.x", 2); _chk(out, F32, "unshuffle.out", 2); _chk(src_row, I32, "unshuffle.src"); _chk(pos_row, I32, "unshuffle.pos")
     _chk(row_mod, U8, "unshuffle.mod")

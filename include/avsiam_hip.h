@@ -299,6 +299,8 @@ int avs_colsum_bf16(const avs_bf16* x, long long ld, float* out, int rows, int C
 /* y[n] += alpha * sum_k x[k] * W[k][n]  (x fp32 [K], W bf16 [K, N] / ld, N % 256 == 0, K % 32 == 0): the value third of the qkv bias
  * gradient = (proj bias gradient) . W_proj, because softmax rows sum to one (Attention, cav_mae_base.py:51,60-77); the key third is 0 */
 int avs_vecmat_bf16(const float* x, const avs_bf16* W, long long ld, float* y, int K, int N, float alpha, avs_stream_t stream);
+/* n such products of one shape in one launch: desc (device, int64 [n][3]) = {x, W, y} pointers (a stack's blocks at the end of its backward) */
+int avs_vecmat_bf16_batched(const long long* desc, int n, long long ld, int K, int N, float alpha, avs_stream_t stream);
 
 /* ---- decoder un-shuffle (forward_decoder, cav_mae_base.py:604-626) */
 int avs_unshuffle_fwd(const float* x, const int* src_row, const int* pos_row, const uint8_t* row_mod,
