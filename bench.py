@@ -152,7 +152,7 @@ def _pmc_file(args, name, kernel_file):
     it is now (SHA-1 stored beside the numbers); else None."""
     if args.batch != 64 or args.frames != 10 or args.audio_tokens != 512 or args.model != "vit_base" or args.fp8 or args.recompute:
         return None
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         if not os.path.exists(path):
             continue
