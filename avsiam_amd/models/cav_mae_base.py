@@ -271,7 +271,7 @@ class CAVMAE_BASE(nn.Module):
         # The gradient all-reduce overlaps the backward (comm.GradReducer, AVSIAM_DP_OVERLAP): RCCL's kernels need compute units
         # WHILE a persistent GEMM holds the chip, so every persistent kernel leaves `cu_reserve` CUs free (include/avsiam_hip.h,
         # avs_tuning_set) - 8 by default when collectives are on the path (one per XCD; AVSIAM_CU_RESERVE overrides, 0 = none).
-        # One blocking message after the backward (AVSIAM_DP_OVERLAP=0) needs no reservation.  Cost at one rank: DESIGN.md 5e.
+        # One blocking message after the backward (AVSIAM_DP_OVERLAP=0) needs no reservation.  Cost at one rank: docs/rounds/r05.md.
         # (the knob is process-wide, like the device: the last model to call set_distributed decides)
         if self.arena.p.is_cuda and _lib.env_value("AVSIAM_CU_RESERVE") is None:
             overlap = os.environ.get("AVSIAM_DP_OVERLAP", "1") != "0"

@@ -178,7 +178,7 @@ def test_train_loop_with_graph_step_equals_the_eager_loop(tmp_path):
     assert me._opt_state[P1]["step"] == mg._opt_state[P1]["step"] == 6 and me._opt_state[P2]["step"] == mg._opt_state[P2]["step"] == 6
     assert re_[0, 9] == rg[0, 9] == 1e-3 and re_[1, 9] == rg[1, 9] == 5e-4
     # Two EAGER runs of this loop differ by up to 3.6e-3 in the reconstruction losses, 1.9e-2 in the InfoNCE terms of a batch of 4 and 1.7e-3 in the
-    # weights after six Adam updates (order of the fp32 atomics x Adam's sign sensitivity: DESIGN.md 5d item 1); graph vs eager measured the same
+    # weights after six Adam updates (order of the fp32 atomics x Adam's sign sensitivity: docs/rounds/r04.md item 1); graph vs eager measured the same
     for col in (0, 1, 3, 4, 5):
         assert np.allclose(re_[:, col], rg[:, col], rtol=1e-2, atol=1e-6), (col, re_[:, col], rg[:, col])
     for col in (2, 6, 7):

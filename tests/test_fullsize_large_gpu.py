@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 # One property per model keeps the run inside the suite's time budget: the MAE pass over 64 clips equals the mean of its two 32-clip
 # halves with the same per-clip plans (loss rel 1e-5, masks bit-equal, whole flat gradient cosine / norm) - the small-shape results
 # of these models are anchored to the oracle by tests/test_parity_gpu.py (test_vit_large_*, test_vit_huge14_*).  ViT-H/14 needs
-# per-layer activation recompute to fit (CAVMAE_BASE(recompute=...), DESIGN.md section 6: 75 GiB instead of 290 GB).
+# per-layer activation recompute to fit (CAVMAE_BASE(recompute=...), docs/fp8_and_large_models.md: 75 GiB instead of 290 GB).
 def _halves_property(cfg, seed, recompute):
     import gc
     from avsiam_amd.models import CAVMAE_BASE

@@ -472,7 +472,7 @@ def test_pruned_decoder_is_the_same_mae_pass(frames, batch, recompute):
     reference computes them for nothing - the last decoder block runs query / proj / LayerNorm-2 / MLP on the scored rows only (keys and values for
     all), decoder_norm, both prediction heads and the loss see the scored rows only, and the decoder rows are laid out [scored | kept] per sample.
     Exact arithmetic removal - but not a bitwise one: the grouped layout permutes the decoder's rows, so every decoder attention sums its keys in
-    another order, and one flipped bf16 rounding at the top of a 22-block backward chain grows to the bf16 noise floor at its bottom (DESIGN.md 5d
+    another order, and one flipped bf16 rounding at the top of a 22-block backward chain grows to the bf16 noise floor at its bottom (docs/rounds/r04.md
     item 1: two runs of the SAME schedule differ as much once an atomics order differs).  Against the same model with prune_dead=False, same
     weights / inputs / plan: masks bitwise, losses to 1e-4 (measured 2.4e-5), every gradient tensor within PRUNE_REL of its norm and the whole gradient within
     PRUNE_WHOLE_REL (~3x measured, parity_margins.json prune_dead_*), dead parameters stay dead - with an injected plan AND with a device-drawn one (the

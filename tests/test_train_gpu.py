@@ -244,7 +244,7 @@ def test_graphed_step_equals_the_eager_step(fp8):
         assert all(torch.equal(p, q) for p, q in zip(px["contrastive"].a_keep, py["contrastive"].a_keep))
 
     def close(oe, og):
-        # the reconstruction losses agree to the order of the fp32 atomics (2e-3 with Adam's sign sensitivity); the
+        # the reconstruction losses agree to the order of the fp32 atomics (2e-3 with Adam's sign sensitivity, docs/rounds/r04.md item 1); the
         # InfoNCE loss of a batch of 4 the model is memorising is 1e-4 .. 5e-2 and moves by a few percent with that same noise (tau = 0.05)
         mae = all(abs(x - y) <= 2e-3 * abs(x) + 1e-6 for x, y in zip(oe[:3], og[:3]))
         return mae and abs(oe[3] - og[3]) <= 0.05 * abs(oe[3]) + 5e-3 and oe[4] == og[4]
@@ -264,7 +264,7 @@ def test_graphed_step_equals_the_eager_step(fp8):
         rel = float((me.arena.p - mg.arena.p).double().norm() / me.arena.p.double().norm())
         assert rel < (2e-3 if fp8 == "0" else 6e-3), rel      # measured 3.6e-4 (bf16) / 3e-4 .. 2.9e-3 (fp8 mode 3, box to box) after five updates: Adam's
                                       # first steps move every weight by +-lr by the SIGN of its gradient element, and the order of the fp32 atomics
-                                      # decides the sign of the smallest ones; e5m2 gradient operands leave more of them near zero
+                                      # decides the sign of the smallest ones (docs/rounds/r04.md item 1); e5m2 gradient operands leave more of them near zero
         # mixed: an eager step on the graphed model, then a replay - the counters are re-written from the host state in front of every replay
         train_step(me, a, v, 2e-4); train_step(mg, a, v, 2e-4)
         oe = [float(x.item()) for x in train_step(me, a, v, 2e-4)]
@@ -289,7 +289,7 @@ def test_deterministic_mode_gives_bit_identical_steps(fp8):
     sums, the fc1 bias gradient by the column-sum kernel instead of the GEMM epilogue's atomics, everything on one stream.  Two models from the same
     seeds, three eager training steps each (device-drawn plans): losses, every weight, both Adam moments BITWISE equal - in bf16 and in fp8 mode 3
     (whose amax atomics are max-reductions, order-free).  The default mode is what makes two runs differ (atomics order x Adam's sign sensitivity,
-    DESIGN.md 5d item 1): it must agree with the deterministic result to the noise it is known to have, which also checks that the one-writer
+    docs/rounds/r04.md item 1): it must agree with the deterministic result to the noise it is known to have, which also checks that the one-writer
     kernels compute the same sums."""
     from avsiam_amd import _lib
     from avsiam_amd.config import EngineOptions
