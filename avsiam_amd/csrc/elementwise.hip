@@ -158,17 +158,26 @@ __global__ void unshuffle_fwd_kernel(const float* __restrict__ x, const int* __r
 // layout (dx[src] = dout row) and accumulates mask-token / modality sums (one atomic per column per block).
 // row_of_pos (may be NULL): the decoder row that holds position (b, l) when the decoder rows are not in position order (the grouped layout of
 // maskplan.hip: scored rows first); src_row is indexed by decoder row.
-__global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ src_row, int B, int T,
+// One block per position, UB_G row groups of 128 threads each (round 6: a single group walked the 640 rows of a frame position one after the other -
+// the launch took 0.5 ms at 0.6 TB/s): group g takes the (sample, frame) pairs g, g + UB_G, ..., the groups' sums fold through LDS in a fixed order, so
+// the positional gradient still has ONE writer; the token sums (mask token, modality embeddings) leave as one atomic per column and block as before.
+// det (AvsTuning::det): the token sums come from unshuffle_tokens_det_kernel instead.
+constexpr int UB_G = 4;
+__global__ __launch_bounds__(128 * UB_G) void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ src_row, int B, int T,
                                      int La, int Lv, float* __restrict__ dx, float* dpos_a, float* dpos_v,
                                      float* dmask, float* dmod_a, float* dmod_v, int D, const int* __restrict__ row_of_pos, int det) {
+    __shared__ float4 red[2][UB_G][128];
     const int l = blockIdx.x;
     const bool audio = l < La;
     const int Ltot = La + T * Lv;
-    for (int c = threadIdx.x; c < D / 4; c += blockDim.x) {
+    const int grp = threadIdx.x >> 7, tc = threadIdx.x & 127;
+    const int reps = audio ? 1 : T;
+    for (int c0 = 0; c0 < D / 4; c0 += 128) {
+        const int c = c0 + tc;
         float4 sp = make_float4(0, 0, 0, 0), sm = sp;
-        const int reps = audio ? 1 : T;
-        for (int b = 0; b < B; ++b)
-            for (int t = 0; t < reps; ++t) {
+        if (c < D / 4)
+            for (int i = grp; i < B * reps; i += UB_G) {
+                const int b = i / reps, t = i - b * reps;
                 const int rp = b * Ltot + (audio ? l : La + t * Lv + (l - La));
                 const int r = row_of_pos ? row_of_pos[rp] : rp;
                 const float4 g = reinterpret_cast<const float4*>(dout + (size_t)r * D)[c];
@@ -177,15 +186,28 @@ __global__ void unshuffle_bwd_kernel(const float* __restrict__ dout, const int* 
                 if (s >= 0) reinterpret_cast<float4*>(dx + (size_t)s * D)[c] = g;
                 else { sm.x += g.x; sm.y += g.y; sm.z += g.z; sm.w += g.w; }
             }
-        float* dp = audio ? dpos_a + (size_t)l * D : dpos_v + (size_t)(l - La) * D;
-        float4 old = reinterpret_cast<float4*>(dp)[c];
-        reinterpret_cast<float4*>(dp)[c] = make_float4(old.x + sp.x, old.y + sp.y, old.z + sp.z, old.w + sp.w);
-        if (det) continue;                                    // (AvsTuning::det: the token sums come from unshuffle_tokens_det_kernel, one writer each)
-        float* dm = audio ? dmod_a : dmod_v;
-        atomicAdd(dm + c * 4 + 0, sp.x); atomicAdd(dm + c * 4 + 1, sp.y);
-        atomicAdd(dm + c * 4 + 2, sp.z); atomicAdd(dm + c * 4 + 3, sp.w);
-        atomicAdd(dmask + c * 4 + 0, sm.x); atomicAdd(dmask + c * 4 + 1, sm.y);
-        atomicAdd(dmask + c * 4 + 2, sm.z); atomicAdd(dmask + c * 4 + 3, sm.w);
+        __syncthreads();
+        red[0][grp][tc] = sp; red[1][grp][tc] = sm;
+        __syncthreads();
+        if (grp == 0 && c < D / 4) {
+            sp = red[0][0][tc]; sm = red[1][0][tc];
+#pragma unroll
+            for (int g2 = 1; g2 < UB_G; ++g2) {
+                const float4 a = red[0][g2][tc], m2 = red[1][g2][tc];
+                sp.x += a.x; sp.y += a.y; sp.z += a.z; sp.w += a.w;
+                sm.x += m2.x; sm.y += m2.y; sm.z += m2.z; sm.w += m2.w;
+            }
+            float* dp = audio ? dpos_a + (size_t)l * D : dpos_v + (size_t)(l - La) * D;
+            float4 old = reinterpret_cast<float4*>(dp)[c];
+            reinterpret_cast<float4*>(dp)[c] = make_float4(old.x + sp.x, old.y + sp.y, old.z + sp.z, old.w + sp.w);
+            if (!det) {                                           // (AvsTuning::det: the token sums come from unshuffle_tokens_det_kernel, one writer each)
+                float* dm = audio ? dmod_a : dmod_v;
+                atomicAdd(dm + c * 4 + 0, sp.x); atomicAdd(dm + c * 4 + 1, sp.y);
+                atomicAdd(dm + c * 4 + 2, sp.z); atomicAdd(dm + c * 4 + 3, sp.w);
+                atomicAdd(dmask + c * 4 + 0, sm.x); atomicAdd(dmask + c * 4 + 1, sm.y);
+                atomicAdd(dmask + c * 4 + 2, sm.z); atomicAdd(dmask + c * 4 + 3, sm.w);
+            }
+        }
     }
 }
 
@@ -753,7 +775,7 @@ extern "C" int avs_unshuffle_bwd_map(const float* dout, const int* src_row, int 
                                      const int* row_of_pos, hipStream_t stream) {
     AVS_CHECK_ARG(B > 0 && T > 0 && (D % 4) == 0 && dout && src_row && dx, "unshuffle_bwd: bad args");
     const int det = avs_tuning().det;
-    unshuffle_bwd_kernel<<<La + Lv, 128, 0, stream>>>(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, row_of_pos, det);
+    unshuffle_bwd_kernel<<<La + Lv, 128 * UB_G, 0, stream>>>(dout, src_row, B, T, La, Lv, dx, dpos_a, dpos_v, dmask, dmod_a, dmod_v, D, row_of_pos, det);
     if (det) unshuffle_tokens_det_kernel<<<ceil_div(D, 64), 256, 0, stream>>>(dout, src_row, B, T, La, Lv, dmask, dmod_a, dmod_v, D, row_of_pos);
     AVS_LAUNCH_CHECK("unshuffle_bwd");
     return 0;

@@ -26,27 +26,28 @@ __device__ __forceinline__ float mae_target(const void* __restrict__ inp, int au
 
 // row_id (may be NULL): prediction row pr scores token row_id[pr] - id_base of the [N * L] (sample, token) numbering the mask and the targets are
 // indexed by - COMPACT predictions: only the rows whose mask is 1 are computed at all (maskplan.hip: pred_id).  NULL: pr is that index itself.
-__global__ void mae_loss_fwd_kernel(const float* __restrict__ pred, const void* __restrict__ inp,
-                                    const float* __restrict__ mask, float* __restrict__ row_loss, int audio, int L, int C,
-                                    int H, int W, int G, int P, int S, InXf xf, const int* __restrict__ row_id, int id_base) {
-    __shared__ float red[4];
-    const int pr = blockIdx.x;
+// One WAVE per prediction row, four rows per block (round 6: a 256-thread block per row spent its time in the block-wide reduction - 118 k blocks,
+// 0.32 ms per direction at 1.9 TB/s): a lane takes elements lane, lane + 64, ..., the row sum is a wave reduction.
+__global__ __launch_bounds__(256) void mae_loss_fwd_kernel(const float* __restrict__ pred, const void* __restrict__ inp,
+                                                          const float* __restrict__ mask, float* __restrict__ row_loss, int rows, int audio, int L, int C,
+                                                          int H, int W, int G, int P, int S, InXf xf, const int* __restrict__ row_id, int id_base) {
+    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pr >= rows) return;
     const int r = row_id ? row_id[pr] - id_base : pr;
-    if (mask[r] == 0.f) {
-        if (threadIdx.x == 0) row_loss[pr] = 0.f;
+    const float m = mask[r];
+    if (m == 0.f) {
+        if (lane == 0) row_loss[pr] = 0.f;
         return;
     }
     float s = 0.f;
-    for (int e = threadIdx.x; e < P; e += blockDim.x) {
+    for (int e = lane; e < P; e += 64) {
         bool valid;
         const float tg = mae_target(inp, audio, r, e, L, C, H, W, G, S, xf, valid);
         const float d = valid ? pred[(size_t)pr * P + e] - tg : 0.f;
         s += d * d;
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) row_loss[pr] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(P / 256 * S * S) * mask[r];      // mean over the scored elements
+    if (lane == 0) row_loss[pr] = s / (float)(P / 256 * S * S) * m;      // mean over the scored elements
 }
 
 // deterministic single-block sum: out[0] = scale * sum(x); optionally total[0] = (total_init ? 0 : total[0]) + out[0]
@@ -67,15 +68,16 @@ __global__ void sum_scale_kernel(const float* __restrict__ x, int n, float scale
 }
 
 // dpred[r, e] = g * 2 (pred - target) mask[r] / (P * nmask)   (bf16: operand of the prediction-head GEMMs)
-__global__ void mae_loss_bwd_kernel(const float* __restrict__ pred, const void* __restrict__ inp,
-                                    const float* __restrict__ mask, const float* __restrict__ gout, bf16_t* __restrict__ dpred,
-                                    int audio, int L, int C, int H, int W, int G, int P, int S, float inv_nmask, InXf xf,
-                                    const int* __restrict__ row_id, int id_base) {
-    const int pr = blockIdx.x;
+__global__ __launch_bounds__(256) void mae_loss_bwd_kernel(const float* __restrict__ pred, const void* __restrict__ inp,
+                                                          const float* __restrict__ mask, const float* __restrict__ gout, bf16_t* __restrict__ dpred, int rows,
+                                                          int audio, int L, int C, int H, int W, int G, int P, int S, float inv_nmask, InXf xf,
+                                                          const int* __restrict__ row_id, int id_base) {
+    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;          // one wave per prediction row (see the forward)
+    if (pr >= rows) return;
     const int r = row_id ? row_id[pr] - id_base : pr;
     const float m = mask[r];
     const float k = gout[0] * 2.0f * m * inv_nmask / (float)(P / 256 * S * S);
-    for (int e = threadIdx.x; e < P; e += blockDim.x) {
+    for (int e = lane; e < P; e += 64) {
         float d = 0.f;
         if (m != 0.f) {
             bool valid;
@@ -238,7 +240,7 @@ extern "C" int avs_mae_loss_fwd_id(const float* pred, const void* inp, const flo
     if (int rc = avs_make_xf(xf, audio ? 1 : 2, &x, "mae_loss_fwd")) return rc;
     const int G = audio ? H / stride : W / stride;
     const int P = 256 * (audio ? 1 : C);
-    mae_loss_fwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, row_loss, audio, L, C, H, W, G, P, stride, x, row_id, id_base);
+    mae_loss_fwd_kernel<<<ceil_div(rows, 4), 256, 0, stream>>>(pred, inp, mask, row_loss, rows, audio, L, C, H, W, G, P, stride, x, row_id, id_base);
     AVS_LAUNCH_CHECK("mae_loss_fwd");
     sum_scale_kernel<<<1, 1024, 0, stream>>>(row_loss, rows, 1.0f / nmask, loss, total, total_init);
     AVS_LAUNCH_CHECK("mae_loss_sum");
@@ -271,7 +273,7 @@ extern "C" int avs_mae_loss_bwd_id(const float* pred, const void* inp, const flo
     if (int rc = avs_make_xf(xf, audio ? 1 : 2, &x, "mae_loss_bwd")) return rc;
     const int G = audio ? H / stride : W / stride;
     const int P = 256 * (audio ? 1 : C);
-    mae_loss_bwd_kernel<<<rows, 256, 0, stream>>>(pred, inp, mask, gout, dpred, audio, L, C, H, W, G, P, stride, 1.0f / nmask, x, row_id, id_base);
+    mae_loss_bwd_kernel<<<ceil_div(rows, 4), 256, 0, stream>>>(pred, inp, mask, gout, dpred, rows, audio, L, C, H, W, G, P, stride, 1.0f / nmask, x, row_id, id_base);
     AVS_LAUNCH_CHECK("mae_loss_bwd");
     return 0;
 }
