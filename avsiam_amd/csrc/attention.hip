@@ -232,37 +232,7 @@ struct AttnArgs {
                                                 // of its rows - and `out` / `dout` are COMPACT: sequence s (= first row / length) owns their rows s * lq .. + lq - 1.
                                                 // The decoder's last block (cav_mae_base.py:629-635,679-682): rows whose prediction is never scored (mask 0) feed
                                                 // nothing but the keys and values of that block; lse / delta / dqkv keep the packed row numbering.  0: every row.
-    float* qb; float* qb2; int qb_split;        // bwd (may be NULL): the QUERY third of the qkv bias gradient, qb[h * hd + c] += sum over the query rows of dq (fp32
-                                                // values, before the bf16 rounding of dqkv) - one atomic per column and half-wave instead of a column-sum pass over
-                                                // dqkv[:, :D] per block (46 launches and 3.9 GB per step, round 6).  Rows from qb_split on (the second weight set of a
-                                                // two-tower stack) add to qb2.  Not in the deterministic mode (the host keeps avs_colsum_bf16 there).
 };
-
-// the query-bias gradient of one wave's 32 query rows (AttnArgs::qb): every accumulator register holds ONE column of dq for the lane's query; the
-// 32 lanes of a half-wave fold it, lane 0 / 32 adds.  `valid`: the lane's query row exists.
-template <int HG, int NDB>
-__device__ __forceinline__ void qbias_grad(const AttnArgs& a, const f32x16 (&dq)[NDB], bool valid, int row0, int head, int lane, int hh) {
-    if (!a.qb) return;                                   // kernel-uniform
-    float* dst = (a.qb2 && row0 >= a.qb_split ? a.qb2 : a.qb) + head * HG;
-#pragma unroll
-    for (int d = 0; d < NDB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int col = d * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (col >= HG) continue;                     // (hd 80 on a 96-wide image: columns beyond the head)
-            float v = valid ? dq[d][r] * a.scale : 0.f;
-            // DPP adds, not __shfl_xor: the five ds_bpermute addresses are loop-invariant, hipcc computes them at kernel start and they cost every
-            // backward kernel 4 - 18 VGPRs through its main loop (dq<64,2> 162 -> 170: an occupancy step)
-            v = dpp_add<0xB1, 0xF>(v);                      // quad_perm [1,0,3,2]
-            v = dpp_add<0x4E, 0xF>(v);                      // quad_perm [2,3,0,1]
-            v = dpp_add<0x141, 0xF>(v);                     // row_half_mirror
-            v = dpp_add<0x140, 0xF>(v);                     // row_mirror: every lane of a row of 16 holds the row's sum
-            v = dpp_add<0x142, 0xA>(v);                     // row_bcast15 into rows 1 and 3: lanes 16-31 / 48-63 hold the half-wave sums
-            if ((lane & 31) == 31) atomicAdd(dst + col, v);
-            // one column at a time: scheduled across columns the 32 partial sums cost the hd-64 two-wave kernels an occupancy step (dq<64,2> 162 -> 170 registers)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-}
 
 // queries of a sequence of length L, and the row of `out` / `dout` that holds the sequence's first query (AttnArgs::lq)
 __device__ __forceinline__ int attn_lq(const AttnArgs& a, int L) { return a.lq > 0 ? a.lq : L; }
@@ -901,8 +871,6 @@ __global__ __launch_bounds__(64 * NW, (HD == 32 && NW == 4) ? 4 : (HD == 64 && N
         for (int d = 0; d < NDB; ++d) store_block<HG, true>(drow, d, hh, dq[d], a.scale, drow8, g8s, g8max);
     }
     if (G8) q_amax_update(a.qd8, g8max, g8seen);
-    __builtin_amdgcn_sched_barrier(0);                    // (after the stores: their temporaries are dead - in front of them the sums cost an occupancy step)
-    qbias_grad<HG, NDB>(a, dq, qq < Lq, seq0, head, lane, hh);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1313,8 +1281,6 @@ __global__ __launch_bounds__(64 * NW, (HD == 64 && NW == 2 && G8) ? 3 : 1) void 
         }
     }
     if (G8) q_amax_update(a.qd8, g8max, g8seen);
-    __builtin_amdgcn_sched_barrier(0);                    // (after the stores, see attn_bwd_dq_kernel)
-    qbias_grad<HD, NDB>(a, dq, rl < L, seq0, head, lane, hh);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1446,7 +1412,6 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused224_kernel(AttnArgs a) {
                 for (int d = 0; d < NDB; ++d)
                     dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(sK, 16 * ks, d, lane), dsf, dq[d], 0, 0, 0);
             }
-            qbias_grad<HD, NDB>(a, dq, rl < L, seq0, head, lane, hh);
             if (rl < L) {
                 bf16_t* qrow = a.dqkv + (size_t)(seq0 + rl) * a.ld + head * HD;
                 float unused = 0.f;
@@ -1489,7 +1454,7 @@ static int attn_fwd_impl(const bf16_t* qkv, long long ld, int D, int H, const in
     AVS_CHECK_ARG(out && lse, "attn_fwd: null output");
     AVS_CHECK_ARG((ldo % 8) == 0 && ldo >= D, "attn_fwd: ldo=%lld must be a multiple of 8 (the epilogue stores 16 bytes per lane) and >= D", ldo);
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd),
-               out8, ldo8, q8, nullptr, 0, nullptr, 1, lq, nullptr, nullptr, 0};
+               out8, ldo8, q8, nullptr, 0, nullptr, 1, lq};
     dim3 grid(ntiles * H);
     // hd 80 (ViT-H: 1280 / 16 heads): a 96-wide LDS image whose last 16 columns are zero, five contraction steps, 128-row tiles only
     const bool ring = avs_tuning().attn_ring != 0 && lq == 0;          // K / V tiles by LDS-DMA ring (hd 32 / 64; bitwise the register-staged kernels' results)
@@ -1531,10 +1496,8 @@ extern "C" int avs_attn_fwd(const bf16_t* qkv, long long ld, int D, int H, const
 static int attn_bwd_impl(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                          const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
                          const float* lse, float* delta, int rows_total, bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
-                         int kv_bf16, int lq, hipStream_t stream, float* qb = nullptr, float* qb2 = nullptr, int qb_split = 0) {
+                         int kv_bf16, int lq, hipStream_t stream) {
     AVS_CHECK_ARG(lq >= 0, "attn_bwd: lq < 0");
-    AVS_CHECK_ARG(!(qb && avs_tuning().det), "attn_bwd: the fused query-bias gradient uses atomics - not in the deterministic mode");
-    AVS_CHECK_ARG(!qb2 || (qb && qb_split > 0), "attn_bwd: qb2 goes with qb and a positive qb_split");
     // kv_bf16 == 0 (with dqkv8 only): the key and value thirds of the bf16 dqkv are left unwritten - their only readers take the e5m2 copy
     AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd: kv_bf16 = 0 needs the e5m2 copy");
     AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 16) == 0)), "attn_bwd: dqkv8 and its record go together, ld8 %% 16 == 0");
@@ -1545,7 +1508,7 @@ static int attn_bwd_impl(const bf16_t* qkv, long long ld, int D, int H, const in
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
     AVS_CHECK_ARG((ldo % 8) == 0 && ldo >= D, "attn_bwd: ldo=%lld must be a multiple of 8 (16-byte fragment loads of out / dO rows) and >= D", ldo);
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16, lq, qb, qb2, qb_split};
+               dout, delta, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16, lq};
     dim3 grid(ntiles * H);
 #define ATTN_BWD2(K, G)                                                                                     \
     do {                                                                                                    \
@@ -1558,7 +1521,7 @@ static int attn_bwd_impl(const bf16_t* qkv, long long ld, int D, int H, const in
             else K<32, 2, 32, G><<<grid, 128, 0, stream>>>(a);                                              \
         }                                                                                                   \
     } while (0)
-    const bool ring = avs_tuning().attn_ring != 0 && hd != 80 && lq == 0 && !qb;
+    const bool ring = avs_tuning().attn_ring != 0 && hd != 80 && lq == 0;
 #define ATTN_BWD2R(K, G)                                                                                    \
     do {                                                                                                    \
         if (tile_rows == 128) {                                                                             \
@@ -1595,16 +1558,6 @@ extern "C" int avs_attn_bwd_cq(const bf16_t* qkv, long long ld, int D, int H, co
     return attn_bwd_impl(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, dout, ldo, lse, delta, rows_total, dqkv, nullptr, 0, nullptr, 1, lq, stream);
 }
 
-// Every option of the two-kernel backward in one entry point: dqkv8 / ld8 / qd8 / kv_bf16 as avs_attn_bwd_q8, lq as avs_attn_bwd_cq (0: every row a
-// query), and the fused QUERY-BIAS gradient: qb[h * hd + c] += sum over the query rows of dq (qb2 for the rows from qb_split on; both may be NULL).
-extern "C" int avs_attn_bwd_ex(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
-                               const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
-                               const float* lse, float* delta, int rows_total, bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
-                               int kv_bf16, int lq, float* qb, float* qb2, int qb_split, hipStream_t stream) {
-    return attn_bwd_impl(qkv, ld, D, H, tile_start, tile_len, tile_q0, ntiles, tile_rows, out, dout, ldo, lse, delta, rows_total, dqkv, dqkv8, ld8, qd8, kv_bf16, lq,
-                         stream, qb, qb2, qb_split);
-}
-
 extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                             const int* tile_q0, int ntiles, int tile_rows, const bf16_t* out, const bf16_t* dout, long long ldo,
                             const float* lse, float* delta, int rows_total, bf16_t* dqkv, hipStream_t stream) {
@@ -1613,11 +1566,9 @@ extern "C" int avs_attn_bwd(const bf16_t* qkv, long long ld, int D, int H, const
 }
 
 // One workgroup per (sequence, head) for sequences of at most `rows_per_wg` (64 or 128) tokens: seq_start / seq_len [nseq].
-static int attn_bwd_fused_impl(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
-                               int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
-                               bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, float* qb, float* qb2, int qb_split, hipStream_t stream) {
-    AVS_CHECK_ARG(!(qb && avs_tuning().det), "attn_bwd_fused: the fused query-bias gradient uses atomics - not in the deterministic mode");
-    AVS_CHECK_ARG(!qb2 || (qb && qb_split > 0), "attn_bwd_fused: qb2 goes with qb and a positive qb_split");
+extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
+                                     int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
+                                     bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, hipStream_t stream) {
     AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd_fused: kv_bf16 = 0 needs the e5m2 copy");
     AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 16) == 0)), "attn_bwd_fused: dqkv8 and its record go together, ld8 %% 16 == 0");
     AVS_CHECK_ARG(rows_per_wg == 64 || rows_per_wg == 128 || rows_per_wg == 224, "attn_bwd_fused: rows_per_wg must be 64, 128 or 224");
@@ -1627,7 +1578,7 @@ static int attn_bwd_fused_impl(const bf16_t* qkv, long long ld, int D, int H, co
     AVS_CHECK_ARG(out && dout && lse && dqkv && (ldo % 8) == 0, "attn_bwd_fused: null pointer");
     AVS_CHECK_ARG(rows_per_wg != 224 || (hd == 64 && !dqkv8), "attn_bwd_fused: 224-row workgroups exist for head dim 64 without the e5m2 copy");
     AttnArgs a{qkv, ld, D, seq_start, seq_len, nullptr, nseq, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
-               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16, 0, qb, qb2, qb_split};
+               dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16, 0};
     dim3 grid(nseq * H);
     if (rows_per_wg == 224) {
         constexpr int SMEM224 = 3 * 224 * 64 * 2 + 224 * 128 * 2 + 2 * 224 * 4;
@@ -1657,19 +1608,6 @@ static int attn_bwd_fused_impl(const bf16_t* qkv, long long ld, int D, int H, co
 #undef ATTN_BWDF
     AVS_LAUNCH_CHECK("attn_bwd_fused");
     return 0;
-}
-
-extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
-                                     int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
-                                     bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, hipStream_t stream) {
-    return attn_bwd_fused_impl(qkv, ld, D, H, seq_start, seq_len, nseq, rows_per_wg, out, dout, ldo, lse, rows_total, dqkv, dqkv8, ld8, qd8, kv_bf16, nullptr, nullptr, 0, stream);
-}
-
-// avs_attn_bwd_fused_q8 with the fused query-bias gradient (see avs_attn_bwd_ex)
-extern "C" int avs_attn_bwd_fused_ex(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
-                                     int rows_per_wg, const bf16_t* out, const bf16_t* dout, long long ldo, const float* lse, int rows_total,
-                                     bf16_t* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, float* qb, float* qb2, int qb_split, hipStream_t stream) {
-    return attn_bwd_fused_impl(qkv, ld, D, H, seq_start, seq_len, nseq, rows_per_wg, out, dout, ldo, lse, rows_total, dqkv, dqkv8, ld8, qd8, kv_bf16, qb, qb2, qb_split, stream);
 }
 
 extern "C" int avs_attn_bwd_fused(const bf16_t* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,

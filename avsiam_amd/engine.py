@@ -804,15 +804,11 @@ class Stack:
                 if d8 is not None:
                     # (lean mode 3: the qkv input- and weight-gradient GEMMs read the e5m2 copy; of the bf16 dqkv only the query third has a reader)
                     a8 = {"dqkv8": d8, "q8": q8_, "kv_bf16": not self.fp8_lean}
-            # the QUERY third of the qkv bias gradient is summed by the dq kernels themselves (ops.attn_bwd qb=) - not in the deterministic mode (atomics)
-            # and not when the gradients accumulate over two passes' backward in a way the column-sum pass is needed for (it never is: both forms add)
-            qb = None if det else (bp.qkv.gb[:self.D], b2.qkv.gb[:self.D] if b2 is not None else None, split if b2 is not None else 0)
-            a8 = {**a8, "qb": qb}
             if pruned:
                 # queries: the first lq rows of every sequence (out / dO compact); dk, dv for every row.  The query third of the other rows of dqkv
                 # is zero by definition (they asked nothing), and the residual gradient of the compact rows goes back into the packed numbering
                 # for LayerNorm-1's backward - zeros for the rows that were keys / values only - through the freed dO buffer
-                ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv, lq=self.lq, qb=qb)
+                ops.attn_bwd(self.qkv[i], self.tiles_bwd, self.H, self.att[i], self.datt, self.lse[i], self.delta, self.dqkv, lq=self.lq)
                 ops.expand_rows(None, self.q_compact, self.dqkv, M, cols=self.D)
                 ops.expand_rows(dbm, self.q_compact, self.datt, M)
             elif self.tiles_bwd.ntiles:
@@ -833,8 +829,7 @@ class Stack:
                 # qkv bias gradient: only the query third needs the dqkv matrix.  value third = column sum of dO = (proj bias
                 # gradient, complete since this block's LayerNorm-2 backward) . W_proj; key third = 0 exactly (ops.vecmat)
                 D = self.D
-                if qb is None:
-                    ops.colsum(self.dqkv[lo:, :D], bl[i].qkv.gb[:D], hi - lo)
+                ops.colsum(self.dqkv[lo:, :D], bl[i].qkv.gb[:D], hi - lo)
                 # (the vector-matrix product reads the WHOLE accumulated proj bias gradient: a second backward over the same block
                 #  between two zero-fills must say accumulate=True, or the value third would be counted twice - ADVICE r3)
                 #  - checked at the top of this method)

@@ -500,17 +500,12 @@ def attn_fwd(qkv, tiles, H, out, lse, out8=None, q8=None, lq=0):
             lse, lse.shape[1], out8, out8.stride(0) if out8 is not None else 0, _qrec(q8), _stream())
 
 
-def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None, kv_bf16=True, lq=0, qb=None):
+def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None, kv_bf16=True, lq=0):
     """dqkv8 / q8 (fp8 backward): also write the e5m2 copy of dqkv - the gradient operand of the fp8 qkv input-gradient GEMM - scaled by
     the device record q8, whose running amax takes the largest |dqkv| written.  kv_bf16=False (with dqkv8): the key / value thirds of
     the bf16 dqkv are not written.
-    lq > 0 (avs_attn_bwd_cq): the backward of attn_fwd(lq=): out / dout compact, dq written for the first lq rows of every sequence only.
-    qb = (gb, gb2, split): the query third of the qkv bias gradient is summed by the dq kernel (fp32 [D] each; gb2 / split for the rows of a second weight
-    set, else None / 0) instead of a column-sum pass over dqkv[:, :D]."""
+    lq > 0 (avs_attn_bwd_cq): the backward of attn_fwd(lq=): out / dout compact, dq written for the first lq rows of every sequence only."""
     assert kv_bf16 or dqkv8 is not None
-    qb1, qb2, qsplit = qb if qb is not None else (None, None, 0)
-    _chk(qb1, F32, "attnb.qb"); _chk(qb2, F32, "attnb.qb2")
-    assert qb1 is None or (qb1.numel() == qkv.shape[1] // 3 and (qb2 is None or (qb2.numel() == qb1.numel() and qsplit > 0)))
     if lq:
         assert dqkv8 is None and tiles.uniform_len and 0 < lq <= tiles.uniform_len
         _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2)
@@ -520,9 +515,8 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None, kv
         assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape and delta.shape == lse.shape and D // H in (32, 64, 80)
         assert qkv.shape[0] >= tiles.max_row and out.shape[0] >= nseq * lq and lse.shape[0] == H and lse.shape[1] >= tiles.max_row
         frac = lq / tiles.uniform_len
-        _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * frac * D, tiles.rows * ((16.0 + 8.0 * frac) * D + 16.0 * H * frac)), "avs_attn_bwd_ex", qkv, qkv.stride(0), D, H,
-                tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout, out.stride(0), lse, delta, lse.shape[1], dqkv, None, 0, None, 1, int(lq),
-                qb1, qb2, int(qsplit), _stream())
+        _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * frac * D, tiles.rows * ((16.0 + 8.0 * frac) * D + 16.0 * H * frac)), "avs_attn_bwd_cq", qkv, qkv.stride(0), D, H,
+                tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout, out.stride(0), lse, delta, lse.shape[1], dqkv, int(lq), _stream())
         return
     _chk(qkv, BF16, "attnb.qkv", 2); _chk(out, BF16, "attnb.out", 2); _chk(dout, BF16, "attnb.dout", 2); _chk(dqkv8, U8, "attnb.dqkv8", 2)
     assert (dqkv8 is None) == (q8 is None) and (dqkv8 is None or (dqkv8.shape[0] >= tiles.max_row and dqkv8.shape[1] == qkv.shape[1]))
@@ -533,8 +527,8 @@ def attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=None, q8=None, kv
     # algorithmic FLOP: 8 * sum L^2 * D - the four products of the backward (dV, dP, dQ, dK); the recomputation of S = Q.K^T that the
     # kernels pay instead of keeping an L x L tensor is NOT counted.  Algorithmic HBM bytes of the two kernels: dQ
     # reads q, k, v, o, dO and writes dq (+ delta); dK/dV reads q, k, v, dO and writes dk, dv
-    _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd_ex", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
-            out.stride(0), lse, delta, lse.shape[1], dqkv, dqkv8, dqkv8.stride(0) if dqkv8 is not None else 0, _qrec(q8), 1 if kv_bf16 else 0, 0, qb1, qb2, int(qsplit), _stream())
+    _launch("attn_bwd_hd%d" % (D // H), (8.0 * tiles.sum_sq * D, tiles.rows * (24.0 * D + 16.0 * H)), "avs_attn_bwd_q8", qkv, qkv.stride(0), D, H, tiles.start, tiles.len, tiles.q0, tiles.ntiles, tiles.tile_rows, out, dout,
+            out.stride(0), lse, delta, lse.shape[1], dqkv, dqkv8, dqkv8.stride(0) if dqkv8 is not None else 0, _qrec(q8), 1 if kv_bf16 else 0, _stream())
 
 
 class AttnSeqs:
@@ -553,7 +547,7 @@ class AttnSeqs:
         self.sum_sq = float(sum(L * L for L in lens))
 
 
-def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv, dqkv8=None, q8=None, kv_bf16=True, qb=None):
+def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv, dqkv8=None, q8=None, kv_bf16=True):
     """dq, dk, dv of the sequences in `seqs` (each at most seqs.max_len = 64 | 128 | 224 tokens; 224: head dim 64, no e5m2 copy) in one kernel: one
     read of q, k, v, o, dO and one evaluation of S per (sequence, head).  Rows of other sequences are not touched."""
     _chk(qkv, BF16, "attnf.qkv", 2); _chk(out, BF16, "attnf.out", 2); _chk(dout, BF16, "attnf.dout", 2)
@@ -564,13 +558,10 @@ def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv, dqkv8=None, q8=None, kv_b
     assert seqs.max_len != 224 or (D // H == 64 and dqkv8 is None)
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape
     assert qkv.shape[0] >= seqs.max_row and out.shape[0] >= seqs.max_row and lse.shape[0] == H and lse.shape[1] >= seqs.max_row
-    qb1, qb2, qsplit = qb if qb is not None else (None, None, 0)          # (as attn_bwd: the fused query-bias gradient)
-    _chk(qb1, F32, "attnf.qb"); _chk(qb2, F32, "attnf.qb2")
-    assert qb1 is None or (qb1.numel() == D and (qb2 is None or (qb2.numel() == D and qsplit > 0)))
     # algorithmic work: 8 * sum L^2 * D FLOP; q, k, v, o, dO read and dq, dk, dv written once (bf16), lse read
-    _launch("attn_bwd_hd%d" % (D // H), (8.0 * seqs.sum_sq * D, seqs.rows * (16.0 * D + 4.0 * H)), "avs_attn_bwd_fused_ex", qkv, qkv.stride(0), D, H, seqs.start,
+    _launch("attn_bwd_hd%d" % (D // H), (8.0 * seqs.sum_sq * D, seqs.rows * (16.0 * D + 4.0 * H)), "avs_attn_bwd_fused_q8", qkv, qkv.stride(0), D, H, seqs.start,
             seqs.len, seqs.nseq, seqs.max_len, out, dout, out.stride(0), lse, lse.shape[1], dqkv, dqkv8, dqkv8.stride(0) if dqkv8 is not None else 0,
-            _qrec(q8), 1 if kv_bf16 else 0, qb1, qb2, int(qsplit), _stream())
+            _qrec(q8), 1 if kv_bf16 else 0, _stream())
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -221,14 +221,6 @@ int avs_attn_fwd_cq(const avs_bf16* qkv, long long ld, int D, int H, const int* 
 int avs_attn_bwd_cq(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
                     const int* tile_q0, int ntiles, int tile_rows, const avs_bf16* out, const avs_bf16* dout, long long ldo,
                     const float* lse, float* delta, int rows_total, avs_bf16* dqkv, int lq, avs_stream_t stream);
-/* Every option of the two-kernel backward in one entry point (round 6): dqkv8 / ld8 / qd8 / kv_bf16 as avs_attn_bwd_q8 (all may be NULL / 0 / NULL / 1), lq
- * as avs_attn_bwd_cq (0: every row is a query), and the fused QUERY-BIAS gradient - qb[h * hd + c] += sum over the query rows of dq (the query third of
- * `attn.qkv.bias`'s gradient, cav_mae_base.py:51,60: fp32 values, one atomic per column and half-wave) instead of a column-sum pass over dqkv[:, :D] per
- * block; rows from qb_split on (the second weight set of a two-tower stack) add to qb2 (qb, qb2 may be NULL; not with the "det" knob) */
-int avs_attn_bwd_ex(const avs_bf16* qkv, long long ld, int D, int H, const int* tile_start, const int* tile_len,
-                    const int* tile_q0, int ntiles, int tile_rows, const avs_bf16* out, const avs_bf16* dout, long long ldo,
-                    const float* lse, float* delta, int rows_total, avs_bf16* dqkv, uint8_t* dqkv8, long long ld8, float* qd8,
-                    int kv_bf16, int lq, float* qb, float* qb2, int qb_split, avs_stream_t stream);
 /* the same backward for sequences of at most rows_per_wg (64 | 128) tokens, in ONE kernel: a workgroup per (sequence, head) reads q, k,
  * v, dO, o once, evaluates S and its exponentials once and writes dq, dk and dv (hd 32 | 64).  seq_start / seq_len: [nseq] */
 int avs_attn_bwd_fused(const avs_bf16* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
@@ -237,11 +229,6 @@ int avs_attn_bwd_fused(const avs_bf16* qkv, long long ld, int D, int H, const in
 int avs_attn_bwd_fused_q8(const avs_bf16* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
                           int rows_per_wg, const avs_bf16* out, const avs_bf16* dout, long long ldo, const float* lse, int rows_total,
                           avs_bf16* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, avs_stream_t stream);
-/* ... with the fused query-bias gradient of avs_attn_bwd_ex; rows_per_wg 224 (hd 64, no e5m2 copy): the 7-wave form for 129 .. 224 tokens */
-int avs_attn_bwd_fused_ex(const avs_bf16* qkv, long long ld, int D, int H, const int* seq_start, const int* seq_len, int nseq,
-                          int rows_per_wg, const avs_bf16* out, const avs_bf16* dout, long long ldo, const float* lse, int rows_total,
-                          avs_bf16* dqkv, uint8_t* dqkv8, long long ld8, float* qd8, int kv_bf16, float* qb, float* qb2, int qb_split,
-                          avs_stream_t stream);
 
 /* ---- input normalisation on the device (what the reference dataloader does per sample on the host: dataloader.py:505-513
  * fbank = (fbank - norm_mean) / norm_std [+ rand * amp, roll(shift) when `noise`]; :461-462,152-155 frame / 255 then

@@ -516,16 +516,6 @@ def test_attention_fwd_bwd(H, hd, lens, tile_rows):
         e = rel_err(dqkv[:rows, i * D:(i + 1) * D], g[:, i * D:(i + 1) * D])
         assert e < 1.5e-2, (name, e)
     assert dqkv[rows:].abs().max().item() == 0
-    # the fused query-bias gradient (round 6): the dq kernel adds the column sums of its fp32 dq rows to qb - for two weight sets split at a sequence
-    # boundary to qb / qb2 - and leaves dqkv bitwise as without it
-    dq2, qb1, qb2 = torch.zeros_like(qkv), torch.ones(D, device=DEV), torch.ones(D, device=DEV)
-    split = lens[0] + (lens[1] if len(lens) > 1 else 0)
-    o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dq2, qb=(qb1, qb2 if len(lens) > 2 else None, split if len(lens) > 2 else 0))
-    assert torch.equal(dq2, dqkv)
-    if len(lens) > 2:
-        assert rel_err(qb1 - 1, g[:split, :D].sum(0)) < 1.5e-2 and rel_err(qb2 - 1, g[split:, :D].sum(0)) < 1.5e-2
-    else:
-        assert rel_err(qb1 - 1, g[:, :D].sum(0)) < 1.5e-2
 
 
 @pytest.mark.parametrize("H,hd", [(12, 64), (16, 32)])
@@ -604,11 +594,10 @@ def test_attention_bwd_fused_matches_two_kernel_form(H, hd):
     delta = torch.zeros_like(lse)
     o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, want)
     got = torch.full_like(qkv, 7.0)
-    qbf = torch.zeros(D, device=DEV)                          # the fused query-bias gradient of every sequence these kernels take
     for lo, hi in ((0, 64), (64, 128)) + (((128, 224),) if big == 224 else ()):
         sq = o.AttnSeqs(lens, DEV, lo, hi)
         assert sq.nseq == sum(1 for L in lens if lo < L <= hi)
-        o.attn_bwd_fused(qkv, sq, H, out, dout, lse, got, qb=(qbf, None, 0))
+        o.attn_bwd_fused(qkv, sq, H, out, dout, lse, got)
     r0 = 0
     for L in lens:
         blk = slice(r0, r0 + L)
@@ -623,12 +612,6 @@ def test_attention_bwd_fused_matches_two_kernel_form(H, hd):
             assert float((got[blk].float() - 7.0).abs().max()) == 0.0, L          # not this kernel's rows
         r0 += L
     assert float((got[rows:].float() - 7.0).abs().max()) == 0.0
-    r0, want_qb = 0, torch.zeros(D, device=DEV, dtype=torch.float64)
-    for L in lens:
-        if 1 < L <= big:
-            want_qb += want[r0:r0 + L, :D].double().sum(0)
-        r0 += L
-    assert rel_err(qbf, want_qb) < 5e-3                       # (fp32 sums against sums of the bf16-rounded dq rows of the two-kernel form)
     # and against the fp64 formula, like test_attention_fwd_bwd
     qr = qkv[:rows].double()
     qr[:, :D] /= o.attn_q_scale(hd)
