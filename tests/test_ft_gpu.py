@@ -84,6 +84,37 @@ def test_ft_mm_grad_matches_oracle_odd_batch():
         assert float((g - r).abs().max()) <= 0.05 * max(1.0, float(r.abs().max())), (k, float((g - r).abs().max()))
 
 
+@pytest.mark.parametrize("family", ["large", "huge14"])
+def test_ft_large_and_huge_skeletons_match_oracle(family):
+    """models.CAVMAEFT_LARGE / CAVMAEFT_HUGE (the names /root/reference/src/models/__init__.py:9,13 exports; their source files are absent from the
+    snapshot): the same inference modes on the ViT-L/16 and ViT-H/14 skeletons (2 layers deep here), against oracle/ref_cpu.py::ft_forward - the joint
+    head's LayerNorm runs at D = 2048 / 2560 (round 6), ViT-H/14 with heads of 80 and the 14 x 14 patch stride."""
+    from oracle import ref_cpu
+    from avsiam_amd.config import vit_huge14, vit_large
+    from avsiam_amd.models import CAVMAEFT_HUGE, CAVMAEFT_LARGE
+    from avsiam_amd.weights import synth_inputs
+    torch.set_num_threads(16)
+    cfg = vit_large(depth=2) if family == "large" else vit_huge14(depth=2)
+    cls = CAVMAEFT_LARGE if family == "large" else CAVMAEFT_HUGE
+    B, L = 3, 10
+    a, v = synth_inputs(cfg, B, 5)
+    v = v.unsqueeze(1)
+    m = cls(L, cfg=cfg, init_seed=7, init_mode="init").cuda()
+    assert m.cfg.embed_dim == (1024 if family == "large" else 1280)
+    P = synth_state_ft(cfg, L, 7, "init")
+    out = m(a.cuda(), v.cuda(), "mm_grad")
+    with torch.no_grad():
+        ref = ref_cpu.ft_forward(P, cfg, a, v, "mm_grad")
+    for g, r, k in zip(out, ref, ("out", "out_a", "out_v")):
+        g, r = g.double().cpu(), r.double()
+        assert g.shape == r.shape == (B, L)
+        assert float((g - r).abs().max()) <= 0.05 * max(1.0, float(r.abs().max())), (family, k, float((g - r).abs().max()))
+    oa = m(a.cuda(), None, "audioonly")
+    with torch.no_grad():
+        ra = ref_cpu.ft_forward(P, cfg, a, None, "audioonly")
+    assert float((oa.double().cpu() - ra.double()).abs().max()) <= 0.05 * max(1.0, float(ra.abs().max()))
+
+
 def test_ft_serving_batch_properties():
     """16 clips x 10 frames (8 192 audio + 31 360 frame rows in the encoder, 113 280 rows in the fusion blocks): logits are finite, clip order does not
     matter (every clip is its own set of sequences), the audio-only / video-only modes agree with the per-modality heads
