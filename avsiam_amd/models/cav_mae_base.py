@@ -172,7 +172,9 @@ class CAVMAE_BASE(nn.Module):
         super().__init__()
         if options is not None and any(x is not None for x in (fp8_mode, recompute, grad_stream, deterministic)):
             raise ValueError("pass either `options` or the single keywords (fp8_mode / recompute / grad_stream / deterministic), not both")
-        self.options = options.validated() if options is not None else EngineOptions.from_env(fp8=fp8_mode, recompute=recompute, grad_stream=grad_stream,
+        import dataclasses as _dc
+        # (a COPY of a given options object: the engines hold it by reference and set_options() edits it in place - two models built from one object stay apart)
+        self.options = _dc.replace(options).validated() if options is not None else EngineOptions.from_env(fp8=fp8_mode, recompute=recompute, grad_stream=grad_stream,
                                                                                               deterministic=deterministic)
         # engine.BufferPool: the two passes of the training step (run one after the other) take their activation buffers from the SAME
         # memory - the card holds the larger pass, not the sum.  Opt-in (None: AVSIAM_SHARE_PASS_BUFFERS=1); a combined-loss forward WITH

@@ -282,6 +282,10 @@ def test_model_family_exports_and_per_model_options(monkeypatch):
     assert (m3.cfg.embed_dim, m3.cfg.head_dim, m3.cfg.st) == (1280, 80, 14)
     m0.set_options(deterministic=True)                                                           # a runtime field: no engine is dropped, m3 untouched
     assert m0.options.deterministic and not m3.options.deterministic
+    shared = EngineOptions(fp8="1")                                                              # one options object handed to two models: each keeps a copy
+    ma, mb = (models.CAVMAE_BASE(cfg=AVSiamConfig(audio_tokens=128, **small), verbose=False, options=shared) for _ in range(2))
+    ma.set_options(fp8="2", deterministic=True)
+    assert (ma.options.fp8, mb.options.fp8, shared.fp8) == ("2", "1", "1") and not mb.options.deterministic
     with pytest.raises(ValueError):
         models.CAVMAE_LARGE(cfg=AVSiamConfig(), verbose=False)
     with pytest.raises(ValueError):
