@@ -1012,7 +1012,7 @@ void attn_bwd_dq_ring_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // dK, dV (key-major): each wave owns 32 keys (the lane) and walks the query rows of the sequence.
 template <int HD, int NW, int HG = HD, bool G8 = false>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, (HD == 96 && NW == 2) ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     constexpr int NTH = 64 * NW;
     constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * HD * 2 + 2 * 64 * 4];
@@ -1142,10 +1142,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(AttnArgs a) {
 //   phase 2 (as attn_bwd_dq): wave w owns queries 32w..: dQ^T += K^T . dS^T with BOTH operands read transposed from LDS (K image
 //     written from the key fragments the wave already holds, into the space of the Q image; the dS image written in phase 1).
 // No atomics, no second pass; per (sequence, head) the arithmetic and its order equal the two-kernel form's.
-template <int HD, int NW, bool G8 = false>
+// HG: the head dim in memory (80: ViT-H, in a 96-wide image whose columns 80.. are zero - cf. attn_fwd_kernel)
+template <int HD, int NW, bool G8 = false, int HG = HD>
 __global__ __launch_bounds__(64 * NW, (HD == 64 && NW == 2 && G8) ? 3 : 1) void attn_bwd_fused_kernel(AttnArgs a) {
     constexpr int R = 32 * NW;                            // rows (queries = keys) a workgroup holds
-    constexpr int NKK = HD / 16, NDB = HD / 32;
+    constexpr int NKK = HG / 16, NDB = HD / 32;          // contraction steps over the real head dim; 32-wide output blocks of the image
     constexpr int IMG = R * HD * 2;                       // bytes of a [R][HD] bf16 image
     __shared__ __attribute__((aligned(16))) char smem[2 * IMG + R * R * 2 + 2 * R * 4];
     char* sQ = smem;                                      // phase 2: the K image
@@ -1159,9 +1160,9 @@ __global__ __launch_bounds__(64 * NW, (HD == 64 && NW == 2 && G8) ? 3 : 1) void 
     const int rl = 32 * wave + (lane & 31);               // this lane's row of the images: its key (phase 1) and its query (phase 2)
     const int row = min(rl, L - 1);
     const bool active = 32 * wave < L;
-    const bf16_t* qp = a.qkv + (size_t)(seq0 + row) * a.ld + head * HD;
-    const bf16_t* dop = a.dout + (size_t)(seq0 + row) * a.ldo + head * HD;
-    const bf16_t* op = a.out + (size_t)(seq0 + row) * a.ldo + head * HD;
+    const bf16_t* qp = a.qkv + (size_t)(seq0 + row) * a.ld + head * HG;
+    const bf16_t* dop = a.dout + (size_t)(seq0 + row) * a.ldo + head * HG;
+    const bf16_t* op = a.out + (size_t)(seq0 + row) * a.ldo + head * HG;
 
     bf16x8 kf[NKK], vf[NKK];
     {
@@ -1174,6 +1175,13 @@ __global__ __launch_bounds__(64 * NW, (HD == 64 && NW == 2 && G8) ? 3 : 1) void 
             vf[kk] = *reinterpret_cast<const bf16x8*>(qp + 2 * a.D + c);
             dov[kk] = *reinterpret_cast<const bf16x8*>(dop + c);
             ov[kk] = *reinterpret_cast<const bf16x8*>(op + c);
+        }
+        if (HG != HD) {                                    // the image's columns beyond the real head dim (the K image written over sQ below keeps them)
+#pragma unroll
+            for (int ch = HG / 8 + hh; ch < HD / 8; ch += 2) {
+                *reinterpret_cast<f32x4*>(sQ + Img<HD>::off(rl, ch)) = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(sDO + Img<HD>::off(rl, ch)) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         float dpart = 0.f;
 #pragma unroll
@@ -1269,15 +1277,15 @@ __global__ __launch_bounds__(64 * NW, (HD == 64 && NW == 2 && G8) ? 3 : 1) void 
     float g8s = 0.f, g8seen = 0.f, g8max = 0.f;
     if (G8) { g8s = a.qd8[AVS_Q_SCALE]; g8seen = a.qd8[AVS_Q_AMAX]; }
     if (rl < L) {
-        bf16_t* qrow = a.dqkv + (size_t)(seq0 + rl) * a.ld + head * HD;
+        bf16_t* qrow = a.dqkv + (size_t)(seq0 + rl) * a.ld + head * HG;
         bf16_t* krow = (G8 && !a.kv16) ? nullptr : qrow + a.D;
         bf16_t* vrow = krow ? krow + a.D : nullptr;
-        uint8_t* q8p = G8 ? a.dqkv8 + (size_t)(seq0 + rl) * a.ld8 + head * HD : nullptr;
+        uint8_t* q8p = G8 ? a.dqkv8 + (size_t)(seq0 + rl) * a.ld8 + head * HG : nullptr;
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
-            store_block<HD, true>(qrow, d, hh, dq[d], a.scale, q8p, g8s, g8max);
-            store_block<HD, true>(krow, d, hh, dk[d], LN2, G8 ? q8p + a.D : nullptr, g8s, g8max);      // dK = dS^T . (q * scale), the staged q is q * scale * log2(e)
-            store_block<HD, true>(vrow, d, hh, dv[d], 1.0f, G8 ? q8p + 2 * a.D : nullptr, g8s, g8max);
+            store_block<HG, true>(qrow, d, hh, dq[d], a.scale, q8p, g8s, g8max);
+            store_block<HG, true>(krow, d, hh, dk[d], LN2, G8 ? q8p + a.D : nullptr, g8s, g8max);      // dK = dS^T . (q * scale), the staged q is q * scale * log2(e)
+            store_block<HG, true>(vrow, d, hh, dv[d], 1.0f, G8 ? q8p + 2 * a.D : nullptr, g8s, g8max);
         }
     }
     if (G8) q_amax_update(a.qd8, g8max, g8seen);
@@ -1448,7 +1456,6 @@ static int attn_fwd_impl(const bf16_t* qkv, long long ld, int D, int H, const in
     AVS_CHECK_ARG(lq >= 0, "attn_fwd: lq < 0");
     AVS_CHECK_ARG((out8 == nullptr) == (q8 == nullptr) && (!out8 || (ldo8 >= D && (ldo8 % 16) == 0)), "attn_fwd: out8 and q8 go together, ldo8 %% 16 == 0");
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_fwd: tile_rows must be 64 or 128");
-    AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_fwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_fwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && lse, "attn_fwd: null output");
@@ -1456,9 +1463,9 @@ static int attn_fwd_impl(const bf16_t* qkv, long long ld, int D, int H, const in
     AttnArgs a{qkv, ld, D, tile_start, tile_len, tile_q0, ntiles, out, ldo, lse, rows_total, nullptr, nullptr, nullptr, 1.0f / sqrtf((float)hd),
                out8, ldo8, q8, nullptr, 0, nullptr, 1, lq};
     dim3 grid(ntiles * H);
-    // hd 80 (ViT-H: 1280 / 16 heads): a 96-wide LDS image whose last 16 columns are zero, five contraction steps, 128-row tiles only
+    // hd 80 (ViT-H: 1280 / 16 heads): a 96-wide LDS image whose last 16 columns are zero, five contraction steps
     const bool ring = avs_tuning().attn_ring != 0 && lq == 0;          // K / V tiles by LDS-DMA ring (hd 32 / 64; bitwise the register-staged kernels' results)
-    if (hd == 80) attn_fwd_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a);
+    if (hd == 80) { if (tile_rows == 128) attn_fwd_kernel<96, 4, 80><<<grid, 256, 0, stream>>>(a); else attn_fwd_kernel<96, 2, 80><<<grid, 128, 0, stream>>>(a); }
     else if (tile_rows == 128) {
         if (hd == 64) { if (ring) attn_fwd_ring_kernel<64, 4, 3><<<grid, 256, 0, stream>>>(a); else attn_fwd_kernel<64, 4><<<grid, 256, 0, stream>>>(a); }
         else { if (ring) attn_fwd_ring_kernel<32, 4, 3><<<grid, 256, 0, stream>>>(a); else attn_fwd_kernel<32, 4><<<grid, 256, 0, stream>>>(a); }
@@ -1502,7 +1509,6 @@ static int attn_bwd_impl(const bf16_t* qkv, long long ld, int D, int H, const in
     AVS_CHECK_ARG(kv_bf16 || dqkv8, "attn_bwd: kv_bf16 = 0 needs the e5m2 copy");
     AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 16) == 0)), "attn_bwd: dqkv8 and its record go together, ld8 %% 16 == 0");
     AVS_CHECK_ARG(tile_rows == 128 || tile_rows == 64, "attn_bwd: tile_rows must be 64 or 128");
-    AVS_CHECK_ARG(!(H > 0 && D / H == 80 && tile_rows != 128), "attn_bwd: head dim 80 runs with 128-row tiles only");
     const int hd = H > 0 ? D / H : 0;
     if (int e = check_common("attn_bwd", qkv, ld, D, H, hd, tile_start, tile_len, tile_q0, ntiles)) return e;
     AVS_CHECK_ARG(out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
@@ -1512,8 +1518,10 @@ static int attn_bwd_impl(const bf16_t* qkv, long long ld, int D, int H, const in
     dim3 grid(ntiles * H);
 #define ATTN_BWD2(K, G)                                                                                     \
     do {                                                                                                    \
-        if (hd == 80) K<96, 4, 80, G><<<grid, 256, 0, stream>>>(a);                                         \
-        else if (tile_rows == 128) {                                                                        \
+        if (hd == 80) {                                                                                     \
+            if (tile_rows == 128) K<96, 4, 80, G><<<grid, 256, 0, stream>>>(a);                             \
+            else K<96, 2, 80, G><<<grid, 128, 0, stream>>>(a);                                              \
+        } else if (tile_rows == 128) {                                                                     \
             if (hd == 64) K<64, 4, 64, G><<<grid, 256, 0, stream>>>(a);                                     \
             else K<32, 4, 32, G><<<grid, 256, 0, stream>>>(a);                                              \
         } else {                                                                                            \
@@ -1573,10 +1581,11 @@ extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int
     AVS_CHECK_ARG((dqkv8 == nullptr) == (qd8 == nullptr) && (!dqkv8 || (ld8 >= 3LL * D && (ld8 % 16) == 0)), "attn_bwd_fused: dqkv8 and its record go together, ld8 %% 16 == 0");
     AVS_CHECK_ARG(rows_per_wg == 64 || rows_per_wg == 128 || rows_per_wg == 224, "attn_bwd_fused: rows_per_wg must be 64, 128 or 224");
     const int hd = H > 0 ? D / H : 0;
-    AVS_CHECK_ARG(qkv && seq_start && seq_len && nseq > 0 && H > 0 && (hd == 32 || hd == 64) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0,
+    AVS_CHECK_ARG(qkv && seq_start && seq_len && nseq > 0 && H > 0 && (hd == 32 || hd == 64 || hd == 80) && D == H * hd && ld >= 3LL * D && (ld % 8) == 0,
                   "attn_bwd_fused: bad arguments (D=%d H=%d hd=%d ld=%lld nseq=%d)", D, H, hd, ld, nseq);
     AVS_CHECK_ARG(out && dout && lse && dqkv && (ldo % 8) == 0, "attn_bwd_fused: null pointer");
     AVS_CHECK_ARG(rows_per_wg != 224 || (hd == 64 && !dqkv8), "attn_bwd_fused: 224-row workgroups exist for head dim 64 without the e5m2 copy");
+    AVS_CHECK_ARG(hd != 80 || rows_per_wg == 64, "attn_bwd_fused: head dim 80 runs with 64-row workgroups only (a 128-row one needs 81 KB of LDS)");
     AttnArgs a{qkv, ld, D, seq_start, seq_len, nullptr, nseq, const_cast<bf16_t*>(out), ldo, const_cast<float*>(lse), rows_total,
                dout, nullptr, dqkv, 1.0f / sqrtf((float)hd), nullptr, 0, nullptr, dqkv8, ld8, qd8, kv_bf16, 0};
     dim3 grid(nseq * H);
@@ -1596,7 +1605,8 @@ extern "C" int avs_attn_bwd_fused_q8(const bf16_t* qkv, long long ld, int D, int
     }
 #define ATTN_BWDF(G)                                                                                        \
     do {                                                                                                    \
-        if (rows_per_wg == 128) {                                                                           \
+        if (hd == 80) attn_bwd_fused_kernel<96, 2, G, 80><<<grid, 128, 0, stream>>>(a);                     \
+        else if (rows_per_wg == 128) {                                                                         \
             if (hd == 64) attn_bwd_fused_kernel<64, 4, G><<<grid, 256, 0, stream>>>(a);                     \
             else attn_bwd_fused_kernel<32, 4, G><<<grid, 256, 0, stream>>>(a);                              \
         } else {                                                                                            \

@@ -355,8 +355,9 @@ class Stack:
         # faster with 64-row workgroups, its forward 11 % slower; 49/128-token towers: forward 10 % faster; 618 and 2472 tokens: 128
         mean_len = rows / max(1, len(seq_lens))
         force = int(opts.attn_tile)                                           # A/B switch: 64 | 128 for every stack and direction
-        if D // H == 80:
-            force = 128                                                       # the hd-80 instantiation (ViT-H) exists for 128-row workgroups only
+        if D // H == 80 and not force:
+            force = 128                                                       # hd 80 (ViT-H): the 64-row instantiations exist and lose (round 6, tools/bench_attn.py --huge --tile64:
+                                                                              # backward +25 % on the contrastive mix - 232-256 registers, the dK/dV kernel spills)
         self.tiles = ops.AttnTiles(seq_lens, dev, tile_rows=force or (64 if mean_len < 64 else 128))
         # backward: sequences that fit one workgroup (<= 64 / <= 128 tokens: the encoder's video sequences, the MAE towers) take the
         # fused kernel (one read of q, k, v, o, dO and one S / exp evaluation for dq, dk and dv; ops.attn_bwd_fused), the longer ones the
@@ -365,9 +366,11 @@ class Stack:
         if inference:
             self.tiles_bwd = self.tiles
         else:
-            cut = 128 if (opts.attn_fused and D // H in (32, 64)) else 0
+            # (head dim 80 has the 64-row fused form only - a 128-row workgroup would need 81 KB of LDS: the MAE towers' 64-token frame sequences and the
+            #  contrastive pass's 51-token ones; -27 % / -2 % on those stacks' backward attention, tools/bench_attn.py --huge)
+            cut = 0 if not opts.attn_fused else {32: 128, 64: 128, 80: 64}.get(D // H, 0)
             if cut:
-                self.fused_bwd = [sq for sq in (ops.AttnSeqs(seq_lens, dev, 0, 64), ops.AttnSeqs(seq_lens, dev, 64, 128)) if sq.nseq]
+                self.fused_bwd = [sq for sq in (ops.AttnSeqs(seq_lens, dev, 0, 64), ops.AttnSeqs(seq_lens, dev, 64, cut)) if sq.nseq]
                 # round 6: sequences of 129 .. 224 tokens at head dim 64 (the encoder's 156 / 196-token frames, 204-token audio) in one 7-wave workgroup
                 # per (sequence, head) whose dS image holds the queries in two halves (attn_bwd_fused224_kernel); not with the e5m2 copy of dqkv
                 if D // H == 64 and not self.fp8_bwd and opts.attn_fused224:

@@ -548,14 +548,15 @@ class AttnSeqs:
 
 
 def attn_bwd_fused(qkv, seqs, H, out, dout, lse, dqkv, dqkv8=None, q8=None, kv_bf16=True):
-    """dq, dk, dv of the sequences in `seqs` (each at most seqs.max_len = 64 | 128 | 224 tokens; 224: head dim 64, no e5m2 copy) in one kernel: one
-    read of q, k, v, o, dO and one evaluation of S per (sequence, head).  Rows of other sequences are not touched."""
+    """dq, dk, dv of the sequences in `seqs` (each at most seqs.max_len = 64 | 128 | 224 tokens; 224: head dim 64, no e5m2 copy; head dim 80: 64 only) in one
+    kernel: one read of q, k, v, o, dO and one evaluation of S per (sequence, head).  Rows of other sequences are not touched."""
     _chk(qkv, BF16, "attnf.qkv", 2); _chk(out, BF16, "attnf.out", 2); _chk(dout, BF16, "attnf.dout", 2)
     _chk(lse, F32, "attnf.lse", 2); _chk(dqkv, BF16, "attnf.dqkv", 2); _chk(dqkv8, U8, "attnf.dqkv8", 2)
     assert (dqkv8 is None) == (q8 is None) and (dqkv8 is None or (dqkv8.shape[0] >= seqs.max_row and dqkv8.shape[1] == qkv.shape[1]))
     D = qkv.shape[1] // 3
-    assert seqs.nseq > 0 and seqs.max_len in (64, 128, 224) and D // H in (32, 64) and D % H == 0
+    assert seqs.nseq > 0 and seqs.max_len in (64, 128, 224) and D // H in (32, 64, 80) and D % H == 0
     assert seqs.max_len != 224 or (D // H == 64 and dqkv8 is None)
+    assert D // H != 80 or seqs.max_len == 64
     assert dqkv.shape == qkv.shape and out.shape[1] == D and dout.shape == out.shape
     assert qkv.shape[0] >= seqs.max_row and out.shape[0] >= seqs.max_row and lse.shape[0] == H and lse.shape[1] >= seqs.max_row
     # algorithmic work: 8 * sum L^2 * D FLOP; q, k, v, o, dO read and dq, dk, dv written once (bf16), lse read

@@ -484,10 +484,8 @@ def _attn_ref(qkv, lens, H):
 
 @pytest.mark.parametrize("tile_rows", [128, 64])
 @pytest.mark.parametrize("H,hd,lens", [(12, 64, [39, 128, 177, 512, 1, 65]), (16, 32, [708, 33, 200]), (2, 64, [300]),
-                                       (4, 80, [257, 64, 1, 130])])          # hd 80: ViT-H (1280 / 16 heads), 128-row tiles only
+                                       (4, 80, [257, 64, 1, 130, 51, 153])])          # hd 80: ViT-H (1280 / 16 heads)
 def test_attention_fwd_bwd(H, hd, lens, tile_rows):
-    if hd == 80 and tile_rows != 128:
-        pytest.skip("head dim 80 runs with 128-row tiles only")
     o = ops()
     D = H * hd
     rows = sum(lens)
@@ -569,7 +567,7 @@ def test_attention_ring_kernels_match_the_register_staged_ones(H, hd, tile_rows)
         _lib.tuning_set("attn_ring", 0)
 
 
-@pytest.mark.parametrize("H,hd", [(12, 64), (4, 32)])
+@pytest.mark.parametrize("H,hd", [(12, 64), (4, 32), (4, 80)])
 def test_attention_bwd_fused_matches_two_kernel_form(H, hd):
     """avs_attn_bwd_fused (sequences of at most 64 / 128 tokens: dq, dk, dv from one read and one S / exp evaluation per (sequence,
     head)) against the fp64 reference AND against the two-kernel backward on the same inputs - the same products in the same order, so
@@ -577,7 +575,7 @@ def test_attention_bwd_fused_matches_two_kernel_form(H, hd):
     o = ops()
     D = H * hd
     lens = [39, 200, 49, 64, 65, 1, 128, 300, 33, 100, 117, 78, 127, 2, 129, 224, 196, 156, 204, 225, 160, 193]
-    big = 224 if hd == 64 else 128            # (head dim 64: sequences of 129 .. 224 tokens through the 7-wave kernel, round 6)
+    big = {64: 224, 32: 128, 80: 64}[hd]      # (head dim 64: sequences of 129 .. 224 tokens through the 7-wave kernel, round 6; head dim 80 - ViT-H - has the 64-row form only)
     rows = sum(lens)
     rp = o.pad_rows(rows)
     qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
@@ -594,7 +592,9 @@ def test_attention_bwd_fused_matches_two_kernel_form(H, hd):
     delta = torch.zeros_like(lse)
     o.attn_bwd(qkv, tiles, H, out, dout, lse, delta, want)
     got = torch.full_like(qkv, 7.0)
-    for lo, hi in ((0, 64), (64, 128)) + (((128, 224),) if big == 224 else ()):
+    for lo, hi in ((0, 64), (64, 128), (128, 224)):
+        if hi > big:
+            continue
         sq = o.AttnSeqs(lens, DEV, lo, hi)
         assert sq.nseq == sum(1 for L in lens if lo < L <= hi)
         o.attn_bwd_fused(qkv, sq, H, out, dout, lse, got)
@@ -682,23 +682,23 @@ def test_attention_bwd_writes_the_e5m2_copy_of_dqkv(H, hd):
     relative, plus the bf16 rounding), untouched outside the sequences' rows, and the record's amax must equal max |dqkv|."""
     o = ops()
     D = H * hd
-    lens = [39, 200, 64, 130, 128, 300, 7] if hd != 80 else [200, 130, 300, 129]       # hd 80: no fused kernel, two-kernel form only
+    lens = [39, 200, 64, 130, 128, 300, 7]
     rows = sum(lens)
     rp = o.pad_rows(rows, 256)
     qkv = torch.zeros(rp, 3 * D, device=DEV, dtype=torch.bfloat16)
     x = torch.randn(rows, 3 * D, device=DEV)
     x[:, :D] *= o.attn_q_scale(hd)
     qkv[:rows] = bf(x)
-    tr = 128 if hd == 80 else 64
+    tr = 64
     fwd_tiles = o.AttnTiles(lens, DEV, tile_rows=tr)
     out = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
     lse = torch.zeros(H, rp, device=DEV)
     o.attn_fwd(qkv, fwd_tiles, H, out, lse)
     dout = torch.zeros(rp, D, device=DEV, dtype=torch.bfloat16)
     dout[:rows] = bf(torch.randn(rows, D, device=DEV))
-    cut = 0 if hd == 80 else 128
+    cut = 64 if hd == 80 else 128             # (head dim 80: the fused kernel has the 64-row form only)
     tiles = o.AttnTiles(lens, DEV, tile_rows=tr, min_len=cut)
-    fused = [] if hd == 80 else [sq for sq in (o.AttnSeqs(lens, DEV, 0, 64), o.AttnSeqs(lens, DEV, 64, 128)) if sq.nseq]
+    fused = [sq for sq in (o.AttnSeqs(lens, DEV, 0, 64), o.AttnSeqs(lens, DEV, 64, cut)) if sq.nseq]
 
     def run(d8=None, rec=None, kv_bf16=True):
         dq = torch.zeros_like(qkv)

@@ -61,6 +61,23 @@ def run_case(name, H, hd, lens, dev, tile_rows=(128, 64)):
             tb8 = timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=d8, q8=rec.rec(1)), 10)
             tb8l = timeit(lambda: ops.attn_bwd(qkv, tiles, H, out, dout, lse, delta, dqkv, dqkv8=d8, q8=rec.rec(1), kv_bf16=False), 10)
             msg += f"  [+8-bit copies] fwd {tf8*1e6:7.1f} us  bwd {tb8*1e6:7.1f} us  bwd without bf16 dK/dV {tb8l*1e6:7.1f} us"
+    if hd == 80 and min(lens) <= 64:
+        # head dim 80: the fused kernel exists for 64-row workgroups only
+        f = [ops.AttnSeqs(lens, dev, 0, 64)]
+        for tr in tile_rows:
+            tl = ops.AttnTiles(lens, dev, tile_rows=tr, min_len=64)
+
+            def mixed80():
+                if tl.ntiles:
+                    ops.attn_bwd(qkv, tl, H, out, dout, lse, delta, dqkv)
+                ops.attn_bwd_fused(qkv, f[0], H, out, dout, lse, dqkv)
+            msg += f"  [fused<=64 + tile {tr}] bwd {timeit(mixed80, 10)*1e6:7.1f} us"
+            if "--g8" in sys.argv:
+                def mixed80l():
+                    if tl.ntiles:
+                        ops.attn_bwd(qkv, tl, H, out, dout, lse, delta, dqkv, dqkv8=d8, q8=rec.rec(1), kv_bf16=False)
+                    ops.attn_bwd_fused(qkv, f[0], H, out, dout, lse, dqkv, dqkv8=d8, q8=rec.rec(1), kv_bf16=False)
+                msg += f" (lean e5m2 {timeit(mixed80l, 10)*1e6:7.1f} us)"
     if hd in (32, 64) and min(lens) <= 128:
         # the backward as the engine runs it: sequences of at most 128 tokens through the fused kernel, the rest through the two kernels
         f = [sq for sq in (ops.AttnSeqs(lens, dev, 0, 64), ops.AttnSeqs(lens, dev, 64, 128)) if sq.nseq]
@@ -104,11 +121,25 @@ def step_mixes(dev):
     run_case("decoder (64x2472)", 16, 32, [2472] * 64, dev, tile_rows=(128,))
 
 
+def huge_mixes(dev):
+    """the sequence mixes of the ViT-H/14 step (batch 64, 10 frames; 16 heads of 80): contrastive pass, MAE towers, joint layers, decoder"""
+    vid = [256] * 130 + [204] * 130 + [153] * 130 + [102] * 130 + [51] * 120
+    aud = [657] * 13 + [525] * 13 + [394] * 13 + [262] * 13 + [131] * 12
+    tr = (128, 64) if "--tile64" in sys.argv else (128,)
+    run_case("H/14 contrastive pass (audio+video)", 16, 80, aud + vid, dev, tile_rows=tr)
+    run_case("H/14 contrastive pass, video only", 16, 80, vid, dev, tile_rows=tr)
+    run_case("H/14 MAE towers (64x164 + 640x64)", 16, 80, [164] * 64 + [64] * 640, dev, tile_rows=tr)
+    run_case("H/14 MAE joint layers (64x804)", 16, 80, [804] * 64, dev, tile_rows=tr)
+    run_case("H/14 decoder (64x3217)", 16, 32, [3217] * 64, dev, tile_rows=(128,))
+
+
 def main():
     dev = "cuda"
     import sys
     if "--step" in sys.argv:
         return step_mixes(dev)
+    if "--huge" in sys.argv:
+        return huge_mixes(dev)
     for H, hd, L, rows_target in [(12, 64, 39, 40000), (12, 64, 49, 40000), (12, 64, 78, 40000), (12, 64, 117, 40000), (12, 64, 128, 40000),
                                   (12, 64, 156, 40000), (12, 64, 196, 40000), (12, 64, 307, 40000), (12, 64, 512, 40000), (12, 64, 618, 40000),
                                   (16, 32, 708, 80000), (16, 32, 2472, 160000)]:
