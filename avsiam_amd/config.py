@@ -134,6 +134,9 @@ class EngineOptions:
                   stream | "auto" (default): "2" for stacks of at least 32 768 packed rows (the headline shape: every stack), "1" below - the
                   reference's one-frame shapes, whose forward / input-gradient GEMMs leave partial rounds for them to fill (+0.9 % at batch 64)      [runtime]
     wgrad_group   a block's fc2 / fc1 / proj weight gradients in one launch                                                       [runtime]
+    batch_reduce  single GPU, no gradient accumulation: the small per-block reductions of a stack's backward - the parameter-gradient
+                  reduce of every LayerNorm backward, the value third of every qkv bias gradient - in ONE launch each at the end of the
+                  stack's backward instead of ~100 launches of ~10 us inside it (each backward keeps a slab workspace of its own)          [runtime]
     deterministic weight gradients with ONE writer per output tile and an ordered contraction (no split over the token rows, no
                   cross-workgroup atomics), everything on one stream: two runs of a step are bit-identical.  For debugging (the
                   first multi-GPU session); slower                                                                                [runtime]
@@ -151,6 +154,7 @@ class EngineOptions:
     prune_dead: bool = True
     wgrad_stream: str = "auto"
     wgrad_group: bool = True
+    batch_reduce: bool = True
     deterministic: bool = False
 
     STRUCTURAL = ("fp8", "fp8_lean", "fp8_gelu8", "gelu8", "recompute", "grad_stream", "attn_tile", "attn_fused", "attn_fused224", "group_towers", "prune_dead")
@@ -158,7 +162,7 @@ class EngineOptions:
     _ENV = {"fp8": ("AVSIAM_FP8", str), "fp8_lean": ("AVSIAM_FP8_LEAN", "flag"), "fp8_gelu8": ("AVSIAM_FP8_GELU8", "flag"), "gelu8": ("AVSIAM_GELU8", "flag"),
             "recompute": ("AVSIAM_RECOMPUTE", str), "grad_stream": ("AVSIAM_GRAD_STREAM", str), "attn_tile": ("AVSIAM_ATTN_TILE", int),
             "attn_fused": ("AVSIAM_ATTN_FUSED", "flag"), "attn_fused224": ("AVSIAM_ATTN_FUSED224", "flag"), "group_towers": ("AVSIAM_GROUP_TOWERS", "flag"), "prune_dead": ("AVSIAM_PRUNE_DEAD", "flag"),
-            "wgrad_stream": ("AVSIAM_WGRAD_STREAM", str), "wgrad_group": ("AVSIAM_WGRAD_GROUP", "flag"), "deterministic": ("AVSIAM_DETERMINISTIC", "flag")}
+            "wgrad_stream": ("AVSIAM_WGRAD_STREAM", str), "wgrad_group": ("AVSIAM_WGRAD_GROUP", "flag"), "batch_reduce": ("AVSIAM_BATCH_REDUCE", "flag"), "deterministic": ("AVSIAM_DETERMINISTIC", "flag")}
 
     @classmethod
     def from_env(cls, **over):

@@ -433,6 +433,45 @@ __global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblocks, 
 
 extern "C" int avs_layernorm_ws_floats(int rows, int D) { return ceil_div(rows, 4 * LN_MIN_ROWS_PER_WAVE) * LN_SETS * D; }
 
+// rows per wave of the backward kernels: a block of 4 waves x RPW rows writes one slab of parameter-gradient partial sums; fewer rows per wave = more
+// blocks (helps only when 16 rows leave most CUs with a single block) and more slab traffic.
+static int ln_bwd_rpw(int rows) {
+    int rpw = avs_tuning().ln_rpw;
+    if (rpw != 4 && rpw != 8 && rpw != 16) rpw = rows >= 16384 ? 16 : 8;        // measured (tools/bench_ln.py): 8 wins only on the 8192-row audio tower
+    return rpw;
+}
+// slabs ([LN_SETS][D] floats each) a backward over `rows` rows writes with the current knobs: what a caller that reduces the slabs itself
+// (avs_layernorm_bwd with no gradient target, then avs_layernorm_bwd_reduce_batched) must reserve and tell the batched reduce
+extern "C" int avs_layernorm_bwd_slabs(int rows) { return rows > 0 ? ceil_div(rows, 4 * ln_bwd_rpw(rows)) : 0; }
+
+// n slab sets in ONE launch (a stack's LayerNorm backwards: one reduce at the end of the stack's backward instead of one ~10-us launch per LayerNorm
+// inside it): desc[7 i ..] = {ws, slabs, dg0, db0, dg1, db1, dcol} of set i (gradient targets may be 0), all of width D
+__global__ void ln_bwd_reduce_batched_kernel(const long long* __restrict__ desc, int D, int chunks) {
+    const long long* d = desc + 7 * (blockIdx.z / chunks);
+    const int chunk = blockIdx.z % chunks;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int set = blockIdx.y;
+    if (c >= D) return;
+    float* dst = reinterpret_cast<float*>(d[2 + set]);
+    if (!dst) return;
+    const float* ws = reinterpret_cast<const float*>(d[0]);
+    const int nblocks = (int)d[1];
+    const int per = (nblocks + chunks - 1) / chunks;
+    const int b0 = chunk * per, b1 = min(nblocks, b0 + per);
+    if (b0 >= b1) return;
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += ws[((size_t)b * LN_SETS + set) * D + c];
+    atomicAdd(dst + c, s);
+}
+
+extern "C" int avs_layernorm_bwd_reduce_batched(const long long* desc, int n, int D, hipStream_t stream) {
+    AVS_CHECK_ARG(desc && n > 0 && n * LN_REDUCE_CHUNKS <= 65535 && D > 0, "layernorm_bwd_reduce_batched: n=%d D=%d", n, D);
+    AVS_CHECK_ARG(!avs_tuning().det, "layernorm_bwd_reduce_batched: not in the deterministic mode (avs_layernorm_bwd reduces per call there)");
+    ln_bwd_reduce_batched_kernel<<<dim3(ceil_div(D, 256), LN_SETS, n * LN_REDUCE_CHUNKS), 256, 0, stream>>>(desc, D, LN_REDUCE_CHUNKS);
+    AVS_LAUNCH_CHECK("layernorm_bwd_reduce_batched");
+    return 0;
+}
+
 // knobs (api.cpp, common.h AvsTuning): ln_dma - 1: the LDS-DMA backward kernel where it applies (default), 0: never (A/B);
 // ln_rpw - rows per wave of the backward kernel: 0 automatic, 4 / 8 / 16 forced (tuning)
 
@@ -483,11 +522,10 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
     AVS_CHECK_ARG(rows > 0 && (D == 512 || D == 768 || D == 1024 || D == 1280), "layernorm_bwd: unsupported rows=%d D=%d", rows, D);
     AVS_CHECK_ARG(dy && x && mean && rstd && g0 && (dx || dx_bf16) && ws, "layernorm_bwd: null pointer");
     AVS_CHECK_ARG(!(dres && dres_bf16 && (const void*)dx_bf16 == dres), "layernorm_bwd: dx_bf16 must not alias a bf16 dres");
-    // A block of 4 waves x RPW rows writes one slab of parameter-gradient partial sums; fewer rows per wave = more blocks
-    // (helps only when 16 rows leave most CUs with a single block) and more slab traffic.
-    int rpw = avs_tuning().ln_rpw;
-    if (rpw != 4 && rpw != 8 && rpw != 16) rpw = rows >= 16384 ? 16 : 8;        // measured (tools/bench_ln.py): 8 wins only on the 8192-row audio tower
+    const int rpw = ln_bwd_rpw(rows);
     const int nblocks = ceil_div(rows, 4 * rpw);
+    // no gradient target at all: the slabs stay in ws for the caller's own reduce (avs_layernorm_bwd_reduce_batched)
+    const bool reduce = dg0 || db0 || dg1 || db1 || dcol;
     dim3 grid(nblocks), block(256);
     // the step's common case - bf16 dy, bf16 residual-gradient stream in, bf16 dx out only - takes the LDS-DMA kernel (D = 1280, round 5: 80 KiB of
     // dynamic LDS, two blocks per CU); AVSIAM_LN_DMA=0: the register-load kernel for everything (A/B)
@@ -515,6 +553,7 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
 #undef LN_DMA
 #undef LN_DMA_
         AVS_LAUNCH_CHECK("layernorm_bwd_dma");
+        if (!reduce) return 0;
         const int chunks_ = avs_tuning().det ? 1 : nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;       // (det: one adder per address)
         ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), LN_SETS, chunks_), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1, dcol);
         AVS_LAUNCH_CHECK("layernorm_bwd_reduce");
@@ -538,6 +577,7 @@ extern "C" int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, con
 #undef LN_BWD
 #undef LN_BWD_R
     AVS_LAUNCH_CHECK("layernorm_bwd");
+    if (!reduce) return 0;
     const int chunks = avs_tuning().det ? 1 : nblocks < LN_REDUCE_CHUNKS ? nblocks : LN_REDUCE_CHUNKS;            // (det: one adder per address)
     ln_bwd_reduce_kernel<<<dim3(ceil_div(D, 256), LN_SETS, chunks), 256, 0, stream>>>(ws, nblocks, D, dg0, db0, dg1, db1, dcol);
     AVS_LAUNCH_CHECK("layernorm_bwd_reduce");

@@ -199,11 +199,44 @@ def _ln_fwd(x, norms, y, mean, rstd, rows, eps, row_mod=None, out_map=None, y8=N
                       row_mod if n1 else None, out_map, y8=y8, q8_dev=q8_dev)
 
 
-def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None, dcol=None, dx8=None, q8=None):
+class _LnBatch:
+    """The LayerNorm backwards of one stack backward with their parameter-gradient reduces deferred to ONE launch (ops.LnReduceBatch): the first
+    backward allocates a slab workspace per call and collects the table, later ones walk the same calls in the same order."""
+
+    def __init__(self, D, dev):
+        self.batch, self.dev, self.k, self.keep = ops.LnReduceBatch(D), dev, 0, None
+
+    def slot(self, rows, n0, n1, dcol):
+        """the workspace of the next LayerNorm backward of this stack backward"""
+        b = self.batch
+        if b.desc is None:
+            ws = _z((ops.layernorm_bwd_slabs(rows) * 5 * b.D,), F32, self.dev)
+            b.add(ws, rows, n0.dg, n0.db, n1.dg if n1 else None, n1.db if n1 else None, dcol)
+        else:
+            assert self.k < len(b.entries), "a stack's backward issued more LayerNorm backwards than its first one"
+        ws = b.keep[self.k][0]
+        self.k += 1
+        return ws
+
+    def finish(self):
+        b = self.batch
+        if b.desc is None:
+            b.build(self.dev)
+        assert self.k == len(b.entries), "a stack's backward issued fewer LayerNorm backwards than its first one"
+        self.k = 0
+        b.run()
+
+
+def _ln_bwd(dy, x, mean, rstd, norms, dx, ws, rows, row_mod=None, out_map=None, dres=None, dx_bf16=None, dcol=None, dx8=None, q8=None, batch=None):
     """dcol: bias gradient of the Linear whose output gradient is the dx produced here (column sum fused in-kernel).
-    dx8 / q8: e5m2 copy of dx for an fp8 input-gradient GEMM and its device record."""
+    dx8 / q8: e5m2 copy of dx for an fp8 input-gradient GEMM and its device record.
+    batch (_LnBatch): the parameter gradients are reduced by the batch's one launch at the end of the stack's backward, not here."""
     n0 = norms[0]
     n1 = norms[1] if len(norms) > 1 else None
+    if batch is not None:
+        ops.layernorm_bwd(dy, x, mean, rstd, n0.g, dx, None, None, batch.slot(rows, n0, n1, dcol), rows, n1.g if n1 else None, None, None,
+                          row_mod if n1 else None, out_map, dres, dx_bf16, None, dx8=dx8, q8=q8, defer=True)
+        return
     ops.layernorm_bwd(dy, x, mean, rstd, n0.g, dx, n0.dg, n0.db, ws, rows, n1.g if n1 else None, n1.dg if n1 else None,
                       n1.db if n1 else None, row_mod if n1 else None, out_map, dres, dx_bf16, dcol, dx8=dx8, q8=q8)
 
@@ -670,9 +703,14 @@ class Stack:
         # the value thirds of the blocks' qkv bias gradients (a [D] x [D, D] product each, below) in ONE launch at the end of the stack's backward instead
         # of one ~10-us launch per block inside it - unless something wants a block's gradients final as it completes (the data-parallel reducer), the
         # gradients accumulate over two passes, or the deterministic forms are asked for
-        vm_batch = None
-        if reducer is None and not accumulate and not det:
+        vm_batch = ln_batch = None
+        if reducer is None and not accumulate and not det and self.opts.batch_reduce:
             key = (id(blocks), id(blocks2), split)
+            lcache = self.__dict__.setdefault("_ln_batches", {})
+            if key not in lcache:
+                lcache[key] = (_LnBatch(self.D, dxo.device), blocks, blocks2)
+            ln_batch = lcache[key][0]
+            ln_batch.k = 0
             cache = self.__dict__.setdefault("_vm_batches", {})
             if key not in cache:
                 vb = ops.VecmatBatch()
@@ -790,7 +828,7 @@ class Stack:
                 d8, q8_ = g8rec(i, "dbm")
                 _ln_bwd(self.dln[lo:], self.xmid[i][lo:], st[2][lo:], st[3][lo:], bl[i].n2, None if g16 else dxm[lo:], self.lnws, hi - lo,
                         None if one else self.row_mod, dres=(dbo if g16 else dxo)[lo:], dx_bf16=dbm[lo:], dcol=bl[i].proj.gb,
-                        dx8=d8[lo:] if d8 is not None else None, q8=q8_)
+                        dx8=d8[lo:] if d8 is not None else None, q8=q8_, batch=ln_batch)
             # proj
             if f8b:
                 self._dgrad_fp8(i, "dbm", "proj", dbm, self.dx8[1], bp.proj, b2.proj if b2 else None, split, self.datt)
@@ -841,8 +879,10 @@ class Stack:
                 d8, q8_ = g8rec(i - 1, "dbo")          # the block below reads this gradient through its fc2 input-gradient GEMM
                 _ln_bwd(self.dln[lo:], self.x[i][lo:], st[0][lo:], st[1][lo:], bl[i].n1, None if g16 and i > 0 else dxo[lo:], self.lnws,
                         hi - lo, None if one else self.row_mod, dres=(self.datt if pruned else dbm if g16 else dxm)[lo:], dx_bf16=dbo[lo:],
-                        dcol=bl[i - 1].fc2.gb if i > 0 else None, dx8=d8[lo:] if d8 is not None else None, q8=q8_)
+                        dcol=bl[i - 1].fc2.gb if i > 0 else None, dx8=d8[lo:] if d8 is not None else None, q8=q8_, batch=ln_batch)
         side.join()
+        if ln_batch is not None:
+            ln_batch.finish()          # (before the value thirds: they read the complete proj bias gradients, which are LayerNorm-2 column sums)
         if vm_batch is not None:
             vm_batch.run()
         for j in reversed(range(self.nblocks)):        # (mode 2 has reported all but block 0 on the way)

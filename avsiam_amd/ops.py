@@ -135,10 +135,41 @@ def layernorm_fwd(x, g0, b0, y, mean, rstd, rows, eps, g1=None, b1=None, row_mod
               float(eps), y8, float(q8), _qrec(q8_dev), _stream())
 
 
+def layernorm_bwd_slabs(rows):
+    """per-block slabs (5 * D floats each) a backward over `rows` rows leaves in its workspace (LnReduceBatch)"""
+    return _lib.load().avs_layernorm_bwd_slabs(int(rows))
+
+
+class LnReduceBatch:
+    """The parameter-gradient reduces of many LayerNorm backwards in ONE launch (avs_layernorm_bwd_reduce_batched): each backward runs with
+    defer=True on a workspace of its own and leaves its per-block partial sums there; run() adds them all to their targets."""
+
+    def __init__(self, D):
+        self.D, self.entries, self.keep, self.desc = D, [], [], None
+
+    def add(self, ws, rows, dg0, db0, dg1=None, db1=None, dcol=None):
+        assert self.desc is None, "table already built"
+        slabs = layernorm_bwd_slabs(rows)
+        _chk(ws, F32, "lnbatch.ws")
+        assert ws.numel() >= slabs * 5 * self.D
+        for t in (dg0, db0, dg1, db1, dcol):
+            _chk(t, F32, "lnbatch.target")
+            assert t is None or t.numel() == self.D
+        self.entries.append([ws.data_ptr(), slabs] + [t.data_ptr() if t is not None else 0 for t in (dg0, db0, dg1, db1, dcol)])
+        self.keep.append((ws, dg0, db0, dg1, db1, dcol))
+
+    def build(self, dev):
+        self.desc = torch.tensor(self.entries, dtype=torch.int64, device=dev)
+
+    def run(self):
+        _call("avs_layernorm_bwd_reduce_batched", self.desc, len(self.entries), self.D, _stream())
+
+
 def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=None, db1=None, row_mod=None,
-                  out_map=None, dres=None, dx_bf16=None, dcol=None, dx8=None, q8=None):
+                  out_map=None, dres=None, dx_bf16=None, dcol=None, dx8=None, q8=None, defer=False):
     """dres: fp32, or bf16 (the residual-gradient stream kept in bf16: the previous call's dx_bf16); dx (fp32) may be None when
-    dx_bf16 is given."""
+    dx_bf16 is given.  defer: the parameter gradients (dg*, db*, dcol) are NOT formed here - the per-block partial sums stay in `ws`
+    (this call's own, layernorm_bwd_slabs(rows) * 5 * D floats) for an LnReduceBatch holding the same targets."""
     D = x.shape[1]
     _chk(dy, dy.dtype if dy.dtype in (BF16, F32) else BF16, "lnb.dy", 2); _chk(x, F32, "lnb.x", 2); _chk(dx, F32, "lnb.dx", 2)
     _chk(dres, dres.dtype if dres is not None and dres.dtype in (BF16, F32) else F32, "lnb.dres", 2)
@@ -154,7 +185,9 @@ def layernorm_bwd(dy, x, mean, rstd, g0, dx, dg0, db0, ws, rows, g1=None, dg1=No
     for t, n in ((g0, "g0"), (g1, "g1"), (dg0, "dg0"), (db0, "db0"), (dg1, "dg1"), (db1, "db1"), (mean, "mean"), (rstd, "rstd")):
         _chk(t, F32, "lnb." + n)
     assert x.shape[0] >= rows and dy.shape[1] == D and (dx is None or (dx.shape[0] >= rows and dx.shape[1] == D))
-    assert ws.numel() >= layernorm_ws(rows, D)
+    assert ws.numel() >= (layernorm_bwd_slabs(rows) * 5 * D if defer else layernorm_ws(rows, D))
+    if defer:
+        dg0 = db0 = dg1 = db1 = dcol = None
     if out_map is None:
         assert dy.shape[0] >= rows
     if dres is not None:

@@ -74,6 +74,12 @@ int avs_layernorm_bwd(const void* dy, int dy_f32, const float* x, const float* m
                       const float* g1, const uint8_t* row_mod, const int* out_map, const void* dres, int dres_bf16, float* dx,
                       avs_bf16* dx_bf16, float* dg0, float* db0, float* dg1, float* db1, float* dcol, float* ws, int rows,
                       int D, uint8_t* dx8, float* q8, avs_stream_t stream);
+/* Deferred parameter-gradient reduce (a stack's LayerNorm backwards: ONE reduce launch at the end of the stack's backward instead of one per
+ * LayerNorm inside it).  avs_layernorm_bwd called with dg0 = db0 = dg1 = db1 = dcol = NULL leaves its per-block partial sums in ws
+ * (avs_layernorm_bwd_slabs(rows) slabs of 5 * D floats; a ws of its own per call); avs_layernorm_bwd_reduce_batched adds n such slab sets to their
+ * targets: desc (device, 7 * n int64) = {ws, slabs, dg0, db0, dg1, db1, dcol} per set, targets may be 0.  Not in the deterministic mode. */
+int avs_layernorm_bwd_slabs(int rows);
+int avs_layernorm_bwd_reduce_batched(const long long* desc, int n, int D, avs_stream_t stream);
 
 /* ---- bf16 MFMA GEMMs (nn.Linear / PatchEmbed.proj and their backward: cav_mae_base.py:51,55,60,77,96-99,138-143,
  * 600,634-635).  nt: x = alpha*(A[M,K].B[N,K]^T + bias [*aux] + res[res_idx? res_idx[m] : m]); act 0: out = x;

@@ -98,6 +98,59 @@ def test_layernorm(D, rows):
         o.layernorm_bwd(dyf, x, mean, rstd, g[0], None, dg[0], db[0], ws, rows, g[1], dg[1], db[1], mod, perm, dres_b, dres_b)
 
 
+@pytest.mark.parametrize("D", [512, 768, 1280])
+def test_layernorm_bwd_deferred_reduce(D):
+    """avs_layernorm_bwd without gradient targets leaves its per-block partial sums in the call's workspace; avs_layernorm_bwd_reduce_batched adds the
+    slabs of MANY such calls to their targets in one launch (engine: one reduce per stack backward instead of one per LayerNorm).  Three calls of
+    different row counts (8- and 16-rows-per-wave block counts, a last block with missing rows), with and without a second affine set and a column-sum
+    target, accumulating onto what the targets hold: dx BITWISE the direct call's, the parameter gradients equal up to the order of the fp32 atomics."""
+    o = ops()
+    calls = []
+    for rows, two, col in ((1000, True, True), (20001, False, True), (16500, True, False)):
+        x = torch.randn(rows, D, device=DEV) * 2 + 0.3
+        mean = x.mean(1).contiguous()
+        rstd = (1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)).contiguous()
+        calls.append(dict(rows=rows, x=x, mean=mean, rstd=rstd, g=[torch.randn(D, device=DEV) * 0.1 + 1 for _ in range(2)],
+                          mod=(torch.rand(rows, device=DEV) > 0.5).to(torch.uint8) if two else None, col=col,
+                          dy=bf(torch.randn(rows, D, device=DEV)), dres=bf(torch.randn(rows, D, device=DEV))))
+
+    def targets():
+        return [[torch.full((D,), 0.5, device=DEV) for _ in range(5)] for _ in calls]       # dg0, db0, dg1, db1, dcol: accumulated onto
+
+    def run(c, t, ws, defer):
+        two = c["mod"] is not None
+        dxb = torch.zeros(c["rows"], D, device=DEV, dtype=torch.bfloat16)
+        o.layernorm_bwd(c["dy"], c["x"], c["mean"], c["rstd"], c["g"][0], None, t[0], t[1], ws, c["rows"], c["g"][1] if two else None, t[2] if two else None,
+                        t[3] if two else None, c["mod"], None, c["dres"], dxb, t[4] if c["col"] else None, defer=defer)
+        return dxb
+
+    want_t = targets()
+    want_dx = [run(c, t, torch.empty(o.layernorm_ws(c["rows"], D), device=DEV), False) for c, t in zip(calls, want_t)]
+    got_t = targets()
+    batch = o.LnReduceBatch(D)
+    wss = []
+    for c, t in zip(calls, got_t):
+        two = c["mod"] is not None
+        wss.append(torch.full((o.layernorm_bwd_slabs(c["rows"]) * 5 * D,), float("nan"), device=DEV))      # exactly the slabs: every one is written
+        batch.add(wss[-1], c["rows"], t[0], t[1], t[2] if two else None, t[3] if two else None, t[4] if c["col"] else None)
+    batch.build(DEV)
+    for rep in range(2):                                          # the table is reused step after step
+        got_dx = [run(c, t, ws, True) for c, t, ws in zip(calls, got_t, wss)]
+        for t in got_t:
+            assert all(float((v - 0.5).abs().max()) == 0.0 for v in t) or rep == 1      # nothing reduced before run()
+        batch.run()
+        for a, b_ in zip(got_dx, want_dx):
+            assert torch.equal(a, b_)
+    for c, gt, wt in zip(calls, got_t, want_t):
+        two = c["mod"] is not None
+        for k in range(5):
+            live = k < 2 or (k < 4 and two) or (k == 4 and c["col"])
+            if live:
+                assert rel_err(gt[k] - 0.5, 2.0 * (wt[k] - 0.5)) < 2e-5, (c["rows"], k)      # two runs of the batch onto the same targets
+            else:
+                assert float((gt[k] - 0.5).abs().max()) == 0.0, (c["rows"], k)
+
+
 @pytest.mark.parametrize("D,rows", [(768, 1000), (768, 20001), (512, 16500), (1024, 777), (1280, 3001), (1280, 17000)])
 def test_layernorm_bwd_dma_kernel(D, rows):
     """The step's common LayerNorm backward - bf16 dy, bf16 residual-gradient stream in, bf16 dx out only - runs the LDS-DMA kernel
